@@ -1,0 +1,54 @@
+"""Build libevoke_hip.so (gfx950) in-tree with hipcc.  `python -m evoke_amd.build`.
+
+The GPU box receives the built .so with the repo snapshot; `evoke_amd.hip` refuses to run without it."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(CSRC, 'obj')
+LIB = os.path.join(HERE, 'libevoke_hip.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function', '-ffp-contract=fast']
+
+
+def _stale(out, deps):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(verbose=False, force=False):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    hdrs.append(os.path.join(os.path.dirname(HERE), 'include', 'evoke_hip.h'))
+    objs, jobs = [], []
+    for s in srcs:
+        o = os.path.join(OBJ, s[:-4] + '.o')
+        objs.append(o)
+        if force or _stale(o, [os.path.join(CSRC, s)] + hdrs):
+            jobs.append([HIPCC] + FLAGS + ['-c', os.path.join(CSRC, s), '-o', o])
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed: %s\n%s\n%s' % (' '.join(cmd), r.stdout, r.stderr))
+        return r.stderr
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        for warn in ex.map(run, jobs):
+            if verbose and warn.strip():
+                print(warn)
+    if jobs or force or _stale(LIB, objs):
+        run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(verbose=True, force='--force' in sys.argv))

@@ -1,0 +1,68 @@
+// common.h -- shared device helpers and host-side launch plumbing for libevoke_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/evoke_hip.h"
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// plain cast -> v_cvt_pk_bf16_f32 (RNE, NaN stays NaN: MI355X_MICROARCH.md "Correctness boundaries")
+__device__ __forceinline__ bf16_t f2bf(float f) { __bf16 b = (__bf16)f; return __builtin_bit_cast(bf16_t, b); }
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ __forceinline__ float lo_bf(uint32_t v) { return __uint_as_float(v << 16); }
+__device__ __forceinline__ float hi_bf(uint32_t v) { return __uint_as_float(v & 0xffff0000u); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float act_apply(float x, int act) {
+  switch (act) {
+    case EVK_ACT_RELU: return fmaxf(x, 0.f);
+    case EVK_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+    case EVK_ACT_TANH: return tanhf(x);
+    case EVK_ACT_SIGMOID: return 1.f / (1.f + __expf(-x));
+    default: return x;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+void evk_set_error(const char* fmt, ...);
+#define EVK_REQUIRE(cond, ...)                \
+  do {                                        \
+    if (!(cond)) {                            \
+      evk_set_error(__VA_ARGS__);             \
+      return EVK_EINVAL;                      \
+    }                                         \
+  } while (0)
+
+// profiling: an event pair around each launch when enabled (bench.py roofline leg)
+void evk_prof_begin(int family, hipStream_t s);
+void evk_prof_end(int family, hipStream_t s, double flops);
+int evk_check_launch(const char* what);
+
+struct ProfScope {
+  int fam; hipStream_t s; double flops;
+  ProfScope(int f, hipStream_t st, double fl = 0.0) : fam(f), s(st), flops(fl) { evk_prof_begin(fam, s); }
+  ~ProfScope() { evk_prof_end(fam, s, flops); }
+};
+
+static inline int ilog2_exact(int64_t v) {
+  int l = 0;
+  while ((int64_t(1) << l) < v) ++l;
+  return ((int64_t(1) << l) == v) ? l : -1;
+}
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

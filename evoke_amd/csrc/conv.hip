@@ -1,0 +1,162 @@
+// conv.hip -- NHWC bf16 convolutions of the ResNet-101 trunk as implicit GEMMs (visual_extractor.py:30-38
+// -> torchvision resnet101 children 0-7) on top of gemm.hip, plus the stem's pack / unpack kernels.
+#include "common.h"
+
+namespace {
+
+bool is_pointwise(const evk_conv_geom* g) {
+  return g->KH == 1 && g->KW == 1 && g->stride_h == 1 && g->stride_w == 1 && g->pad_h == 0 && g->pad_w == 0;
+}
+
+int check_geom(const evk_conv_geom* g) {
+  EVK_REQUIRE(g && g->N > 0 && g->Hi > 0 && g->Wi > 0 && g->Ci > 0 && g->Ho > 0 && g->Wo > 0 && g->Co > 0, "conv: bad geometry");
+  EVK_REQUIRE(g->Ho == (g->Hi + 2 * g->pad_h - g->KH) / g->stride_h + 1 && g->Wo == (g->Wi + 2 * g->pad_w - g->KW) / g->stride_w + 1,
+              "conv: Ho/Wo inconsistent with Hi/Wi, kernel, stride, pad");
+  return EVK_OK;
+}
+
+// images f32 NCHW [N][3][H][W] -> bf16 [N][H+6][W+8][4] with a zero halo (3 left/top, 3 bottom, 5 right) and c=3 zero
+__global__ void stem_pack_image_kernel(const float* __restrict__ img, uint2* __restrict__ out, int N, int H, int W) {
+  const int Hp = H + 6, Wp = W + 8;
+  const long total = (long)N * Hp * Wp;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int xp = (int)(i % Wp);
+    const long t = i / Wp;
+    const int yp = (int)(t % Hp);
+    const int n = (int)(t / Hp);
+    const int x = xp - 3, y = yp - 3;
+    uint2 v = make_uint2(0, 0);
+    if ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) {
+      const long b = ((long)n * 3 * H + y) * W + x;
+      const long cs = (long)H * W;
+      v.x = pack2bf(img[b], img[b + cs]);
+      v.y = pack2bf(img[b + 2 * cs], 0.f);
+    }
+    out[i] = v;
+  }
+}
+
+// w f32 OIHW [64][3][7][7] -> bf16 [64][7][8][4] (kw = 7 and c = 3 are zero)
+__global__ void stem_pack_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 64 * 7 * 8 * 4) return;
+  const int c = i & 3, kw = (i >> 2) & 7, kh = (i >> 5) % 7, co = i / 224;
+  float v = 0.f;
+  if (c < 3 && kw < 7) v = w[((co * 3 + c) * 7 + kh) * 7 + kw];
+  out[i] = f2bf(v);
+}
+
+// dw_packed f32 [64][7][8][4] -> += into OIHW f32 grad [64][3][7][7]
+__global__ void stem_unpack_wgrad_kernel(const float* __restrict__ dwp, float* __restrict__ dw) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 64 * 3 * 7 * 7) return;
+  const int kw = i % 7, kh = (i / 7) % 7, c = (i / 49) % 3, co = i / 147;
+  dw[i] += dwp[((co * 7 + kh) * 8 + kw) * 4 + c];
+}
+
+void stem_geom(evk_conv_geom* g, int N, int H, int W) {
+  const int Hp = H + 6, Wp = W + 8;
+  g->N = N; g->Hi = Hp; g->Wi = W / 2; g->Ci = 32;
+  g->Ho = H / 2; g->Wo = W / 2; g->Co = 64;
+  g->KH = 7; g->KW = 1; g->stride_h = 2; g->stride_w = 1; g->pad_h = 0; g->pad_w = 0;
+  g->sN = (int64_t)Hp * Wp * 4; g->sH = (int64_t)Wp * 4; g->sW = 8;
+}
+
+}  // namespace
+
+extern "C" {
+
+int evk_conv2d_fwd(const void* x, const void* w, void* y, const evk_conv_geom* g, evk_stream_t stream) {
+  if (int e = check_geom(g)) return e;
+  evk_gemm d{};
+  d.A = x; d.B = w; d.C = y;
+  d.M = g->N * g->Ho * g->Wo; d.N = g->Co; d.K = g->KH * g->KW * g->Ci;
+  d.a_mode = is_pointwise(g) ? EVK_A_PLAIN : EVK_A_CONV; d.b_mode = EVK_B_PLAIN;
+  d.lda = g->Ci; d.ldb = d.K; d.ldc = g->Co;
+  d.batch_outer = d.batch_inner = 1; d.alpha = 1.f; d.c_dtype = EVK_BF16;
+  d.g = *g;
+  d.g.sN = (int64_t)g->Hi * g->Wi * g->Ci; d.g.sH = (int64_t)g->Wi * g->Ci; d.g.sW = g->Ci;
+  return evk_gemm_launch(&d, stream);
+}
+
+int evk_conv2d_dgrad(const void* dy, const void* w, void* dx, const evk_conv_geom* g, evk_stream_t stream) {
+  if (int e = check_geom(g)) return e;
+  const int T = g->KH * g->KW;
+  EVK_REQUIRE(ilog2_exact(g->Co) >= 3, "conv dgrad: Co must be a power of two >= 8");
+  evk_gemm d{};
+  d.A = dy; d.B = w; d.C = dx;
+  d.M = g->N * g->Hi * g->Wi; d.N = g->Ci; d.K = T * g->Co;
+  d.a_mode = is_pointwise(g) ? EVK_A_PLAIN : EVK_A_DGRAD; d.b_mode = EVK_B_KSTR;
+  d.lda = g->Co; d.ldb = (int64_t)T * g->Ci; d.ldc = g->Ci;
+  d.b_klog = ilog2_exact(g->Co); d.b_tapstride = g->Ci;
+  d.batch_outer = d.batch_inner = 1; d.alpha = 1.f; d.c_dtype = EVK_BF16;
+  d.g = *g;
+  return evk_gemm_launch(&d, stream);
+}
+
+int evk_conv2d_wgrad(const void* dy, const void* x, float* dw, const evk_conv_geom* g, evk_stream_t stream) {
+  if (int e = check_geom(g)) return e;
+  const int T = g->KH * g->KW;
+  evk_gemm d{};
+  d.A = dy; d.B = x; d.C = dw;
+  d.M = g->Co; d.N = g->Ci; d.K = g->N * g->Ho * g->Wo;
+  d.a_mode = EVK_A_KSTR; d.lda = g->Co;
+  d.ldc = (int64_t)T * g->Ci; d.sCi = g->Ci;
+  d.batch_outer = 1; d.batch_inner = T; d.alpha = 1.f; d.c_dtype = EVK_F32; d.accumulate = 1;
+  d.g = *g;
+  if (is_pointwise(g)) { d.b_mode = EVK_B_KSTR; d.ldb = g->Ci; }
+  else {
+    d.b_mode = EVK_B_WGATHER;
+    d.g.sN = (int64_t)g->Hi * g->Wi * g->Ci; d.g.sH = (int64_t)g->Wi * g->Ci; d.g.sW = g->Ci;
+  }
+  return evk_gemm_launch(&d, stream);
+}
+
+int evk_stem_pack_image(const float* img, void* xpad, int32_t N, int32_t H, int32_t W, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(img && xpad && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "stem_pack_image: bad args");
+  const long total = (long)N * (H + 6) * (W + 8);
+  const int blocks = (int)(cdiv(total, 256) < 4096 ? cdiv(total, 256) : 4096);
+  ProfScope ps(EVK_FAM_ELTWISE, s);
+  hipLaunchKernelGGL(stem_pack_image_kernel, dim3(blocks), dim3(256), 0, s, img, (uint2*)xpad, N, H, W);
+  return evk_check_launch("stem_pack_image");
+}
+
+int evk_stem_pack_weight(const float* w, void* wp, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(w && wp, "stem_pack_weight: null");
+  hipLaunchKernelGGL(stem_pack_weight_kernel, dim3(56), dim3(256), 0, s, w, (bf16_t*)wp);
+  return evk_check_launch("stem_pack_weight");
+}
+
+int evk_stem_unpack_wgrad(const float* dwp, float* dw, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(dwp && dw, "stem_unpack_wgrad: null");
+  hipLaunchKernelGGL(stem_unpack_wgrad_kernel, dim3(37), dim3(256), 0, s, dwp, dw);
+  return evk_check_launch("stem_unpack_wgrad");
+}
+
+int evk_stem_fwd(const void* xpad, const void* wp, void* y, int32_t N, int32_t H, int32_t W, evk_stream_t stream) {
+  EVK_REQUIRE(H % 2 == 0 && W % 2 == 0, "stem: H and W must be even");
+  evk_gemm d{};
+  stem_geom(&d.g, N, H, W);
+  d.A = xpad; d.B = wp; d.C = y;
+  d.M = N * d.g.Ho * d.g.Wo; d.N = 64; d.K = 224;
+  d.a_mode = EVK_A_CONV; d.b_mode = EVK_B_PLAIN; d.ldb = 224; d.ldc = 64;
+  d.batch_outer = d.batch_inner = 1; d.alpha = 1.f; d.c_dtype = EVK_BF16;
+  return evk_gemm_launch(&d, stream);
+}
+
+int evk_stem_wgrad(const void* dy, const void* xpad, float* dwp, int32_t N, int32_t H, int32_t W, evk_stream_t stream) {
+  EVK_REQUIRE(H % 2 == 0 && W % 2 == 0, "stem: H and W must be even");
+  evk_gemm d{};
+  stem_geom(&d.g, N, H, W);
+  d.A = dy; d.B = xpad; d.C = dwp;
+  d.M = 64; d.N = 32; d.K = N * d.g.Ho * d.g.Wo;
+  d.a_mode = EVK_A_KSTR; d.lda = 64; d.b_mode = EVK_B_WGATHER;
+  d.ldc = 224; d.sCi = 32; d.batch_outer = 1; d.batch_inner = 7;
+  d.alpha = 1.f; d.c_dtype = EVK_F32; d.accumulate = 1;
+  return evk_gemm_launch(&d, stream);
+}
+
+}  // extern "C"

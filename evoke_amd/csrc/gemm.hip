@@ -1,0 +1,467 @@
+// gemm.hip -- the MFMA GEMM / implicit-GEMM kernel family of libevoke_hip.so (gfx950).
+//
+// One templated kernel computes C[m][n] = act(alpha * sum_k A(m,k) * B(n,k) + bias[n]) + resid[m][n]
+// for bf16 operands with f32 accumulation on v_mfma_f32_16x16x32_bf16.  The operand "loaders" differ
+// by addressing mode so the same main loop serves nn.Linear forward / dX / dW, batched attention
+// products, and the NHWC convolutions of the ResNet-101 trunk (forward = implicit im2col gather,
+// data-gradient = gather from dY, weight-gradient = K-strided gather with split-K + f32 atomics).
+//
+// Tile: (64*WM) x (64*WN) x 64, 4 waves (256 threads), each wave a 64x64 sub-tile = 4x4 MFMA tiles.
+// LDS image per operand: [row][64 k] bf16 = 128-byte rows, 16-byte chunk index XOR (row & 7): the
+// ds_read_b128 fragment reads are bank-conflict free (cdna_hip_programming.md T2).  Register-staged
+// double buffering: global loads of K-tile t+1 are issued before the MFMAs of tile t and written to the
+// other LDS buffer after them (one barrier per K-tile).
+// MFMA orientation is swapped (weights tile as the "A" operand) so each lane ends up with 4 consecutive
+// n of one row m -> 8/16-byte epilogue stores.
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 64;
+constexpr int NTHR = 256;
+
+struct GemmP {
+  const bf16_t* A; const bf16_t* B; void* C; const float* bias; const void* resid;
+  int M, N, K;
+  long lda, ldb, ldc, ldr;
+  int bi;
+  long sAo, sAi, sBo, sBi, sCo, sCi, sRo, sRi;
+  float alpha; int act, c_f32, r_f32, accumulate, vec_ok;
+  int ksteps_per_split, tilesN;
+  int b_klog, b_kmask; long b_tapstride;
+  // gather geometry
+  int Hi, Wi, Ho, Wo, KH, KW, sh, sw, ph, pw, lgs;
+  int lgC, Cg;       // channels of the gathered tensor (power of two)
+  int rows_per_img, row_w;  // decomposition of the GEMM row (A_CONV: Ho*Wo, Wo; A_DGRAD: Hi*Wi, Wi)
+  long sN, sH, sW;
+};
+
+// ------------------------------------------------------------------------------------------------
+// K-contiguous loaders (PLAIN / CONV / DGRAD): thread -> row (tid>>3)+32i, 16-byte chunk kc = tid&7
+// ------------------------------------------------------------------------------------------------
+template <int ROWS, int MODE>
+struct RowLoader {
+  static constexpr int NI = ROWS / 32;
+  static constexpr int NREG = NI * 4;
+  const bf16_t* base;
+  long off[NI];
+  int y0[NI], x0[NI];
+  bool ok[NI];
+
+  __device__ __forceinline__ void init(const GemmP& p, const bf16_t* b, long ld, int row0, int nrows, int tid) {
+    base = b;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int r = row0 + (tid >> 3) + 32 * i;
+      ok[i] = r < nrows;
+      const int rr = ok[i] ? r : 0;
+      if constexpr (MODE == EVK_A_PLAIN) {
+        off[i] = (long)rr * ld;
+        y0[i] = x0[i] = 0;
+      } else {
+        const int n = rr / p.rows_per_img;
+        const int rem = rr - n * p.rows_per_img;
+        const int yy = rem / p.row_w;
+        const int xx = rem - yy * p.row_w;
+        if constexpr (MODE == EVK_A_CONV) {
+          off[i] = (long)n * p.sN;
+          y0[i] = yy * p.sh - p.ph;
+          x0[i] = xx * p.sw - p.pw;
+        } else {  // DGRAD: gather from dY [N][Ho][Wo][Cg]
+          off[i] = (long)n * p.Ho * p.Wo * p.Cg;
+          y0[i] = yy + p.ph;
+          x0[i] = xx + p.pw;
+        }
+      }
+    }
+  }
+
+  __device__ __forceinline__ void load(const GemmP& p, int k0, int kend, int tid, uint4 (&v)[NI]) const {
+    const int k = k0 + (tid & 7) * 8;
+    const bool kin = k < kend;
+    if constexpr (MODE == EVK_A_PLAIN) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        if (ok[i] && kin) v[i] = *reinterpret_cast<const uint4*>(base + off[i] + k);
+        else v[i] = make_uint4(0, 0, 0, 0);
+      }
+    } else {
+      const int tap = k >> p.lgC;
+      const int c = k & (p.Cg - 1);
+      const int kh = tap / p.KW;
+      const int kw = tap - kh * p.KW;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        bool valid = ok[i] && kin;
+        long a;
+        if constexpr (MODE == EVK_A_CONV) {
+          const int ih = y0[i] + kh, iw = x0[i] + kw;
+          valid = valid && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+          a = off[i] + (long)ih * p.sH + (long)iw * p.sW + c;
+        } else {
+          const int th = y0[i] - kh, tw = x0[i] - kw;
+          const int m = (1 << p.lgs) - 1;
+          valid = valid && th >= 0 && tw >= 0 && !(th & m) && !(tw & m);
+          const int oh = th >> p.lgs, ow = tw >> p.lgs;
+          valid = valid && oh < p.Ho && ow < p.Wo;
+          a = off[i] + ((long)oh * p.Wo + ow) * p.Cg + c;
+        }
+        if (valid) v[i] = *reinterpret_cast<const uint4*>(base + a);
+        else v[i] = make_uint4(0, 0, 0, 0);
+      }
+    }
+  }
+
+  __device__ __forceinline__ void store(char* lds, int tid, const uint4 (&v)[NI]) const {
+    const int rl = tid >> 3;
+    char* d = lds + rl * 128 + (((tid & 7) ^ (rl & 7)) << 4);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) *reinterpret_cast<uint4*>(d + i * 4096) = v[i];
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// K-strided loaders (KSTR / WGATHER): a task = 2 adjacent rows x 8 consecutive k (eight 4-byte loads),
+// transposed in registers into two 16-byte K-contiguous chunks when written to LDS.
+// ------------------------------------------------------------------------------------------------
+template <int ROWS, int MODE>  // MODE: 0 = plain/2-level K-strided, 1 = conv weight-gradient gather
+struct KstrLoader {
+  static constexpr int NI = ROWS / 64;
+  static constexpr int HALF = ROWS / 2;
+  static constexpr int KG_STEP = NTHR / HALF;
+  const bf16_t* ptr;
+  long ld, tapstride;
+  bool rok;
+  int kh, kw, klog, kmask;
+
+  __device__ __forceinline__ void init(const GemmP& p, const bf16_t* b, long ld_, int row0, int nrows, int tid, int tap,
+                                       bool two_level) {
+    const int r0 = row0 + 2 * (tid % HALF);
+    rok = r0 < nrows;
+    ptr = b + (rok ? r0 : 0);
+    ld = ld_;
+    kh = tap / p.KW;
+    kw = tap - kh * p.KW;
+    klog = two_level ? p.b_klog : 30;
+    kmask = two_level ? p.b_kmask : 0x7fffffff;
+    tapstride = two_level ? p.b_tapstride : 0;
+  }
+
+  __device__ __forceinline__ void load(const GemmP& p, int k0, int kend, int tid, uint32_t (&v)[NI][8]) const {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int kb = k0 + (tid / HALF + i * KG_STEP) * 8;
+      if constexpr (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = kb + j;
+          const long a = (long)(k & kmask) * ld + (long)(k >> klog) * tapstride;
+          v[i][j] = (rok && k < kend) ? *reinterpret_cast<const uint32_t*>(ptr + a) : 0u;
+        }
+      } else {
+        int n = kb / p.rows_per_img;
+        int rem = kb - n * p.rows_per_img;
+        int oh = rem / p.row_w;
+        int ow = rem - oh * p.row_w;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int ih = oh * p.sh - p.ph + kh, iw = ow * p.sw - p.pw + kw;
+          const bool valid = rok && (kb + j) < kend && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+          const long a = (long)n * p.sN + (long)ih * p.sH + (long)iw * p.sW;
+          v[i][j] = valid ? *reinterpret_cast<const uint32_t*>(ptr + a) : 0u;
+          if (++ow == p.row_w) { ow = 0; if (++oh == p.Ho) { oh = 0; ++n; } }
+        }
+      }
+    }
+  }
+
+  __device__ __forceinline__ void store(char* lds, int tid, const uint32_t (&v)[NI][8]) const {
+    const int ra = 2 * (tid % HALF), rb = ra + 1;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int kg = tid / HALF + i * KG_STEP;
+      uint4 lo, hi;
+      lo.x = (v[i][0] & 0xffffu) | (v[i][1] << 16);
+      lo.y = (v[i][2] & 0xffffu) | (v[i][3] << 16);
+      lo.z = (v[i][4] & 0xffffu) | (v[i][5] << 16);
+      lo.w = (v[i][6] & 0xffffu) | (v[i][7] << 16);
+      hi.x = (v[i][0] >> 16) | (v[i][1] & 0xffff0000u);
+      hi.y = (v[i][2] >> 16) | (v[i][3] & 0xffff0000u);
+      hi.z = (v[i][4] >> 16) | (v[i][5] & 0xffff0000u);
+      hi.w = (v[i][6] >> 16) | (v[i][7] & 0xffff0000u);
+      *reinterpret_cast<uint4*>(lds + ra * 128 + ((kg ^ (ra & 7)) << 4)) = lo;
+      *reinterpret_cast<uint4*>(lds + rb * 128 + ((kg ^ (rb & 7)) << 4)) = hi;
+    }
+  }
+};
+
+template <int ROWS, int MODE, bool IS_A> struct LoaderSel;
+template <int ROWS> struct LoaderSel<ROWS, EVK_A_PLAIN, true> { using T = RowLoader<ROWS, EVK_A_PLAIN>; static constexpr bool KS = false; };
+template <int ROWS> struct LoaderSel<ROWS, EVK_A_CONV, true> { using T = RowLoader<ROWS, EVK_A_CONV>; static constexpr bool KS = false; };
+template <int ROWS> struct LoaderSel<ROWS, EVK_A_DGRAD, true> { using T = RowLoader<ROWS, EVK_A_DGRAD>; static constexpr bool KS = false; };
+template <int ROWS> struct LoaderSel<ROWS, EVK_A_KSTR, true> { using T = KstrLoader<ROWS, 0>; static constexpr bool KS = true; };
+template <int ROWS> struct LoaderSel<ROWS, EVK_B_PLAIN, false> { using T = RowLoader<ROWS, EVK_A_PLAIN>; static constexpr bool KS = false; };
+template <int ROWS> struct LoaderSel<ROWS, EVK_B_KSTR, false> { using T = KstrLoader<ROWS, 0>; static constexpr bool KS = true; };
+template <int ROWS> struct LoaderSel<ROWS, EVK_B_WGATHER, false> { using T = KstrLoader<ROWS, 1>; static constexpr bool KS = true; };
+
+template <int WM, int WN, int AMODE, int BMODE>
+__global__ __launch_bounds__(NTHR) void gemm_kernel(const GemmP p) {
+  constexpr int TM = 64 * WM, TN = 64 * WN;
+  constexpr int TILE_BYTES = (TM + TN) * BK * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+
+  // XCD-aware bijective remap (cdna_hip_programming.md T1): blocks b, b+8, ... share an XCD/L2, give
+  // each XCD a contiguous run of tiles so neighbouring tiles re-use the same operand panels in L2.
+  int wg;
+  {
+    const int bid = blockIdx.x, nwg = gridDim.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = wg / p.tilesN, tn = wg - tm * p.tilesN;
+  const int zo = blockIdx.z / p.bi, zi = blockIdx.z - zo * p.bi;
+  const int k_begin = blockIdx.y * p.ksteps_per_split * BK;
+  const int k_end = min(p.K, k_begin + p.ksteps_per_split * BK);
+  if (k_begin >= k_end) return;
+
+  using LA = typename LoaderSel<TM, AMODE, true>::T;
+  using LB = typename LoaderSel<TN, BMODE, false>::T;
+  constexpr bool AKS = LoaderSel<TM, AMODE, true>::KS;
+  constexpr bool BKS = LoaderSel<TN, BMODE, false>::KS;
+  LA la;
+  LB lb;
+  const bf16_t* Ab = p.A + zo * p.sAo + zi * p.sAi;
+  const bf16_t* Bb = p.B + zo * p.sBo + zi * p.sBi;
+  if constexpr (AKS) la.init(p, Ab, p.lda, tm * TM, p.M, tid, 0, false);
+  else la.init(p, Ab, p.lda, tm * TM, p.M, tid);
+  if constexpr (BKS) lb.init(p, Bb, p.ldb, tn * TN, p.N, tid, zi, true);
+  else lb.init(p, Bb, p.ldb, tn * TN, p.N, tid);
+
+  typename std::conditional<AKS, uint32_t[LA::NI][8], uint4[LA::NI]>::type ra;
+  typename std::conditional<BKS, uint32_t[LB::NI][8], uint4[LB::NI]>::type rb;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int frow = lane & 15, fq = lane >> 4;
+
+  la.load(p, k_begin, k_end, tid, ra);
+  lb.load(p, k_begin, k_end, tid, rb);
+  la.store(smem, tid, ra);
+  lb.store(smem + TM * 128, tid, rb);
+  __syncthreads();
+
+  int buf = 0;
+  for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+    const bool more = (k0 + BK) < k_end;
+    if (more) {
+      la.load(p, k0 + BK, k_end, tid, ra);
+      lb.load(p, k0 + BK, k_end, tid, rb);
+    }
+    const char* As = smem + buf * TILE_BYTES;
+    const char* Bs = As + TM * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wm * 64 + i * 16 + frow;
+        af[i] = *reinterpret_cast<const bf16x8*>(As + row * 128 + (((ks * 4 + fq) ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wn * 64 + i * 16 + frow;
+        bfr[i] = *reinterpret_cast<const bf16x8*>(Bs + row * 128 + (((ks * 4 + fq) ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int in = 0; in < 4; ++in)
+#pragma unroll
+        for (int im = 0; im < 4; ++im)
+          acc[in][im] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[in], af[im], acc[in][im], 0, 0, 0);
+    }
+    if (more) {
+      char* nxt = smem + (buf ^ 1) * TILE_BYTES;
+      la.store(nxt, tid, ra);
+      lb.store(nxt + TM * 128, tid, rb);
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---- epilogue: lane holds C[m][n0..n0+3], m = ..+(lane&15), n0 = ..+(lane>>4)*4 -------------------
+  char* Cb = reinterpret_cast<char*>(p.C) + (zo * p.sCo + zi * p.sCi) * (p.c_f32 ? 4 : 2);
+  const char* Rb = p.resid ? reinterpret_cast<const char*>(p.resid) + (zo * p.sRo + zi * p.sRi) * (p.r_f32 ? 4 : 2) : nullptr;
+#pragma unroll
+  for (int im = 0; im < 4; ++im) {
+    const int m = tm * TM + wm * 64 + im * 16 + frow;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int in = 0; in < 4; ++in) {
+      const int n0 = tn * TN + wn * 64 + in * 16 + fq * 4;
+      if (n0 >= p.N) continue;
+      float v[4] = {acc[in][im][0] * p.alpha, acc[in][im][1] * p.alpha, acc[in][im][2] * p.alpha, acc[in][im][3] * p.alpha};
+      const bool full = p.vec_ok && (n0 + 3 < p.N);
+      if (p.accumulate) {
+        float* c = reinterpret_cast<float*>(Cb) + (long)m * p.ldc + n0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (n0 + j < p.N) unsafeAtomicAdd(c + j, v[j]);
+        continue;
+      }
+      if (p.bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (n0 + j < p.N) v[j] += p.bias[n0 + j];
+      }
+      if (p.act != EVK_ACT_NONE) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], p.act);
+      }
+      if (Rb) {
+        if (p.r_f32) {
+          const float* r = reinterpret_cast<const float*>(Rb) + (long)m * p.ldr + n0;
+          if (full) { const float4 t = *reinterpret_cast<const float4*>(r); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+          else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (n0 + j < p.N) v[j] += r[j];
+          }
+        } else {
+          const bf16_t* r = reinterpret_cast<const bf16_t*>(Rb) + (long)m * p.ldr + n0;
+          if (full) { const uint2 t = *reinterpret_cast<const uint2*>(r); v[0] += lo_bf(t.x); v[1] += hi_bf(t.x); v[2] += lo_bf(t.y); v[3] += hi_bf(t.y); }
+          else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (n0 + j < p.N) v[j] += bf2f(r[j]);
+          }
+        }
+      }
+      if (p.c_f32) {
+        float* c = reinterpret_cast<float*>(Cb) + (long)m * p.ldc + n0;
+        if (full) *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (n0 + j < p.N) c[j] = v[j];
+        }
+      } else {
+        bf16_t* c = reinterpret_cast<bf16_t*>(Cb) + (long)m * p.ldc + n0;
+        if (full) *reinterpret_cast<uint2*>(c) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (n0 + j < p.N) c[j] = f2bf(v[j]);
+        }
+      }
+    }
+  }
+}
+
+template <int WM, int WN, int AMODE, int BMODE>
+int launch_cfg(const GemmP& p, dim3 grid, hipStream_t s) {
+  constexpr int LDS = 2 * (64 * WM + 64 * WN) * BK * 2;
+  static bool attr_done = false;
+  auto kern = gemm_kernel<WM, WN, AMODE, BMODE>;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(NTHR), LDS, s, p);
+  return evk_check_launch("gemm_kernel");
+}
+
+template <int AMODE, int BMODE>
+int launch_modes(GemmP& p, int batch, int splitk_req, hipStream_t s) {
+  const bool narrow = p.N <= 64;
+  const int TM = narrow ? 256 : 128, TN = narrow ? 64 : 128;
+  const int tilesM = (int)cdiv(p.M, TM);
+  p.tilesN = (int)cdiv(p.N, TN);
+  const int ksteps = (int)cdiv(p.K, BK);
+  int splitk = 1;
+  if (p.accumulate) {
+    const long tiles = (long)tilesM * p.tilesN * batch;
+    splitk = splitk_req > 0 ? splitk_req : (int)cdiv(1024, tiles);
+    if (splitk > ksteps) splitk = ksteps;
+    if (splitk < 1) splitk = 1;
+  }
+  p.ksteps_per_split = (int)cdiv(ksteps, splitk);
+  splitk = (int)cdiv(ksteps, p.ksteps_per_split);
+  dim3 grid(tilesM * p.tilesN, splitk, batch);
+  if (narrow) return launch_cfg<4, 1, AMODE, BMODE>(p, grid, s);
+  return launch_cfg<2, 2, AMODE, BMODE>(p, grid, s);
+}
+
+inline bool al(const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+}  // namespace
+
+extern "C" int evk_gemm_launch(const evk_gemm* d, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(d && d->A && d->B && d->C, "evk_gemm: null operand");
+  EVK_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "evk_gemm: bad dims M=%d N=%d K=%d", d->M, d->N, d->K);
+  EVK_REQUIRE(d->batch_outer >= 1 && d->batch_inner >= 1 && (long)d->batch_outer * d->batch_inner <= 65535,
+              "evk_gemm: bad batch %d x %d", d->batch_outer, d->batch_inner);
+  GemmP p{};
+  p.A = (const bf16_t*)d->A; p.B = (const bf16_t*)d->B; p.C = d->C; p.bias = d->bias; p.resid = d->resid;
+  p.M = d->M; p.N = d->N; p.K = d->K;
+  p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldr = d->ldr;
+  p.bi = d->batch_inner;
+  p.sAo = d->sAo; p.sAi = d->sAi; p.sBo = d->sBo; p.sBi = d->sBi; p.sCo = d->sCo; p.sCi = d->sCi; p.sRo = d->sRo; p.sRi = d->sRi;
+  p.alpha = d->alpha; p.act = d->act; p.c_f32 = d->c_dtype == EVK_F32; p.r_f32 = d->r_dtype == EVK_F32;
+  p.accumulate = d->accumulate;
+  EVK_REQUIRE(!p.accumulate || (p.c_f32 && !d->bias && !d->resid && d->act == EVK_ACT_NONE),
+              "evk_gemm: accumulate needs f32 C and no bias/resid/act");
+  const int esz = p.c_f32 ? 4 : 2;
+  p.vec_ok = (d->ldc % 4 == 0) && al(d->C, 4 * esz) && (d->sCo % 4 == 0) && (d->sCi % 4 == 0) &&
+             (!d->resid || ((d->ldr % 4 == 0) && al(d->resid, p.r_f32 ? 16 : 8) && (d->sRo % 4 == 0) && (d->sRi % 4 == 0)));
+  const evk_conv_geom& g = d->g;
+  const bool gather = d->a_mode == EVK_A_CONV || d->a_mode == EVK_A_DGRAD || d->b_mode == EVK_B_WGATHER;
+  if (gather) {
+    p.Hi = g.Hi; p.Wi = g.Wi; p.Ho = g.Ho; p.Wo = g.Wo; p.KH = g.KH; p.KW = g.KW;
+    p.sh = g.stride_h; p.sw = g.stride_w; p.ph = g.pad_h; p.pw = g.pad_w;
+    p.sN = g.sN; p.sH = g.sH; p.sW = g.sW;
+    EVK_REQUIRE(g.KH >= 1 && g.KW >= 1 && g.stride_h >= 1 && g.stride_w >= 1, "evk_gemm: bad conv geometry");
+    if (d->a_mode == EVK_A_DGRAD) {
+      p.Cg = g.Co; p.rows_per_img = g.Hi * g.Wi; p.row_w = g.Wi;
+      EVK_REQUIRE(g.stride_h == g.stride_w && (g.stride_h == 1 || g.stride_h == 2), "dgrad: stride must be 1 or 2");
+      p.lgs = g.stride_h == 2 ? 1 : 0;
+    } else {
+      p.Cg = g.Ci; p.rows_per_img = g.Ho * g.Wo; p.row_w = g.Wo;
+    }
+    p.lgC = ilog2_exact(p.Cg);
+    EVK_REQUIRE(p.lgC >= 3, "evk_gemm: gathered channel count %d must be a power of two >= 8", p.Cg);
+    EVK_REQUIRE(g.sW % 2 == 0 && g.sH % 2 == 0 && g.sN % 2 == 0, "evk_gemm: gather strides must be even");
+  } else {
+    p.KW = 1; p.KH = 1;
+  }
+  // alignment rules of the loaders
+  EVK_REQUIRE(al(d->A, 16) && al(d->B, 16), "evk_gemm: operands must be 16-byte aligned");
+  if (d->a_mode == EVK_A_PLAIN) EVK_REQUIRE(d->K % 8 == 0 && d->lda % 8 == 0 && d->sAo % 8 == 0 && d->sAi % 8 == 0, "A_PLAIN: K, lda, batch strides must be multiples of 8 (K=%d lda=%ld)", d->K, (long)d->lda);
+  if (d->a_mode == EVK_A_CONV || d->a_mode == EVK_A_DGRAD) EVK_REQUIRE(d->K % 8 == 0, "A gather: K %% 8");
+  if (d->a_mode == EVK_A_CONV) EVK_REQUIRE(g.sW % 8 == 0 && g.sH % 8 == 0 && g.sN % 8 == 0, "A_CONV: strides %% 8");
+  if (d->a_mode == EVK_A_KSTR) EVK_REQUIRE(d->lda % 2 == 0 && d->sAo % 2 == 0 && d->sAi % 2 == 0 && (d->M % 2 == 0 || d->lda > d->M), "A_KSTR: lda even and padded (M=%d lda=%ld)", d->M, (long)d->lda);
+  if (d->b_mode == EVK_B_PLAIN) EVK_REQUIRE(d->K % 8 == 0 && d->ldb % 8 == 0 && d->sBo % 8 == 0 && d->sBi % 8 == 0, "B_PLAIN: K, ldb, batch strides must be multiples of 8 (K=%d ldb=%ld)", d->K, (long)d->ldb);
+  if (d->b_mode == EVK_B_KSTR) {
+    EVK_REQUIRE(d->ldb % 2 == 0 && d->sBo % 2 == 0 && d->sBi % 2 == 0 && d->b_tapstride % 2 == 0 && (d->N % 2 == 0 || d->ldb > d->N), "B_KSTR: ldb even and padded (N=%d ldb=%ld)", d->N, (long)d->ldb);
+    p.b_klog = d->b_klog > 0 ? d->b_klog : 30;
+    p.b_kmask = d->b_klog > 0 ? ((1 << d->b_klog) - 1) : 0x7fffffff;
+    p.b_tapstride = d->b_tapstride;
+  }
+  if (d->b_mode != EVK_B_KSTR) { p.b_klog = 30; p.b_kmask = 0x7fffffff; p.b_tapstride = 0; }
+  if (d->b_mode == EVK_B_WGATHER) EVK_REQUIRE(d->N % 2 == 0, "B_WGATHER: N even");
+
+  const int batch = d->batch_outer * d->batch_inner;
+  const double flops = 2.0 * d->M * (double)d->N * d->K * batch;
+  ProfScope ps(EVK_FAM_GEMM, s, flops);
+  const int am = d->a_mode, bm = d->b_mode;
+  if (am == EVK_A_PLAIN && bm == EVK_B_PLAIN) return launch_modes<EVK_A_PLAIN, EVK_B_PLAIN>(p, batch, d->splitk, s);
+  if (am == EVK_A_CONV && bm == EVK_B_PLAIN) return launch_modes<EVK_A_CONV, EVK_B_PLAIN>(p, batch, d->splitk, s);
+  if (am == EVK_A_PLAIN && bm == EVK_B_KSTR) return launch_modes<EVK_A_PLAIN, EVK_B_KSTR>(p, batch, d->splitk, s);
+  if (am == EVK_A_DGRAD && bm == EVK_B_KSTR) return launch_modes<EVK_A_DGRAD, EVK_B_KSTR>(p, batch, d->splitk, s);
+  if (am == EVK_A_KSTR && bm == EVK_B_KSTR) return launch_modes<EVK_A_KSTR, EVK_B_KSTR>(p, batch, d->splitk, s);
+  if (am == EVK_A_KSTR && bm == EVK_B_WGATHER) return launch_modes<EVK_A_KSTR, EVK_B_WGATHER>(p, batch, d->splitk, s);
+  evk_set_error("evk_gemm: unsupported mode pair a=%d b=%d", am, bm);
+  return EVK_EUNSUPPORTED;
+}

@@ -1,0 +1,93 @@
+"""ctypes binding of libevoke_hip.so (the C ABI in include/evoke_hip.h).
+
+The product path has NO fallback: importing this module without the built library raises, and every
+entry point raises RuntimeError with evk_last_error() on a non-zero status."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libevoke_hip.so')
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+A_PLAIN, A_CONV, A_DGRAD, A_KSTR = 0, 1, 2, 3
+B_PLAIN, B_KSTR, B_WGATHER = 0, 1, 2
+FAMILIES = ('gemm', 'norm', 'eltwise', 'reduce', 'optim')
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('N', 'Hi', 'Wi', 'Ci', 'Ho', 'Wo', 'Co', 'KH', 'KW', 'stride_h', 'stride_w',
+                                         'pad_h', 'pad_w')] + [(n, C.c_int64) for n in ('sN', 'sH', 'sW')]
+
+
+class Gemm(C.Structure):
+    _fields_ = [('A', C.c_void_p), ('B', C.c_void_p), ('C', C.c_void_p), ('bias', C.c_void_p), ('resid', C.c_void_p),
+                ('M', C.c_int32), ('N', C.c_int32), ('K', C.c_int32), ('a_mode', C.c_int32), ('b_mode', C.c_int32),
+                ('lda', C.c_int64), ('ldb', C.c_int64), ('ldc', C.c_int64), ('ldr', C.c_int64),
+                ('batch_outer', C.c_int32), ('batch_inner', C.c_int32),
+                ('sAo', C.c_int64), ('sAi', C.c_int64), ('sBo', C.c_int64), ('sBi', C.c_int64),
+                ('sCo', C.c_int64), ('sCi', C.c_int64), ('sRo', C.c_int64), ('sRi', C.c_int64),
+                ('alpha', C.c_float), ('act', C.c_int32), ('c_dtype', C.c_int32), ('r_dtype', C.c_int32),
+                ('accumulate', C.c_int32), ('splitk', C.c_int32), ('b_klog', C.c_int32), ('b_tapstride', C.c_int64),
+                ('g', ConvGeom)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError('evoke_amd: %s is missing -- build it with `python -m evoke_amd.build` '
+                           '(the HIP engine has no CPU/PyTorch fallback)' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.evk_last_error.restype = C.c_char_p
+    return lib
+
+
+lib = _load()
+
+
+def check(status, what=''):
+    if status != 0:
+        raise RuntimeError('libevoke_hip %s failed (%d): %s' % (what, status, lib.evk_last_error().decode()))
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def dt(t):
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.float32:
+        return F32
+    raise TypeError('unsupported dtype %s' % t.dtype)
+
+
+def gemm_launch(desc):
+    check(lib.evk_gemm_launch(C.byref(desc), stream()), 'evk_gemm_launch')
+
+
+def conv_geom(N, Hi, Wi, Ci, Co, KH, KW, stride, pad):
+    g = ConvGeom()
+    g.N, g.Hi, g.Wi, g.Ci, g.Co, g.KH, g.KW = N, Hi, Wi, Ci, Co, KH, KW
+    g.stride_h = g.stride_w = stride
+    g.pad_h = g.pad_w = pad
+    g.Ho = (Hi + 2 * pad - KH) // stride + 1
+    g.Wo = (Wi + 2 * pad - KW) // stride + 1
+    return g
+
+
+def prof_enable(on):
+    check(lib.evk_prof_enable(int(on)))
+
+
+def prof_collect():
+    ms = (C.c_double * len(FAMILIES))()
+    n = (C.c_int64 * len(FAMILIES))()
+    fl = C.c_double(0.0)
+    check(lib.evk_prof_collect(ms, n, C.byref(fl)))
+    return {f: (ms[i], n[i]) for i, f in enumerate(FAMILIES)}, fl.value

@@ -1,0 +1,79 @@
+"""Golden-case definitions shared by make_golden.py (reference side, build container only) and the
+parity tests (oracle / HIP side).  Inputs are generated from integer hashes, not from torch's RNG, so
+they are identical on every machine."""
+import numpy as np
+import torch
+
+from oracle.spec import splitmix64_uniform
+
+CASES = {
+    # FineTune.forward(mode='train') loss + taps (+ grads in train mode); 3 studies, study 0 has 3 views,
+    # study 1 is single-view (bypasses attention and layer_norm_2), study 2 has 2 views.
+    'ft224_inc': dict(kind='finetune', res=224, pids=[0, 1, 2, 0, 2, 0], B=3, L=16, Li=12, modes=['eval', 'train']),
+    'ft224_noinc': dict(kind='finetune', res=224, pids=[0, 1, 2, 0, 2, 0], B=3, L=16, Li=0, modes=['eval', 'train']),
+    'ft384_inc': dict(kind='finetune', res=384, pids=[0, 1, 0], B=2, L=12, Li=8, modes=['eval', 'train']),
+    'ft224_nomv': dict(kind='finetune', res=224, pids=[0, 1], B=2, L=10, Li=6, modes=['eval'], multiview=False),
+    'pt224': dict(kind='pretrain', res=224, pids=[0, 1, 2, 0, 2, 0], B=3, L=10, Li=0, modes=['eval', 'train']),
+    'pt224_nosib': dict(kind='pretrain', res=224, pids=[0, 1, 2], B=3, L=8, Li=0, modes=['eval']),
+    'beam224': dict(kind='beam', res=224, pids=[0, 1, 0], B=2, L=8, Li=6, modes=['eval'], max_seq_len=20, beam_size=3),
+    'beam224_b4': dict(kind='beam', res=224, pids=[0, 1], B=2, L=8, Li=0, modes=['eval'], max_seq_len=14, beam_size=4),
+}
+
+
+def _u(seed, n):
+    return splitmix64_uniform(seed, n)
+
+
+def make_inputs(case, vocab):
+    """-> dict(images f32 (N,3,H,W), ids/masks (B,L) i64, inc_ids/inc_masks or None, patient_ids list[str])."""
+    n, b, res, L, Li = len(case['pids']), case['B'], case['res'], case['L'], case['Li']
+    seed = 1000 + res + 7 * n
+    img = (_u(seed, n * 3 * res * res) * 4.0 - 2.0).astype(np.float32).reshape(n, 3, res, res)
+    bos, eos = vocab - 2, vocab - 1
+    pretrain = case['kind'] == 'pretrain'
+    ids = (5 + np.floor(_u(seed + 1, b * L) * (vocab - 7))).astype(np.int64).reshape(b, L)
+    masks = np.ones((b, L), dtype=np.int64)
+    for i in range(b):
+        ln = max(4, L - 3 * i)
+        ids[i, 0] = 1 if pretrain else bos
+        if not pretrain:
+            ids[i, ln - 1] = eos
+        ids[i, ln:] = 0
+        masks[i, ln:] = 0
+    out = dict(images=torch.from_numpy(img), ids=torch.from_numpy(ids), masks=torch.from_numpy(masks),
+               patient_ids=['p%08d_s%08d' % (p, p) for p in case['pids']], inc_ids=None, inc_masks=None)
+    if Li > 0:
+        inc = (5 + np.floor(_u(seed + 2, b * Li) * (vocab - 7))).astype(np.int64).reshape(b, Li)
+        im = np.ones((b, Li), dtype=np.int64)
+        for i in range(b):
+            ln = max(2, Li - 2 * i)
+            inc[i, 0] = 1
+            inc[i, ln:] = 0
+            im[i, ln:] = 0
+        out['inc_ids'], out['inc_masks'] = torch.from_numpy(inc), torch.from_numpy(im)
+    return out
+
+
+N_SAMPLES = 61
+
+
+def reduce_tensor(t):
+    """[n, sum, sum of squares, 61 strided samples] in float64 -- small enough to commit."""
+    x = t.detach().to(torch.float64).reshape(-1)
+    n = x.numel()
+    idx = (torch.arange(N_SAMPLES, dtype=torch.int64) * (n - 1)) // (N_SAMPLES - 1)
+    return torch.cat([torch.tensor([float(n), x.sum().item(), (x * x).sum().item()], dtype=torch.float64),
+                      x[idx]]).numpy()
+
+
+def compare_reduced(got, want, rtol, atol=0.0):
+    """Returns (ok, message). Sum / sumsq are compared relative to sqrt(n)*rms-scaled magnitudes."""
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    n = want[0]
+    assert got[0] == n, (got[0], n)
+    rms = np.sqrt(want[2] / n) + 1e-30
+    e_sum = abs(got[1] - want[1]) / (rms * np.sqrt(n) + abs(want[1]))
+    e_sq = abs(got[2] - want[2]) / (want[2] + 1e-30)
+    e_smp = np.max(np.abs(got[3:] - want[3:])) / rms
+    ok = e_sum <= rtol + atol and e_sq <= 2 * rtol + atol and e_smp <= rtol + atol
+    return ok, 'sum %.3e sumsq %.3e samples %.3e (rtol %.1e)' % (e_sum, e_sq, e_smp, rtol)

@@ -1,0 +1,191 @@
+"""GPU parity tests of the MFMA GEMM / implicit-GEMM family (evoke_amd/csrc/gemm.hip, conv.hip) through the C ABI.
+
+Reference = torch CPU fp32 math on the same bf16-rounded operands, so the only differences are the f32
+accumulation order and the final bf16 rounding of the output (tolerances stated per test)."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def H():
+    from evoke_amd import hip
+    return hip
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16)
+
+
+def close(got, want, rtol, atol):
+    got, want = got.float().cpu(), want.float()
+    err = (got - want).abs()
+    tol = atol + rtol * want.abs()
+    assert bool((err <= tol).all()), 'max err %.4g (tol %.4g) at %s' % (
+        err.max().item(), tol.flatten()[err.argmax()].item(), err.argmax().item())
+
+
+def base_desc(H, A, B, Cm, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, ldc=None):
+    d = H.Gemm()
+    d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cm.data_ptr()
+    d.M, d.N, d.K, d.a_mode, d.b_mode = M, N, K, a_mode, b_mode
+    d.lda, d.ldb, d.ldc = lda or 0, ldb or 0, ldc or 0
+    d.batch_outer = d.batch_inner = 1
+    d.alpha, d.c_dtype = 1.0, H.dt(Cm)
+    return d
+
+
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (200, 136, 72), (4640, 2048, 512), (37, 64, 256), (300, 1445, 512), (1, 8, 8)])
+def test_gemm_nt(H, M, N, K):
+    a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    bias = torch.randn(N)
+    res = rnd(M, N, seed=3)
+    ldc = (N + 7) // 8 * 8
+    for c_dtype in (torch.bfloat16, torch.float32):
+        for act in (H.ACT_NONE, H.ACT_GELU):
+            c = torch.zeros(M, ldc, dtype=c_dtype, device='cuda')
+            ad, bd, biasd = a.cuda(), b.cuda(), bias.cuda()
+            resd = torch.zeros(M, ldc, dtype=torch.bfloat16, device='cuda')
+            resd[:, :N] = res.cuda()
+            d = base_desc(H, ad, bd, c, M, N, K, lda=K, ldb=K, ldc=ldc)
+            d.bias, d.resid, d.ldr, d.r_dtype, d.act, d.alpha = biasd.data_ptr(), resd.data_ptr(), ldc, H.BF16, act, 0.5
+            H.gemm_launch(d)
+            torch.cuda.synchronize()
+            want = 0.5 * (a.float() @ b.float().t()) + bias
+            if act == H.ACT_GELU:
+                want = F.gelu(want)
+            want = want + res.float()
+            close(c[:, :N], want, 1e-2 if c_dtype == torch.bfloat16 else 2e-4, 2e-3 * K ** 0.5 if c_dtype == torch.float32 else 2e-2 * (K / 64) ** 0.5)
+            assert float(c[:, N:].abs().sum()) == 0.0
+
+
+def test_gemm_batched_heads(H):
+    # attention-style: Q (B,T,Hh*dh) x K (B,S,Hh*dh) -> scores (B,Hh,T,S) f32, then P.V with V K-strided
+    Bz, T, S, Hh, dh = 3, 37, 50, 4, 64
+    q, k, v = rnd(Bz, T, Hh * dh, seed=1), rnd(Bz, S, Hh * dh, seed=2), rnd(Bz, S, Hh * dh, seed=3)
+    qd, kd, vd = q.cuda(), k.cuda(), v.cuda()
+    Sp = 56
+    sc = torch.zeros(Bz, Hh, T, Sp, dtype=torch.float32, device='cuda')
+    d = base_desc(H, qd, kd, sc, T, S, dh, lda=Hh * dh, ldb=Hh * dh, ldc=Sp)
+    d.batch_outer, d.batch_inner = Bz, Hh
+    d.sAo, d.sAi, d.sBo, d.sBi, d.sCo, d.sCi = T * Hh * dh, dh, S * Hh * dh, dh, Hh * T * Sp, T * Sp
+    d.alpha = 0.125
+    H.gemm_launch(d)
+    want = torch.einsum('bthd,bshd->bhts', q.float().view(Bz, T, Hh, dh), k.float().view(Bz, S, Hh, dh)) * 0.125
+    close(sc[..., :S], want, 2e-4, 2e-3)
+    p = torch.softmax(want, -1).to(torch.bfloat16)
+    pd = torch.zeros(Bz, Hh, T, Sp, dtype=torch.bfloat16, device='cuda')
+    pd[..., :S] = p.cuda()
+    ctx = torch.zeros(Bz, T, Hh * dh, dtype=torch.bfloat16, device='cuda')
+    d = base_desc(H, pd, vd, ctx, T, dh, Sp, b_mode=H.B_KSTR, lda=Sp, ldb=Hh * dh, ldc=Hh * dh)
+    d.K = Sp  # padded K: the pad columns of P are zero, V rows beyond S must not be read -> use K = 56 only if V padded
+    d.K = S if S % 8 == 0 else Sp
+    vpad = torch.zeros(Bz, Sp, Hh * dh, dtype=torch.bfloat16, device='cuda')
+    vpad[:, :S] = vd
+    d.B = vpad.data_ptr()
+    d.batch_outer, d.batch_inner = Bz, Hh
+    d.sAo, d.sAi, d.sBo, d.sBi, d.sCo, d.sCi = Hh * T * Sp, T * Sp, Sp * Hh * dh, dh, T * Hh * dh, dh
+    H.gemm_launch(d)
+    want = torch.einsum('bhts,bshd->bthd', p.float(), v.float().view(Bz, S, Hh, dh)).reshape(Bz, T, Hh * dh)
+    close(ctx, want, 1e-2, 1e-2)
+
+
+@pytest.mark.parametrize('M,N,K', [(4640, 512, 2048), (333, 136, 1448), (64, 64, 8)])
+def test_gemm_nn_dx(H, M, N, K):
+    # dX[M,N] = dY[M,K] . W[K,N]   (B K-strided)
+    dy, w = rnd(M, K, seed=4), rnd(K, N, seed=5, scale=0.1)
+    c = torch.zeros(M, N, dtype=torch.bfloat16, device='cuda')
+    dyd, wd = dy.cuda(), w.cuda()
+    d = base_desc(H, dyd, wd, c, M, N, K, b_mode=H.B_KSTR, lda=K, ldb=N, ldc=N)
+    H.gemm_launch(d)
+    close(c, dy.float() @ w.float(), 1e-2, 2e-2 * (K / 64) ** 0.5 * 0.1)
+
+
+@pytest.mark.parametrize('M,N,K', [(512, 2048, 4640), (1445, 512, 300), (64, 72, 128)])
+def test_gemm_tn_dw_accumulate(H, M, N, K):
+    # dW[M,N] += dY[K,M]^T . X[K,N]   (both K-strided, split-K with f32 atomics)
+    ldy = (M + 7) // 8 * 8
+    dy = torch.zeros(K, ldy, dtype=torch.bfloat16)
+    dy[:, :M] = rnd(K, M, seed=6)
+    x = rnd(K, N, seed=7)
+    c0 = torch.randn(M, N)
+    c = c0.clone().cuda()
+    dyd, xd = dy.cuda(), x.cuda()
+    d = base_desc(H, dyd, xd, c, M, N, K, a_mode=H.A_KSTR, b_mode=H.B_KSTR, lda=ldy, ldb=N, ldc=N)
+    d.accumulate = 1
+    H.gemm_launch(d)
+    want = c0 + dy[:, :M].float().t() @ x.float()
+    close(c, want, 2e-4, 3e-3 * K ** 0.5)
+
+
+CONVS = [  # N, Hi, Wi, Ci, Co, KH, stride, pad
+    (2, 12, 12, 64, 64, 3, 1, 1), (3, 14, 10, 128, 64, 3, 2, 1), (2, 8, 8, 256, 512, 1, 2, 0),
+    (2, 9, 9, 64, 256, 1, 1, 0), (1, 24, 24, 256, 256, 3, 1, 1), (2, 7, 7, 512, 512, 3, 1, 1),
+]
+
+
+def _conv_ref(x, w, stride, pad):
+    return F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), None, stride, pad)
+
+
+@pytest.mark.parametrize('cfg', CONVS)
+def test_conv_fwd_dgrad_wgrad(H, cfg):
+    N, Hi, Wi, Ci, Co, KH, stride, pad = cfg
+    x = rnd(N, Hi, Wi, Ci, seed=8)
+    w = rnd(Co, KH, KH, Ci, seed=9, scale=(2.0 / (KH * KH * Ci)) ** 0.5)
+    g = H.conv_geom(N, Hi, Wi, Ci, Co, KH, KH, stride, pad)
+    xd, wd = x.cuda(), w.cuda()
+    y = torch.zeros(N, g.Ho, g.Wo, Co, dtype=torch.bfloat16, device='cuda')
+    H.check(H.lib.evk_conv2d_fwd(H.ptr(xd), H.ptr(wd), H.ptr(y), C.byref(g), H.stream()))
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.float().permute(0, 3, 1, 2).requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, stride, pad)
+    close(y, yr.detach().permute(0, 2, 3, 1), 1e-2, 2e-2)
+    dy = rnd(N, g.Ho, g.Wo, Co, seed=10)
+    yr.backward(dy.float().permute(0, 3, 1, 2))
+    dyd = dy.cuda()
+    dx = torch.full((N, Hi, Wi, Ci), 7.0, dtype=torch.bfloat16, device='cuda')
+    H.check(H.lib.evk_conv2d_dgrad(H.ptr(dyd), H.ptr(wd), H.ptr(dx), C.byref(g), H.stream()))
+    close(dx, xr.grad.permute(0, 2, 3, 1), 1e-2, 2e-2 * (KH * KH * Co / 64) ** 0.5 * w.float().std().item())
+    dw = torch.zeros(Co, KH, KH, Ci, dtype=torch.float32, device='cuda')
+    H.check(H.lib.evk_conv2d_wgrad(H.ptr(dyd), H.ptr(xd), H.ptr(dw), C.byref(g), H.stream()))
+    close(dw, wr.grad.permute(0, 2, 3, 1), 2e-4, 3e-3 * (N * g.Ho * g.Wo) ** 0.5)
+
+
+@pytest.mark.parametrize('N,Hh,W', [(2, 32, 32), (1, 64, 48)])
+def test_stem(H, N, Hh, W):
+    g = torch.Generator().manual_seed(11)
+    img = torch.randn(N, 3, Hh, W, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+    imgd, wdev = img.cuda(), w.cuda()
+    xpad = torch.empty(N, Hh + 6, W + 8, 4, dtype=torch.bfloat16, device='cuda')
+    wp = torch.empty(64, 7, 8, 4, dtype=torch.bfloat16, device='cuda')
+    H.check(H.lib.evk_stem_pack_image(H.ptr(imgd), H.ptr(xpad), N, Hh, W, H.stream()))
+    H.check(H.lib.evk_stem_pack_weight(H.ptr(wdev), H.ptr(wp), H.stream()))
+    y = torch.zeros(N, Hh // 2, W // 2, 64, dtype=torch.bfloat16, device='cuda')
+    H.check(H.lib.evk_stem_fwd(H.ptr(xpad), H.ptr(wp), H.ptr(y), N, Hh, W, H.stream()))
+    ir = img.to(torch.bfloat16).float().requires_grad_(False)
+    wr = w.to(torch.bfloat16).float().requires_grad_(True)
+    yr = F.conv2d(ir, wr, None, 2, 3)
+    close(y, yr.detach().permute(0, 2, 3, 1), 1e-2, 3e-2)
+    dy = rnd(N, Hh // 2, W // 2, 64, seed=12)
+    yr.backward(dy.float().permute(0, 3, 1, 2))
+    dwp = torch.zeros(64, 7, 8, 4, dtype=torch.float32, device='cuda')
+    dyd = dy.cuda()
+    H.check(H.lib.evk_stem_wgrad(H.ptr(dyd), H.ptr(xpad), H.ptr(dwp), N, Hh, W, H.stream()))
+    dw = torch.ones(64, 3, 7, 7, dtype=torch.float32, device='cuda')
+    H.check(H.lib.evk_stem_unpack_wgrad(H.ptr(dwp), H.ptr(dw), H.stream()))
+    close(dw - 1.0, wr.grad, 2e-4, 3e-3 * (N * Hh * W / 4) ** 0.5)
+
+
+def test_gemm_rejects_bad_args(H):
+    a = torch.zeros(8, 12, dtype=torch.bfloat16, device='cuda')
+    c = torch.zeros(8, 8, dtype=torch.bfloat16, device='cuda')
+    d = base_desc(H, a, a, c, 8, 8, 12, lda=12, ldb=12, ldc=8)
+    with pytest.raises(RuntimeError):
+        H.gemm_launch(d)

@@ -1,0 +1,145 @@
+"""CPU tests: the oracle (oracle/) against fixtures produced by the imported reference
+(tests/golden/make_golden.py) and against the known-answer vectors of SURVEY.md section 8c."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import beam as OB
+from oracle import functional as O
+from oracle import spec as S
+from tests.golden.cases import CASES, compare_reduced, make_inputs, reduce_tensor
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+V = 1444
+
+
+def _kat():
+    return json.load(open(os.path.join(GOLDEN, 'kat.json')))
+
+
+def test_kat_losses_and_norms():
+    k = _kat()
+    a = np.array
+    assert abs(O.multi_pos_contra_images(S.det((6, 8)), a(['a', 'b', 'c', 'd', 'a', 'c']), .5).item() - k['multi_pos']) < 1e-6
+    assert O.multi_pos_contra_images(S.det((4, 8)), a(['a', 'b', 'c', 'd']), .5).tolist() == k['multi_pos_nosib']
+    g = O.global_alignment_loss(S.det((4, 8)), S.det((4, 8), a=.23, b=.31, c=1.0), a(['a', 'b', 'a', 'd', 'a', 'c']), .5)
+    assert abs(g.item() - k['global_align']) < 1e-6
+    l = O.local_text_token_alignment_loss(S.det((2, 5, 8), a=.19), S.det((2, 3, 8), a=.29, b=.07, c=.5), .5)
+    assert abs(l.item() - k['local_align']) < 1e-6
+    lp = torch.log_softmax(S.det((2, 4, 5), a=.41), -1)
+    lm = O.compute_lm_loss(lp, torch.tensor([[3, 1, 4, 2], [3, 0, 2, 0]]), torch.tensor([[1, 1, 1, 1], [1, 1, 1, 0]]))
+    assert abs(lm.item() - k['lm_loss']) < 1e-6
+    ln = O.r2_layernorm(S.det((1, 8)), torch.ones(8), torch.zeros(8))[0]
+    np.testing.assert_allclose(ln.numpy(), k['r2_layernorm'], rtol=0, atol=1e-6)
+    assert O.subsequent_mask(4).int().tolist() == k['subsequent_mask4']
+    np.testing.assert_allclose(O.positional_encoding(5000, 8)[0, 1].numpy(), k['pe_0_1'], atol=1e-7)
+    assert O.rm_init_memory(2, 3, 16).tolist() == k['rm_init_memory']
+
+
+def test_kat_tokenizer(tokenizer):
+    k = _kat()
+    assert tokenizer.get_vocab_size() == k['vocab_size'] == V
+    assert [tokenizer.token_to_id(t) for t in ('[BOS]', '[EOS]', '[PAD]')] == k['bos_eos_pad']
+    assert tokenizer.encode('[BOS] a 1.2-cm calcified granuloma, unchanged; no_pneumothorax zzzqq . [EOS]').ids == k['tok_1']
+    assert tokenizer.encode('[CLS] cardiomegaly [SEP] pleural effusion').ids == k['tok_2']
+    assert tokenizer.encode('Heart SIZE').ids == k['tok_3']
+    assert tokenizer.encode('[BOS] the heart size is normal . [EOS]').ids == k['tok_4']
+    assert tokenizer.decode([1442, 6, 20, 22, 8, 10, 5, 1443, 0, 0]) == k['decode_1']
+
+
+def test_spec_counts():
+    # SURVEY.md 8b/8c probes: 347,799,781 (FineTune) / 235,572,544 (Pretrain) trainable params at V=1444,
+    # ResNet-101 trunk 42,500,160
+    assert S.n_trainable(S.finetune_spec(V)) == 347799781
+    assert S.n_trainable(S.pretrain_spec(V)) == 235572544
+    r = {}
+    S.resnet_spec(r)
+    assert S.n_trainable(r) == 42500160
+
+
+def _load(name):
+    p = os.path.join(GOLDEN, name + '.npz')
+    if not os.path.exists(p):
+        pytest.skip('fixture %s missing' % name)
+    return np.load(p)
+
+
+def _check(got, want, rtol, what):
+    ok, msg = compare_reduced(got, want, rtol)
+    assert ok, '%s: %s' % (what, msg)
+
+
+FT_CASES = [n for n, c in CASES.items() if c['kind'] == 'finetune']
+
+
+@pytest.mark.parametrize('name', FT_CASES)
+def test_finetune_vs_reference(name):
+    case, gold = CASES[name], _load(name)
+    inp = make_inputs(case, V)
+    cfg = dict(O.DEFAULT_CFG, is_multiview_learning=case.get('multiview', True))
+    for mode in case['modes']:
+        P = S.procedural_state(S.finetune_spec(V))
+        if mode == 'train':
+            for k, (sh, kind) in S.finetune_spec(V).items():
+                if kind not in S.BUFFER_KINDS:
+                    P[k].requires_grad_(True)
+        taps = {}
+        ret = O.finetune_forward_train(P, inp['images'], inp['ids'], inp['masks'], inp['patient_ids'], inp['inc_ids'],
+                                       inp['inc_masks'], cfg, O.Ctx(train=(mode == 'train')), taps)
+        assert abs(ret['all_loss'].item() - float(gold[mode + '/loss'])) < 2e-5, (mode, ret['all_loss'].item())
+        _check(reduce_tensor(taps['att']), gold[mode + '/tap/att'], 2e-4, mode + ' att')
+        _check(reduce_tensor(taps['fc']), gold[mode + '/tap/fc'], 2e-4, mode + ' fc')
+        _check(reduce_tensor(taps['fused']), gold[mode + '/tap/vhead'], 2e-4, mode + ' vhead')
+        _check(reduce_tensor(taps['enc_states']), gold[mode + '/tap/enc_states'], 2e-4, mode + ' enc_states')
+        _check(reduce_tensor(taps['logp']), gold[mode + '/tap/logp'], 2e-4, mode + ' logp')
+        if mode == 'train':
+            ret['all_loss'].backward()
+            for k in gold.files:
+                if k.startswith('train/grad/'):
+                    _check(reduce_tensor(P[k[len('train/grad/'):]].grad), gold[k], 2e-3, k)
+            _check(reduce_tensor(P['visual_extractor.model.7.2.bn3.running_mean']), gold['train/bn/running_mean'], 1e-4, 'rm')
+            _check(reduce_tensor(P['visual_extractor.model.7.2.bn3.running_var']), gold['train/bn/running_var'], 1e-4, 'rv')
+
+
+@pytest.mark.parametrize('name', [n for n, c in CASES.items() if c['kind'] == 'pretrain'])
+def test_pretrain_vs_reference(name):
+    case, gold = CASES[name], _load(name)
+    inp = make_inputs(case, V)
+    for mode in case['modes']:
+        spec = S.pretrain_spec(V)
+        P = S.procedural_state(spec)
+        if mode == 'train':
+            for k, (sh, kind) in spec.items():
+                if kind not in S.BUFFER_KINDS:
+                    P[k].requires_grad_(True)
+        taps = {}
+        ret = O.pretrain_forward(P, inp['images'], inp['ids'], inp['masks'], inp['patient_ids'], O.DEFAULT_CFG,
+                                 O.Ctx(train=(mode == 'train')), taps)
+        for k in ('sen_text_loss', 'instance_loss', 'multiview_loss', 'all_loss'):
+            assert abs(ret[k].reshape(-1)[0].item() - float(gold['%s/%s' % (mode, k)])) < 2e-5, (mode, k)
+        assert tuple(ret['sen_image_loss'].shape) == (1,)
+        _check(reduce_tensor(taps['fc']), gold[mode + '/tap/fc'], 2e-4, 'fc')
+        _check(reduce_tensor(torch.cat([taps['v_fc'].unsqueeze(1), taps['v_att']], 1)), gold[mode + '/tap/vhead'], 2e-4, 'vhead')
+        _check(reduce_tensor(torch.cat([taps['t_fc'].unsqueeze(1), taps['t_att']], 1)), gold[mode + '/tap/thead'], 2e-4, 'thead')
+        if mode == 'train':
+            ret['all_loss'].backward()
+            for k in gold.files:
+                if k.startswith('train/grad/'):
+                    _check(reduce_tensor(P[k[len('train/grad/'):]].grad), gold[k], 2e-3, k)
+
+
+@pytest.mark.parametrize('name', [n for n, c in CASES.items() if c['kind'] == 'beam'])
+def test_beam_search_vs_reference(name, tokenizer):
+    case, gold = CASES[name], _load(name)
+    inp = make_inputs(case, V)
+    cfg = dict(O.DEFAULT_CFG, max_seq_len=case['max_seq_len'], beam_size=case['beam_size'])
+    P = S.procedural_state(S.finetune_spec(V))
+    with torch.no_grad():
+        x, m = O.finetune_encoder_states(P, inp['images'], inp['patient_ids'], case['B'], inp['inc_ids'], inp['inc_masks'],
+                                         cfg, O.Ctx())
+        seq = OB.beam_search(P, x, m, cfg, bos=V - 2, eos=V - 1, pad=0)
+    assert seq.tolist() == gold['eval/seq'].tolist()          # bit-exact token ids
+    assert OB.decode_texts(tokenizer, seq) == gold['eval/texts'].tolist()
