@@ -1,0 +1,379 @@
+// bn.hip -- BatchNorm (train-mode batch statistics) + ReLU + residual for the NHWC ResNet-101 trunk and the
+// projection heads (torch.nn.BatchNorm2d/1d: visual_extractor.py:30-38 via torchvision; utils_v0511.py:131-208),
+// max-pool 3x3 s2 p1 and the patch mean (visual_extractor.py:40-42).  Rows = N*H*W (or B*T), channels contiguous.
+// All HBM-bound: 16-byte loads, f32 statistics, per-channel partials reduced in LDS then one atomic per block.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ void ld8(const bf16_t* p, float (&v)[8]) {
+  const uint4 a = *reinterpret_cast<const uint4*>(p);
+  v[0] = lo_bf(a.x); v[1] = hi_bf(a.x); v[2] = lo_bf(a.y); v[3] = hi_bf(a.y);
+  v[4] = lo_bf(a.z); v[5] = hi_bf(a.z); v[6] = lo_bf(a.w); v[7] = hi_bf(a.w);
+}
+__device__ __forceinline__ void st8(bf16_t* p, const float (&v)[8]) {
+  *reinterpret_cast<uint4*>(p) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+}
+
+// Column reductions over rows of x[M][C] (C % 8 == 0, C <= 2048): thread -> channel group cg = tid % (C/8),
+// row lane rl = tid / (C/8); a block sweeps rows rl, rl+RPB, ... of its slice.
+// kind 0: {sum x, sum x^2}      kind 1 (bn backward): {sum g, sum g*xhat} with g = dz * (z > 0 if relu)
+struct RedP {
+  const bf16_t* x; const bf16_t* dz; const bf16_t* z; const float* mean; const float* invstd;
+  float* out0; float* out1; long M; int C; int kind; int relu; long rows_per_block;
+};
+
+__global__ __launch_bounds__(256) void colreduce_kernel(const RedP p) {
+  __shared__ float red[2][256 * 8];
+  const int G = p.C >> 3;                 // channel groups
+  const int tpr = G < 256 ? G : 256;      // threads per row
+  const int rpb = 256 / tpr;              // rows in flight per block
+  const int cg0 = threadIdx.x % tpr, rl = threadIdx.x / tpr;
+  const long r0 = blockIdx.x * p.rows_per_block;
+  const long r1 = min(p.M, r0 + p.rows_per_block);
+  for (int cg = cg0; cg < G; cg += tpr) {  // (only loops when C > 2048; kept for generality)
+    float a[8], b[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = b[j] = 0.f;
+    float mu[8], is[8];
+    if (p.kind == 1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { mu[j] = p.mean[cg * 8 + j]; is[j] = p.invstd[cg * 8 + j]; }
+    }
+    if (rl < rpb) {
+      for (long r = r0 + rl; r < r1; r += rpb) {
+        float xv[8];
+        ld8(p.x + r * p.C + cg * 8, xv);
+        if (p.kind == 0) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { a[j] += xv[j]; b[j] += xv[j] * xv[j]; }
+        } else {
+          float g[8];
+          ld8(p.dz + r * p.C + cg * 8, g);
+          if (p.relu) {
+            float zv[8];
+            ld8(p.z + r * p.C + cg * 8, zv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] = zv[j] > 0.f ? g[j] : 0.f;
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { a[j] += g[j]; b[j] += g[j] * (xv[j] - mu[j]) * is[j]; }
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[0][threadIdx.x * 8 + j] = a[j]; red[1][threadIdx.x * 8 + j] = b[j]; }
+    __syncthreads();
+    if (rl == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float sa = 0.f, sb = 0.f;
+        for (int q = 0; q < rpb; ++q) { sa += red[0][(q * tpr + cg0) * 8 + j]; sb += red[1][(q * tpr + cg0) * 8 + j]; }
+        unsafeAtomicAdd(p.out0 + cg * 8 + j, sa);
+        unsafeAtomicAdd(p.out1 + cg * 8 + j, sb);
+      }
+    }
+  }
+}
+
+struct FinP {
+  const float* sum; const float* sumsq; const float* gamma; const float* beta; float* rmean; float* rvar;
+  float* scale; float* shift; float* mean; float* invstd; int C; float count, momentum, eps; int training;
+};
+__global__ void bn_finalize_kernel(const FinP p) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= p.C) return;
+  float mu, var;
+  if (p.training) {
+    mu = p.sum[c] / p.count;
+    var = fmaxf(p.sumsq[c] / p.count - mu * mu, 0.f);
+    if (p.rmean) {
+      p.rmean[c] = (1.f - p.momentum) * p.rmean[c] + p.momentum * mu;
+      p.rvar[c] = (1.f - p.momentum) * p.rvar[c] + p.momentum * var * (p.count / fmaxf(p.count - 1.f, 1.f));
+    }
+  } else {
+    mu = p.rmean[c];
+    var = p.rvar[c];
+  }
+  const float is = rsqrtf(var + p.eps);
+  const float g = p.gamma ? p.gamma[c] : 1.f, b = p.beta ? p.beta[c] : 0.f;
+  p.scale[c] = g * is;
+  p.shift[c] = b - mu * g * is;
+  p.mean[c] = mu;
+  p.invstd[c] = is;
+}
+
+// y = relu?(x*scale[c] + shift[c] + resid)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const bf16_t* __restrict__ resid,
+                                                       bf16_t* __restrict__ y, long total8, int G, int relu) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total8; i += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % G);
+    float v[8], sc[8], sh[8];
+    ld8(x + i * 8, v);
+    *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(scale + cg * 8);
+    *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(scale + cg * 8 + 4);
+    *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(shift + cg * 8);
+    *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(shift + cg * 8 + 4);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + sh[j];
+    if (resid) {
+      float r[8];
+      ld8(resid + i * 8, r);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += r[j];
+    }
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+    }
+    st8(y + i * 8, v);
+  }
+}
+
+// dx = scale[c] * (g - sum_g[c]/cnt - xhat * sum_gx[c]/cnt), g = dz * (z>0);  dres = g (optional)
+struct BwdP {
+  const bf16_t* dz; const bf16_t* z; const bf16_t* x; const float* scale; const float* mean; const float* invstd;
+  const float* sum_g; const float* sum_gx; bf16_t* dx; bf16_t* dres; long total8; int G; int relu; float inv_count;
+};
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdP p) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < p.total8; i += (long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % p.G) * 8;
+    float g[8], xv[8], o[8];
+    ld8(p.dz + i * 8, g);
+    if (p.relu) {
+      float zv[8];
+      ld8(p.z + i * 8, zv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] = zv[j] > 0.f ? g[j] : 0.f;
+    }
+    ld8(p.x + i * 8, xv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = (xv[j] - p.mean[c0 + j]) * p.invstd[c0 + j];
+      o[j] = p.scale[c0 + j] * (g[j] - p.sum_g[c0 + j] * p.inv_count - xh * p.sum_gx[c0 + j] * p.inv_count);
+    }
+    st8(p.dx + i * 8, o);
+    if (p.dres) st8(p.dres + i * 8, g);
+  }
+}
+
+// max-pool 3x3 stride 2 pad 1, NHWC bf16, 8 channels per thread
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int N, int H, int W, int C) {
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1, G = C >> 3;
+  const long total = (long)N * Ho * Wo * G;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % G);
+    long t = i / G;
+    const int ow = (int)(t % Wo); t /= Wo;
+    const int oh = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    float m[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ih = oh * 2 - 1 + kh;
+      if ((unsigned)ih >= (unsigned)H) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int iw = ow * 2 - 1 + kw;
+        if ((unsigned)iw >= (unsigned)W) continue;
+        float v[8];
+        ld8(x + (((long)n * H + ih) * W + iw) * C + cg * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], v[j]);
+      }
+    }
+    st8(y + i * 8, m);
+  }
+}
+
+// gather form of the backward: each input pixel sums dy of the (<=4) windows whose FIRST maximum (scan order kh,kw,
+// strict >, as torch's max_pool2d indices) is this pixel -- deterministic, no atomics.
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                          bf16_t* __restrict__ dx, int N, int H, int W, int C) {
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1, G = C >> 3;
+  const long total = (long)N * H * W * G;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % G);
+    long t = i / G;
+    const int iw = (int)(t % W); t /= W;
+    const int ih = (int)(t % H);
+    const int n = (int)(t / H);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    // windows containing the pixel: oh in [ih/2, (ih+1)/2], ow in [iw/2, (iw+1)/2]
+    for (int oh = ih / 2; oh <= (ih + 1) / 2 && oh < Ho; ++oh) {
+      for (int ow = iw / 2; ow <= (iw + 1) / 2 && ow < Wo; ++ow) {
+        float m[8]; int am[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { m[j] = -INFINITY; am[j] = -1; }
+        for (int kh = 0; kh < 3; ++kh) {
+          const int yh = oh * 2 - 1 + kh;
+          if ((unsigned)yh >= (unsigned)H) continue;
+          for (int kw = 0; kw < 3; ++kw) {
+            const int xw = ow * 2 - 1 + kw;
+            if ((unsigned)xw >= (unsigned)W) continue;
+            float v[8];
+            ld8(x + (((long)n * H + yh) * W + xw) * C + cg * 8, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (v[j] > m[j] || am[j] < 0) { m[j] = v[j]; am[j] = yh * W + xw; }
+          }
+        }
+        float g[8];
+        ld8(dy + (((long)n * Ho + oh) * Wo + ow) * C + cg * 8, g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (am[j] == ih * W + iw) acc[j] += g[j];
+      }
+    }
+    st8(dx + i * 8, acc);
+  }
+}
+
+// patch mean: fc[n][c] = mean_p att[n][p][c] (f32 accumulate); backward adds dfc/P to every patch gradient
+__global__ __launch_bounds__(256) void patch_mean_fwd_kernel(const bf16_t* __restrict__ att, bf16_t* __restrict__ fc, int N, int P, int C) {
+  const int G = C >> 3;
+  const long total = (long)N * G;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % G);
+    const int n = (int)(i / G);
+    float a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = 0.f;
+    for (int q = 0; q < P; ++q) {
+      float v[8];
+      ld8(att + ((long)n * P + q) * C + cg * 8, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] /= P;
+    st8(fc + (long)n * C + cg * 8, a);
+  }
+}
+__global__ __launch_bounds__(256) void patch_mean_bwd_kernel(const bf16_t* __restrict__ datt_in, const bf16_t* __restrict__ dfc,
+                                                             bf16_t* __restrict__ datt, int N, int P, int C) {
+  const int G = C >> 3;
+  const long total = (long)N * P * G;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % G);
+    const int n = (int)(i / ((long)G * P));
+    float a[8], b[8];
+    ld8(dfc + (long)n * C + cg * 8, b);
+    if (datt_in) ld8(datt_in + i * 8, a);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = (datt_in ? a[j] : 0.f) + b[j] / P;
+    st8(datt + i * 8, a);
+  }
+}
+
+inline int ew_blocks(long work) { long b = cdiv(work, 256); return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); }
+
+int launch_reduce(const RedP& p0, hipStream_t s) {
+  RedP p = p0;
+  const int G = p.C >> 3;
+  const int tpr = G < 256 ? G : 256;
+  const int rpb = 256 / tpr;
+  long blocks = cdiv(p.M, (long)rpb * 8);      // >= 8 rows per thread-row
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  p.rows_per_block = cdiv(p.M, blocks);
+  blocks = cdiv(p.M, p.rows_per_block);
+  ProfScope ps(EVK_FAM_REDUCE, s);
+  hipLaunchKernelGGL(colreduce_kernel, dim3((int)blocks), dim3(256), 0, s, p);
+  return evk_check_launch("colreduce");
+}
+
+}  // namespace
+
+extern "C" {
+
+// out0[c] += sum_rows x, out1[c] += sum_rows x^2     (outputs must be zeroed by the caller)
+int evk_bn_stats(const void* x, float* sum, float* sumsq, int64_t M, int32_t C, evk_stream_t stream) {
+  EVK_REQUIRE(x && sum && sumsq && M > 0 && C % 8 == 0 && C >= 8 && C <= 2048 && (C / 8 >= 256 || 256 % (C / 8) == 0),
+              "bn_stats: bad args (C=%d must be a power-of-two multiple of 8, <= 2048)", C);
+  RedP p{(const bf16_t*)x, nullptr, nullptr, nullptr, nullptr, sum, sumsq, M, C, 0, 0, 0};
+  return launch_reduce(p, reinterpret_cast<hipStream_t>(stream));
+}
+
+int evk_bn_finalize(const float* sum, const float* sumsq, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, float* scale, float* shift, float* mean, float* invstd, int32_t C, float count,
+                    float momentum, float eps, int32_t training, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(scale && shift && mean && invstd && C > 0, "bn_finalize: null outputs");
+  EVK_REQUIRE(training ? (sum && sumsq && count > 0) : (running_mean && running_var), "bn_finalize: missing statistics");
+  FinP p{sum, sumsq, gamma, beta, running_mean, running_var, scale, shift, mean, invstd, C, count, momentum, eps, training};
+  ProfScope ps(EVK_FAM_REDUCE, s);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((int)cdiv(C, 256)), dim3(256), 0, s, p);
+  return evk_check_launch("bn_finalize");
+}
+
+int evk_bn_apply(const void* x, const float* scale, const float* shift, const void* resid, void* y, int64_t M, int32_t C,
+                 int32_t relu, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(x && scale && shift && y && M > 0 && C % 8 == 0, "bn_apply: bad args");
+  const long total8 = M * (C / 8);
+  ProfScope ps(EVK_FAM_ELTWISE, s);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(total8)), dim3(256), 0, s, (const bf16_t*)x, scale, shift,
+                     (const bf16_t*)resid, (bf16_t*)y, total8, C / 8, relu);
+  return evk_check_launch("bn_apply");
+}
+
+// sum_g[c] += sum_rows g, sum_gx[c] += sum_rows g*xhat  with g = dz * (z > 0 if relu)    (zeroed by the caller)
+int evk_bn_bwd_reduce(const void* dz, const void* z, const void* x, const float* mean, const float* invstd, float* sum_g,
+                      float* sum_gx, int64_t M, int32_t C, int32_t relu, evk_stream_t stream) {
+  EVK_REQUIRE(dz && x && mean && invstd && sum_g && sum_gx && (!relu || z) && M > 0 && C % 8 == 0 && C <= 2048 &&
+              (C / 8 >= 256 || 256 % (C / 8) == 0), "bn_bwd_reduce: bad args");
+  RedP p{(const bf16_t*)x, (const bf16_t*)dz, (const bf16_t*)z, mean, invstd, sum_g, sum_gx, M, C, 1, relu, 0};
+  return launch_reduce(p, reinterpret_cast<hipStream_t>(stream));
+}
+
+int evk_bn_bwd_apply(const void* dz, const void* z, const void* x, const float* scale, const float* mean, const float* invstd,
+                     const float* sum_g, const float* sum_gx, void* dx, void* dres, int64_t M, int32_t C, int32_t relu,
+                     evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(dz && x && scale && mean && invstd && sum_g && sum_gx && dx && (!relu || z) && M > 0 && C % 8 == 0, "bn_bwd_apply: bad args");
+  BwdP p{(const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)x, scale, mean, invstd, sum_g, sum_gx, (bf16_t*)dx, (bf16_t*)dres,
+         M * (C / 8), C / 8, relu, 1.f / (float)M};
+  ProfScope ps(EVK_FAM_ELTWISE, s);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(p.total8)), dim3(256), 0, s, p);
+  return evk_check_launch("bn_bwd_apply");
+}
+
+int evk_maxpool3x3s2_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C % 8 == 0, "maxpool_fwd: bad args");
+  const long total = (long)N * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * (C / 8);
+  ProfScope ps(EVK_FAM_ELTWISE, s);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, N, H, W, C);
+  return evk_check_launch("maxpool_fwd");
+}
+
+int evk_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(x && dy && dx && N > 0 && H > 0 && W > 0 && C % 8 == 0, "maxpool_bwd: bad args");
+  const long total = (long)N * H * W * (C / 8);
+  ProfScope ps(EVK_FAM_ELTWISE, s);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C);
+  return evk_check_launch("maxpool_bwd");
+}
+
+int evk_patch_mean_fwd(const void* att, void* fc, int32_t N, int32_t P, int32_t C, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(att && fc && N > 0 && P > 0 && C % 8 == 0, "patch_mean_fwd: bad args");
+  ProfScope ps(EVK_FAM_REDUCE, s);
+  hipLaunchKernelGGL(patch_mean_fwd_kernel, dim3(ew_blocks((long)N * C / 8)), dim3(256), 0, s, (const bf16_t*)att, (bf16_t*)fc, N, P, C);
+  return evk_check_launch("patch_mean_fwd");
+}
+
+int evk_patch_mean_bwd(const void* datt_in, const void* dfc, void* datt, int32_t N, int32_t P, int32_t C, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(dfc && datt && N > 0 && P > 0 && C % 8 == 0, "patch_mean_bwd: bad args");
+  ProfScope ps(EVK_FAM_ELTWISE, s);
+  hipLaunchKernelGGL(patch_mean_bwd_kernel, dim3(ew_blocks((long)N * P * C / 8)), dim3(256), 0, s, (const bf16_t*)datt_in,
+                     (const bf16_t*)dfc, (bf16_t*)datt, N, P, C);
+  return evk_check_launch("patch_mean_bwd");
+}
+
+}  // extern "C"

@@ -1,0 +1,297 @@
+// eltwise.hip -- memory-bound elementwise / gather / scatter kernels:
+//   casts (f32 master weights -> bf16 GEMM operands), activation forward/backward (F.relu / gelu / tanh / sigmoid),
+//   dropout (nn.Dropout, stateless hash RNG so the backward recomputes the mask), embedding gather + scatter-add
+//   (nn.Embedding: encoder_decoder.py:217-224, HF BertEmbeddings), bias-gradient column sums, the relational-memory
+//   gate (encoder_decoder.py:282-289), fused value-clip + RAdam / Adam(amsgrad) (optimizers.py:17-53,
+//   trainer_v0401.py:262,434).
+#include "common.h"
+
+namespace {
+
+inline int ew_blocks(long work) { long b = cdiv(work, 256); return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); }
+
+__device__ __forceinline__ uint32_t hash32(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+  return (uint32_t)x;
+}
+
+__device__ __forceinline__ float ldx(const void* p, int f32, long i) {
+  return f32 ? reinterpret_cast<const float*>(p)[i] : bf2f(reinterpret_cast<const bf16_t*>(p)[i]);
+}
+__device__ __forceinline__ void stx(void* p, int f32, long i, float v) {
+  if (f32) reinterpret_cast<float*>(p)[i] = v; else reinterpret_cast<bf16_t*>(p)[i] = f2bf(v);
+}
+
+__global__ __launch_bounds__(256) void cast_kernel(const void* __restrict__ src, int s32, void* __restrict__ dst, int d32, long n) {
+  const long n4 = n >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float v[4];
+    if (s32) { const float4 t = reinterpret_cast<const float4*>(src)[i]; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    else { const uint2 t = reinterpret_cast<const uint2*>(src)[i]; v[0] = lo_bf(t.x); v[1] = hi_bf(t.x); v[2] = lo_bf(t.y); v[3] = hi_bf(t.y); }
+    if (d32) reinterpret_cast<float4*>(dst)[i] = make_float4(v[0], v[1], v[2], v[3]);
+    else reinterpret_cast<uint2*>(dst)[i] = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const long i = (n4 << 2) + threadIdx.x; stx(dst, d32, i, ldx(src, s32, i)); }
+}
+
+// y = act(x)    /   dx = dy * act'(ref)   (ref = output for relu/tanh/sigmoid, pre-activation for gelu)
+__global__ __launch_bounds__(256) void act_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long n, int act) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = f2bf(act_apply(bf2f(x[i]), act));
+}
+__global__ __launch_bounds__(256) void act_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ ref,
+                                                      bf16_t* __restrict__ dx, long n, int act) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float g = bf2f(dy[i]), r = bf2f(ref[i]);
+    float d;
+    switch (act) {
+      case EVK_ACT_RELU: d = r > 0.f ? 1.f : 0.f; break;
+      case EVK_ACT_TANH: d = 1.f - r * r; break;
+      case EVK_ACT_SIGMOID: d = r * (1.f - r); break;
+      case EVK_ACT_GELU: d = 0.5f * (1.f + erff(r * 0.70710678118654752f)) + r * 0.3989422804014327f * __expf(-0.5f * r * r); break;
+      default: d = 1.f;
+    }
+    dx[i] = f2bf(g * d);
+  }
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ resid,
+                                                      bf16_t* __restrict__ y, long n, float p, unsigned long long seed) {
+  const float sc = 1.f / (1.f - p);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const bool keep = (hash32(seed * 0x9E3779B97F4A7C15ULL + (uint64_t)i) >> 8) * (1.f / 16777216.f) >= p;
+    float v = keep ? bf2f(x[i]) * sc : 0.f;
+    if (resid) v += bf2f(resid[i]);
+    y[i] = f2bf(v);
+  }
+}
+
+// out[r][:] = table[ids[r]][:] * scale + (pos ? pos[r % L][:] : 0) + (extra ? extra[:] : 0)
+__global__ __launch_bounds__(256) void embedding_fwd_kernel(const float* __restrict__ table, const long long* __restrict__ ids,
+                                                            const float* __restrict__ pos, const float* __restrict__ extra,
+                                                            void* __restrict__ out, int out_f32, long rows, int D, int L, float scale) {
+  const long total = rows * D;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / D;
+    const int c = (int)(i - r * D);
+    float v = table[ids[r] * D + c] * scale;
+    if (pos) v += pos[(r % L) * D + c];
+    if (extra) v += extra[c];
+    stx(out, out_f32, i, v);
+  }
+}
+// dtable[ids[r]][:] += dout[r][:] * scale  (rows with ids == padding_idx are skipped)
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const void* __restrict__ dout, int d_f32, const long long* __restrict__ ids,
+                                                            float* __restrict__ dtable, long rows, int D, float scale, long long padding_idx) {
+  const long total = rows * D;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / D;
+    const long long id = ids[r];
+    if (id == padding_idx) continue;
+    unsafeAtomicAdd(dtable + id * D + (i - r * D), ldx(dout, d_f32, i) * scale);
+  }
+}
+
+// out[c] += sum_r x[r*ld + c], c < N  (bias gradients). block = 128 column pairs x 2 row lanes
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, long M, int N, long ld,
+                                                     long rows_per_block) {
+  const int cp = blockIdx.x * 128 + (threadIdx.x & 127);
+  const int c = cp * 2;
+  const long r0 = blockIdx.y * rows_per_block + (threadIdx.x >> 7);
+  const long r1 = min(M, (long)(blockIdx.y + 1) * rows_per_block);
+  float a = 0.f, b = 0.f;
+  if (c < N) {
+    if (c + 1 < N || ld > N) {
+      for (long r = r0; r < r1; r += 2) {
+        const uint32_t t = *reinterpret_cast<const uint32_t*>(x + r * ld + c);
+        a += lo_bf(t); b += hi_bf(t);
+      }
+    } else {
+      for (long r = r0; r < r1; r += 2) a += bf2f(x[r * ld + c]);
+    }
+  }
+  __shared__ float red[2][256];
+  red[0][threadIdx.x] = a; red[1][threadIdx.x] = b;
+  __syncthreads();
+  if (threadIdx.x < 128 && c < N) {
+    unsafeAtomicAdd(out + c, red[0][threadIdx.x] + red[0][threadIdx.x + 128]);
+    if (c + 1 < N) unsafeAtomicAdd(out + c + 1, red[1][threadIdx.x] + red[1][threadIdx.x + 128]);
+  }
+}
+
+// relational-memory gate: gates = gw[b][1][2d] (broadcast over slots) + gu[b][s][2d];
+//   next = sigmoid(ig) * tanh(nm) + sigmoid(fg) * m          (encoder_decoder.py:282-288)
+__global__ __launch_bounds__(256) void rm_gate_fwd_kernel(const bf16_t* __restrict__ gw, const bf16_t* __restrict__ gu,
+                                                          const bf16_t* __restrict__ nm, const bf16_t* __restrict__ m,
+                                                          bf16_t* __restrict__ out, bf16_t* __restrict__ sig_i, bf16_t* __restrict__ sig_f,
+                                                          bf16_t* __restrict__ tnm, long B, int S, int D) {
+  const long total = B * S * D;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % D);
+    const long bs = i / D;
+    const long b = bs / S;
+    const float ig = bf2f(gw[b * 2 * D + c]) + bf2f(gu[bs * 2 * D + c]);
+    const float fg = bf2f(gw[b * 2 * D + D + c]) + bf2f(gu[bs * 2 * D + D + c]);
+    const float si = 1.f / (1.f + __expf(-ig)), sf = 1.f / (1.f + __expf(-fg)), t = tanhf(bf2f(nm[i]));
+    out[i] = f2bf(si * t + sf * bf2f(m[i]));
+    if (sig_i) { sig_i[i] = f2bf(si); sig_f[i] = f2bf(sf); tnm[i] = f2bf(t); }
+  }
+}
+// given dnext: dnm = dnext*si*(1-t^2); dm_direct = dnext*sf; dgates[b][s][2d] = {dnext*t*si*(1-si), dnext*m*sf*(1-sf)}
+__global__ __launch_bounds__(256) void rm_gate_bwd_kernel(const bf16_t* __restrict__ dnext, const bf16_t* __restrict__ sig_i,
+                                                          const bf16_t* __restrict__ sig_f, const bf16_t* __restrict__ tnm,
+                                                          const bf16_t* __restrict__ m, bf16_t* __restrict__ dnm, bf16_t* __restrict__ dm,
+                                                          bf16_t* __restrict__ dgates, long B, int S, int D) {
+  const long total = B * S * D;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % D);
+    const long bs = i / D;
+    const float g = bf2f(dnext[i]), si = bf2f(sig_i[i]), sf = bf2f(sig_f[i]), t = bf2f(tnm[i]);
+    dnm[i] = f2bf(g * si * (1.f - t * t));
+    dm[i] = f2bf(g * sf);
+    dgates[bs * 2 * D + c] = f2bf(g * t * si * (1.f - si));
+    dgates[bs * 2 * D + D + c] = f2bf(g * bf2f(m[i]) * sf * (1.f - sf));
+  }
+}
+
+// fused step over a flat parameter buffer: g = clamp(g, -clip, clip) ; RAdam (torch.optim.RAdam, decoupled=False)
+// or Adam with amsgrad + L2 weight decay (optimizers.py:19-21 "AdamW" == optim.Adam(amsgrad=True)); also refreshes
+// the bf16 shadow used as GEMM operand.  Hyper-parameters that depend on the step count are precomputed on the host.
+struct OptP {
+  float* p; const float* g; float* m; float* v; float* vmax; bf16_t* shadow; long n;
+  float lr, beta1, beta2, eps, wd, clip, bc1, bc2_sqrt, rect; int kind; int use_rect;
+};
+__global__ __launch_bounds__(256) void optim_kernel(const OptP o) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < o.n; i += (long)gridDim.x * blockDim.x) {
+    float g = o.g[i];
+    if (o.clip > 0.f) g = fminf(fmaxf(g, -o.clip), o.clip);
+    float w = o.p[i];
+    if (o.wd != 0.f) g += o.wd * w;
+    const float m = o.beta1 * o.m[i] + (1.f - o.beta1) * g;
+    const float v = o.beta2 * o.v[i] + (1.f - o.beta2) * g * g;
+    o.m[i] = m; o.v[i] = v;
+    if (o.kind == 0) {          // RAdam
+      const float mh = m / o.bc1;
+      if (o.use_rect) w -= o.lr * mh * o.rect * o.bc2_sqrt / (sqrtf(v) + o.eps);
+      else w -= o.lr * mh;
+    } else {                    // Adam (+amsgrad)
+      float vv = v;
+      if (o.vmax) { vv = fmaxf(o.vmax[i], v); o.vmax[i] = vv; }
+      w -= (o.lr / o.bc1) * m / (sqrtf(vv) / o.bc2_sqrt + o.eps);
+    }
+    o.p[i] = w;
+    if (o.shadow) o.shadow[i] = f2bf(w);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int evk_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(src && dst && n > 0, "cast: bad args");
+  ProfScope ps(EVK_FAM_ELTWISE, s);
+  hipLaunchKernelGGL(cast_kernel, dim3(ew_blocks(n / 4 + 1)), dim3(256), 0, s, src, src_dtype == EVK_F32, dst, dst_dtype == EVK_F32, (long)n);
+  return evk_check_launch("cast");
+}
+
+int evk_act_fwd(const void* x, void* y, int64_t n, int32_t act, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(x && y && n > 0, "act_fwd: bad args");
+  ProfScope ps(EVK_FAM_ELTWISE, s);
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, (long)n, act);
+  return evk_check_launch("act_fwd");
+}
+
+int evk_act_bwd(const void* dy, const void* ref, void* dx, int64_t n, int32_t act, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(dy && ref && dx && n > 0, "act_bwd: bad args");
+  ProfScope ps(EVK_FAM_ELTWISE, s);
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)ref, (bf16_t*)dx, (long)n, act);
+  return evk_check_launch("act_bwd");
+}
+
+int evk_dropout(const void* x, const void* resid, void* y, int64_t n, float p, uint64_t seed, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(x && y && n > 0 && p >= 0.f && p < 1.f, "dropout: bad args");
+  ProfScope ps(EVK_FAM_ELTWISE, s);
+  hipLaunchKernelGGL(dropout_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)resid, (bf16_t*)y, (long)n, p, (unsigned long long)seed);
+  return evk_check_launch("dropout");
+}
+
+int evk_embedding_fwd(const float* table, const int64_t* ids, const float* pos, const float* extra, void* out, int out_dtype,
+                      int64_t rows, int32_t D, int32_t L, float scale, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(table && ids && out && rows > 0 && D > 0 && L > 0, "embedding_fwd: bad args");
+  ProfScope ps(EVK_FAM_ELTWISE, s);
+  hipLaunchKernelGGL(embedding_fwd_kernel, dim3(ew_blocks(rows * D)), dim3(256), 0, s, table, (const long long*)ids, pos, extra, out,
+                     out_dtype == EVK_F32, (long)rows, D, L, scale);
+  return evk_check_launch("embedding_fwd");
+}
+
+int evk_embedding_bwd(const void* dout, int d_dtype, const int64_t* ids, float* dtable, int64_t rows, int32_t D, float scale,
+                      int64_t padding_idx, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(dout && ids && dtable && rows > 0 && D > 0, "embedding_bwd: bad args");
+  ProfScope ps(EVK_FAM_ELTWISE, s);
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(ew_blocks(rows * D)), dim3(256), 0, s, dout, d_dtype == EVK_F32, (const long long*)ids,
+                     dtable, (long)rows, D, scale, (long long)padding_idx);
+  return evk_check_launch("embedding_bwd");
+}
+
+int evk_colsum(const void* x, float* out, int64_t M, int32_t N, int64_t ld, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(x && out && M > 0 && N > 0 && ld >= N && ld % 2 == 0, "colsum: bad args (ld must be even)");
+  const int bx = (int)cdiv(N, 256);
+  long by = cdiv(1024, bx);
+  if (by > cdiv(M, 16)) by = cdiv(M, 16);
+  if (by < 1) by = 1;
+  long rpb = cdiv(M, by);
+  rpb += rpb & 1;
+  by = cdiv(M, rpb);
+  ProfScope ps(EVK_FAM_REDUCE, s);
+  hipLaunchKernelGGL(colsum_kernel, dim3(bx, (int)by), dim3(256), 0, s, (const bf16_t*)x, out, (long)M, N, (long)ld, rpb);
+  return evk_check_launch("colsum");
+}
+
+int evk_rm_gate_fwd(const void* gw, const void* gu, const void* nm, const void* m, void* out, void* sig_i, void* sig_f, void* tnm,
+                    int64_t B, int32_t S, int32_t D, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(gw && gu && nm && m && out && B > 0 && S > 0 && D > 0, "rm_gate_fwd: bad args");
+  ProfScope ps(EVK_FAM_ELTWISE, s);
+  hipLaunchKernelGGL(rm_gate_fwd_kernel, dim3(ew_blocks(B * S * D)), dim3(256), 0, s, (const bf16_t*)gw, (const bf16_t*)gu,
+                     (const bf16_t*)nm, (const bf16_t*)m, (bf16_t*)out, (bf16_t*)sig_i, (bf16_t*)sig_f, (bf16_t*)tnm, (long)B, S, D);
+  return evk_check_launch("rm_gate_fwd");
+}
+
+int evk_rm_gate_bwd(const void* dnext, const void* sig_i, const void* sig_f, const void* tnm, const void* m, void* dnm, void* dm,
+                    void* dgates, int64_t B, int32_t S, int32_t D, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(dnext && sig_i && sig_f && tnm && m && dnm && dm && dgates && B > 0, "rm_gate_bwd: bad args");
+  ProfScope ps(EVK_FAM_ELTWISE, s);
+  hipLaunchKernelGGL(rm_gate_bwd_kernel, dim3(ew_blocks(B * S * D)), dim3(256), 0, s, (const bf16_t*)dnext, (const bf16_t*)sig_i,
+                     (const bf16_t*)sig_f, (const bf16_t*)tnm, (const bf16_t*)m, (bf16_t*)dnm, (bf16_t*)dm, (bf16_t*)dgates, (long)B, S, D);
+  return evk_check_launch("rm_gate_bwd");
+}
+
+int evk_optim_step(float* p, const float* g, float* m, float* v, float* vmax, void* shadow, int64_t n, int32_t kind, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, float clip, int64_t step, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(p && g && m && v && n > 0 && step >= 1 && (kind == 0 || kind == 1), "optim_step: bad args");
+  OptP o{p, g, m, v, vmax, (bf16_t*)shadow, n, lr, beta1, beta2, eps, weight_decay, clip, 0.f, 0.f, 0.f, kind, 0};
+  const double b1t = pow((double)beta1, (double)step), b2t = pow((double)beta2, (double)step);
+  o.bc1 = (float)(1.0 - b1t);
+  o.bc2_sqrt = (float)sqrt(1.0 - b2t);
+  if (kind == 0) {  // torch.optim.RAdam
+    const double rho_inf = 2.0 / (1.0 - beta2) - 1.0;
+    const double rho_t = rho_inf - 2.0 * step * b2t / (1.0 - b2t);
+    o.use_rect = rho_t > 5.0;
+    if (o.use_rect) o.rect = (float)sqrt((rho_t - 4.0) * (rho_t - 2.0) * rho_inf / ((rho_inf - 4.0) * (rho_inf - 2.0) * rho_t));
+  }
+  ProfScope ps(EVK_FAM_OPTIM, s);
+  hipLaunchKernelGGL(optim_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, o);
+  return evk_check_launch("optim_step");
+}
+
+}  // extern "C"

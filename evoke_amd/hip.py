@@ -34,12 +34,40 @@ class Gemm(C.Structure):
                 ('g', ConvGeom)]
 
 
+_CTYPES = {'int': C.c_int32, 'int32_t': C.c_int32, 'int64_t': C.c_int64, 'uint64_t': C.c_uint64, 'float': C.c_float,
+           'evk_stream_t': C.c_void_p}
+
+
+def _prototypes():
+    """argtypes for every `int evk_*(...)` prototype of include/evoke_hip.h (pointers -> void*)."""
+    import re
+    hdr = os.path.join(os.path.dirname(_HERE), 'include', 'evoke_hip.h')
+    txt = re.sub(r'/\*.*?\*/', '', open(hdr).read(), flags=re.S)
+    out = {}
+    for m in re.finditer(r'\bint\s+(evk_[a-z0-9_]+)\s*\(([^)]*)\)\s*;', txt):
+        args = []
+        for a in m.group(2).split(','):
+            a = a.strip()
+            if a in ('void', ''):
+                continue
+            if '*' in a:
+                args.append(C.c_void_p)
+            else:
+                args.append(_CTYPES[a.replace('const ', '').split()[0]])
+        out[m.group(1)] = args
+    return out
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError('evoke_amd: %s is missing -- build it with `python -m evoke_amd.build` '
                            '(the HIP engine has no CPU/PyTorch fallback)' % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
     lib.evk_last_error.restype = C.c_char_p
+    for name, args in _prototypes().items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
     return lib
 
 
@@ -52,11 +80,11 @@ def check(status, what=''):
 
 
 def stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return torch.cuda.current_stream().cuda_stream
 
 
 def ptr(t):
-    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    return t.data_ptr() if t is not None else None
 
 
 def dt(t):

@@ -1,0 +1,595 @@
+"""Parameter containers + HIP forward passes of the non-convolutional blocks of the path.
+
+Names and shapes reproduce the reference state_dict:
+  * TextEncoderModel            models/language_encoder/language_model.py:120-158 (HF BertModel, 6 layers / 768)
+  * BertLayer / BertCrossLayer  models/language_encoder/bert_model.py:444-502, 548-628 (vendored HF BERT)
+  * projection heads, ScaledDotProductAttention    modules/utils_v0511.py:131-279
+  * R2Gen EncoderDecoder        modules/encoder_decoder.py:37-404, modules/att_model.py:28-72
+Every heavy op goes through evoke_amd.ops (HIP kernels); torch is used for views / cat / index plumbing.
+"""
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip as H
+from . import ops
+from .ops import BF16, F32
+from .trunk import BNP, batchnorm
+
+
+class LinearP(nn.Module):
+    """nn.Linear parameter holder (default nn.Linear init)."""
+
+    def __init__(self, in_f, out_f):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(out_f, in_f))
+        self.bias = nn.Parameter(torch.empty(out_f))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1 / math.sqrt(in_f)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x, resid=None, act=H.ACT_NONE, out_f32=False):
+        return ops.linear(x, self.weight, self.bias, resid=resid, act=act, out_f32=out_f32)
+
+
+class Conv1dP(nn.Module):
+    """nn.Conv1d(kernel_size=1) parameter holder: weight (out, in, 1)."""
+
+    def __init__(self, in_f, out_f):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(out_f, in_f, 1))
+        self.bias = nn.Parameter(torch.empty(out_f))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1 / math.sqrt(in_f)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x):
+        return ops.linear(x, self.weight, self.bias)
+
+
+class LayerNormP(nn.Module):
+    def __init__(self, d, eps=1e-5):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(d))
+        self.bias = nn.Parameter(torch.zeros(d))
+        self.eps = eps
+
+    def forward(self, x):
+        return ops.layernorm(x, self.weight, self.bias, eps=self.eps, mode=0)
+
+
+class EmbP(nn.Module):
+    def __init__(self, n, d, std=0.02):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(n, d) * std)
+
+
+class _Empty(nn.Module):
+    """index placeholder (ReLU / Dropout slots of an nn.Sequential in the reference)."""
+
+    def forward(self, x):
+        return x
+
+
+def key_mask(mask):
+    """(B, S) 0/1 attention mask -> uint8 key mask for ops.attention, or None when nothing is masked."""
+    if mask is None:
+        return None
+    return mask.to(torch.uint8).contiguous()
+
+
+# ----------------------------------------------------------------------------------------------------
+# BERT blocks
+# ----------------------------------------------------------------------------------------------------
+class BertSelfAttentionP(nn.Module):
+    def __init__(self, h):
+        super().__init__()
+        self.query, self.key, self.value = LinearP(h, h), LinearP(h, h), LinearP(h, h)
+
+
+class BertSelfOutputP(nn.Module):
+    def __init__(self, h, eps):
+        super().__init__()
+        self.dense = LinearP(h, h)
+        self.LayerNorm = LayerNormP(h, eps)
+
+
+class BertAttention(nn.Module):
+    """bert_model.py:210-412: (cross-)attention + output dense + dropout + residual + LayerNorm."""
+
+    def __init__(self, h, heads, eps=1e-12, p_attn=0.1, p_hidden=0.1):
+        super().__init__()
+        self.self = BertSelfAttentionP(h)
+        self.output = BertSelfOutputP(h, eps)
+        self.heads, self.p_attn, self.p_hidden = heads, p_attn, p_hidden
+
+    def forward(self, x, kv=None, mask=None):
+        kv = x if kv is None else kv
+        q = self.self.query(x)
+        k = self.self.key(kv)
+        v = self.self.value(kv)
+        c = ops.attention(q, k, v, self.heads, mask=mask, p_drop=self.p_attn, training=self.training)
+        o = ops.linear_dropout_resid(c, self.output.dense.weight, self.output.dense.bias, x, self.p_hidden, self.training)
+        return self.output.LayerNorm(o)
+
+
+class BertIntermediateP(nn.Module):
+    def __init__(self, h, inter):
+        super().__init__()
+        self.dense = LinearP(h, inter)
+
+
+class BertOutputP(nn.Module):
+    def __init__(self, h, inter, eps):
+        super().__init__()
+        self.dense = LinearP(inter, h)
+        self.LayerNorm = LayerNormP(h, eps)
+
+
+class BertLayer(nn.Module):
+    """bert_model.py:548-628 (encoder configuration) / 444-502 (BertCrossLayer when cross=True)."""
+
+    def __init__(self, h, heads, inter=3072, eps=1e-12, cross=False, p_attn=0.1, p_hidden=0.1):
+        super().__init__()
+        self.attention = BertAttention(h, heads, eps, p_attn, p_hidden)
+        if cross:
+            self.crossattention = BertAttention(h, heads, eps, p_attn, p_hidden)
+        self.intermediate = BertIntermediateP(h, inter)
+        self.output = BertOutputP(h, inter, eps)
+        self.cross, self.p_hidden = cross, p_hidden
+
+    def forward(self, x, y=None, x_mask=None, y_mask=None):
+        a = self.attention(x, None, x_mask)
+        if self.cross:
+            a = self.crossattention(a, y, y_mask)
+        hmid = ops.activation(self.intermediate.dense(a), H.ACT_GELU)
+        o = ops.linear_dropout_resid(hmid, self.output.dense.weight, self.output.dense.bias, a, self.p_hidden, self.training)
+        return self.output.LayerNorm(o)
+
+
+class BertEmbeddingsP(nn.Module):
+    def __init__(self, vocab, h, max_pos, types, eps):
+        super().__init__()
+        self.word_embeddings = EmbP(vocab, h)
+        self.position_embeddings = EmbP(max_pos, h)
+        self.token_type_embeddings = EmbP(types, h)
+        self.LayerNorm = LayerNormP(h, eps)
+        # transformers==4.23.1 (the reference's pin) keeps position_ids as a persistent buffer
+        self.register_buffer('position_ids', torch.arange(max_pos).expand((1, -1)).clone())
+        with torch.no_grad():
+            self.word_embeddings.weight[0].zero_()      # nn.Embedding(padding_idx=0)
+
+
+class _BertEncoderP(nn.Module):
+    def __init__(self, layers, h, heads, inter, eps):
+        super().__init__()
+        self.layer = nn.ModuleList([BertLayer(h, heads, inter, eps) for _ in range(layers)])
+
+
+class _BertPoolerP(nn.Module):
+    def __init__(self, h):
+        super().__init__()
+        self.dense = LinearP(h, h)
+
+
+class BertModel(nn.Module):
+    """HF BertModel(...)[0] (last_hidden_state); the pooler exists only for state_dict compatibility."""
+
+    def __init__(self, vocab, h=768, layers=6, heads=12, inter=3072, max_pos=512, types=2, eps=1e-12, p_hidden=0.1):
+        super().__init__()
+        self.embeddings = BertEmbeddingsP(vocab, h, max_pos, types, eps)
+        self.encoder = _BertEncoderP(layers, h, heads, inter, eps)
+        self.pooler = _BertPoolerP(h)
+        self.p_hidden = p_hidden
+        self.hidden_size = h
+        for m in self.modules():
+            if isinstance(m, LinearP):
+                nn.init.normal_(m.weight, std=0.02)
+                nn.init.zeros_(m.bias)
+
+    def forward(self, input_ids, attention_mask):
+        e = self.embeddings
+        x = ops.embedding(input_ids.contiguous(), e.word_embeddings.weight, pos=e.position_embeddings.weight,
+                          extra=e.token_type_embeddings.weight, padding_idx=0)
+        x = ops.dropout(e.LayerNorm(x), self.p_hidden, self.training)
+        km = key_mask(attention_mask)
+        for layer in self.encoder.layer:
+            x = layer(x, None, km)
+        return x
+
+
+def _load_hf_weights(model, ckpt_dir):
+    """Best-effort warm start from a local HF checkpoint dir (shape-filtered, as the reference's
+    from_pretrained(ignore_mismatched_sizes=True) does for the 6-layer truncation, language_model.py:137-138)."""
+    if not ckpt_dir or not os.path.isdir(ckpt_dir):
+        return 0
+    sd = None
+    st = os.path.join(ckpt_dir, 'model.safetensors')
+    pt = os.path.join(ckpt_dir, 'pytorch_model.bin')
+    if os.path.exists(st):
+        from safetensors.torch import load_file
+        sd = load_file(st)
+    elif os.path.exists(pt):
+        sd = torch.load(pt, map_location='cpu')
+    if sd is None:
+        return 0
+    own = model.state_dict()
+    hit = {}
+    for k, v in sd.items():
+        kk = k[5:] if k.startswith('bert.') else k
+        if kk in own and own[kk].shape == v.shape:
+            hit[kk] = v
+    model.load_state_dict(hit, strict=False)
+    return len(hit)
+
+
+class TextEncoderModel(nn.Module):
+    """models/language_encoder/language_model.py:120-158."""
+
+    def __init__(self, config, tokenizer):
+        super().__init__()
+        self.encoder = BertModel(config['vocab_size'], h=config['encoder_hidden_size'],
+                                 layers=config['encoder_num_hidden_layers'], heads=config.get('encoder_num_heads', 12))
+        _load_hf_weights(self.encoder, config.get('text_checkpoint'))
+
+    def forward(self, input_ids, attention_mask):
+        return self.encoder(input_ids, attention_mask)
+
+
+# ----------------------------------------------------------------------------------------------------
+# projection heads  (utils_v0511.py:131-208)
+# ----------------------------------------------------------------------------------------------------
+class ProjectionHead(nn.Module):
+    def __init__(self, input_dim, hidden_dim, output_dim, final_bn):
+        super().__init__()
+        mods = [Conv1dP(input_dim, hidden_dim), BNP(hidden_dim), _Empty(), Conv1dP(hidden_dim, output_dim)]
+        if final_bn:
+            mods.append(BNP(output_dim, affine=False))
+        self.head = nn.Sequential(*mods)
+        self.final_bn = final_bn
+
+    def forward(self, x):
+        h = self.head[0](x)
+        h = batchnorm(h, self.head[1], self.training, relu=True)
+        h = self.head[3](h)
+        if self.final_bn:
+            h = batchnorm(h, self.head[4], self.training, relu=False)
+        return h
+
+
+# ----------------------------------------------------------------------------------------------------
+# multi-view cross attention (utils_v0511.py:211-279) -- batched var-len formulation
+# ----------------------------------------------------------------------------------------------------
+class ScaledDotProductAttention(nn.Module):
+    def __init__(self, d_model, d_k, d_v, h, dropout=.1):
+        super().__init__()
+        self.fc_q, self.fc_k = LinearP(d_model, h * d_k), LinearP(d_model, h * d_k)
+        self.fc_v, self.fc_o = LinearP(d_model, h * d_v), LinearP(h * d_v, d_model)
+        self.d_k, self.h, self.p = d_k, h, dropout
+        for m in (self.fc_q, self.fc_k, self.fc_v, self.fc_o):
+            nn.init.normal_(m.weight, std=0.001)
+            nn.init.constant_(m.bias, 0)
+
+    def forward(self, q_in, kv_in):
+        """q_in (G, nq, d), kv_in (G, nk, d) [detached by the caller] -> fc_o(attn) + q_in  (residual fused)."""
+        q = self.fc_q(q_in)
+        k = self.fc_k(kv_in)
+        v = self.fc_v(kv_in)
+        o = ops.attention(q, k, v, self.h, p_drop=self.p, training=self.training, scale=1.0 / math.sqrt(self.d_k))
+        return self.fc_o(o, resid=q_in)
+
+
+def multiview_fusion(x, patient_ids, batch_size, sdpa, ln2):
+    """...v0623_large_res.py:135-148 on LN1'd tokens x (N, T, D): anchors with same-study siblings get
+    LN2(SDPA(x_i, cat(x_j)) + x_i); the others keep x_i.  Anchors are grouped by sibling count so each group is
+    one batched call (the reference loops over anchors with M = T per GEMM)."""
+    pid = np.asarray(patient_ids)
+    same = pid.reshape(-1, 1) == pid.reshape(1, -1)
+    np.fill_diagonal(same, False)
+    groups = {}
+    for i in range(batch_size):
+        sib = np.nonzero(same[i])[0]
+        if len(sib):
+            groups.setdefault(len(sib), []).append((i, sib))
+    if not groups:
+        return x[:batch_size].contiguous()
+    dev = x.device
+    xd = x.detach()
+    T, D = x.shape[1], x.shape[2]
+    out_rows = [None] * batch_size
+    pieces, order = [], []
+    for s, items in sorted(groups.items()):
+        a_idx = torch.tensor([i for i, _ in items], device=dev)
+        s_idx = torch.tensor(np.concatenate([sib for _, sib in items]), device=dev)
+        q_in = x.index_select(0, a_idx)                                   # (G, T, D) keeps grad
+        kv_in = xd.index_select(0, s_idx).view(len(items), s * T, D)      # (G, s*T, D) detached
+        y = ln2(sdpa(q_in, kv_in))
+        pieces.append(y)
+        order += [i for i, _ in items]
+    lone = [i for i in range(batch_size) if i not in set(order)]
+    if lone:
+        pieces.append(x.index_select(0, torch.tensor(lone, device=dev)))
+        order += lone
+    allrows = torch.cat(pieces, 0)
+    inv = torch.empty(batch_size, dtype=torch.long)
+    inv[torch.tensor(order)] = torch.arange(batch_size)
+    return allrows.index_select(0, inv.to(dev))
+
+
+# ----------------------------------------------------------------------------------------------------
+# R2Gen memory-driven Transformer
+# ----------------------------------------------------------------------------------------------------
+class R2LayerNorm(nn.Module):
+    """encoder_decoder.py:93-103."""
+
+    def __init__(self, d, eps=1e-6):
+        super().__init__()
+        self.gamma = nn.Parameter(torch.ones(d))
+        self.beta = nn.Parameter(torch.zeros(d))
+        self.eps = eps
+
+    def forward(self, x):
+        return ops.layernorm(x, self.gamma, self.beta, eps=self.eps, mode=1)
+
+
+class ConditionalLayerNorm(nn.Module):
+    """encoder_decoder.py:144-179."""
+
+    def __init__(self, d_model, rm_num_slots, rm_d_model, eps=1e-6):
+        super().__init__()
+        self.gamma = nn.Parameter(torch.ones(d_model))
+        self.beta = nn.Parameter(torch.zeros(d_model))
+        self.eps = eps
+        self.mlp_gamma = nn.Sequential(LinearP(rm_num_slots * rm_d_model, d_model), _Empty(), LinearP(rm_d_model, rm_d_model))
+        self.mlp_beta = nn.Sequential(LinearP(rm_num_slots * rm_d_model, d_model), _Empty(), LinearP(d_model, d_model))
+        for m in self.modules():
+            if isinstance(m, LinearP):
+                nn.init.xavier_uniform_(m.weight)
+                nn.init.constant_(m.bias, 0.1)
+
+    def forward(self, x, memory):
+        dg = self.mlp_gamma[2](self.mlp_gamma[0](memory, act=H.ACT_RELU))
+        db = self.mlp_beta[2](self.mlp_beta[0](memory, act=H.ACT_RELU))
+        return ops.layernorm(x, self.gamma, self.beta, eps=self.eps, mode=1, dgam=dg, dbet=db)
+
+
+class MultiHeadedAttention(nn.Module):
+    """encoder_decoder.py:182-203 (dropout 0.1 on the probabilities is the reference's hard default)."""
+
+    def __init__(self, h, d_model, dropout=0.1):
+        super().__init__()
+        self.h, self.p = h, dropout
+        self.linears = nn.ModuleList([LinearP(d_model, d_model) for _ in range(4)])
+
+    def forward(self, q_in, k_in, v_in, mask=None, causal=False, resid=None):
+        q = self.linears[0](q_in)
+        k = self.linears[1](k_in)
+        v = self.linears[2](v_in)
+        c = ops.attention(q, k, v, self.h, mask=mask, causal=causal, p_drop=self.p, training=self.training)
+        return self.linears[3](c, resid=resid)
+
+
+class PositionwiseFeedForward(nn.Module):
+    def __init__(self, d_model, d_ff, dropout=0.1):
+        super().__init__()
+        self.w_1, self.w_2 = LinearP(d_model, d_ff), LinearP(d_ff, d_model)
+        self.p = dropout
+
+    def forward(self, x, resid=None):
+        h = ops.dropout(self.w_1(x, act=H.ACT_RELU), self.p, self.training)
+        return self.w_2(h, resid=resid)
+
+
+class _Sub(nn.Module):
+    def __init__(self, norm):
+        super().__init__()
+        self.norm = norm
+
+
+class EncoderLayer(nn.Module):
+    def __init__(self, d_model, h, d_ff, dropout):
+        super().__init__()
+        self.self_attn = MultiHeadedAttention(h, d_model)
+        self.feed_forward = PositionwiseFeedForward(d_model, d_ff, dropout)
+        self.sublayer = nn.ModuleList([_Sub(R2LayerNorm(d_model)) for _ in range(2)])
+        self.p = dropout
+
+    def forward(self, x, mask):
+        drop = self.training and self.p > 0 and ops.DROPOUT_ENABLED[0]
+        n = self.sublayer[0].norm(x)
+        if drop:
+            x = ops.dropout(self.self_attn(n, n, n, mask), self.p, True, resid=x)
+        else:
+            x = self.self_attn(n, n, n, mask, resid=x)
+        n = self.sublayer[1].norm(x)
+        if drop:
+            return ops.dropout(self.feed_forward(n), self.p, True, resid=x)
+        return self.feed_forward(n, resid=x)
+
+
+class Encoder(nn.Module):
+    def __init__(self, d_model, h, d_ff, dropout, n):
+        super().__init__()
+        self.layers = nn.ModuleList([EncoderLayer(d_model, h, d_ff, dropout) for _ in range(n)])
+        self.norm = R2LayerNorm(d_model)
+
+    def forward(self, x, mask):
+        for layer in self.layers:
+            x = layer(x, mask)
+        return self.norm(x)
+
+
+class DecoderLayer(nn.Module):
+    def __init__(self, d_model, h, d_ff, dropout, slots, rm_d):
+        super().__init__()
+        self.self_attn = MultiHeadedAttention(h, d_model)
+        self.src_attn = MultiHeadedAttention(h, d_model)
+        self.feed_forward = PositionwiseFeedForward(d_model, d_ff, dropout)
+        self.sublayer = nn.ModuleList([_Sub(ConditionalLayerNorm(d_model, slots, rm_d)) for _ in range(3)])
+        self.p = dropout
+
+    def _res(self, y_fn, x):
+        if self.training and self.p > 0 and ops.DROPOUT_ENABLED[0]:
+            return ops.dropout(y_fn(None), self.p, True, resid=x)
+        return y_fn(x)
+
+    def forward(self, x, enc, src_mask, tgt_key_mask, memory):
+        n = self.sublayer[0].norm(x, memory)
+        x = self._res(lambda r: self.self_attn(n, n, n, tgt_key_mask, causal=True, resid=r), x)
+        n = self.sublayer[1].norm(x, memory)
+        x = self._res(lambda r: self.src_attn(n, enc, enc, src_mask, resid=r), x)
+        n = self.sublayer[2].norm(x, memory)
+        return self._res(lambda r: self.feed_forward(n, resid=r), x)
+
+
+class Decoder(nn.Module):
+    def __init__(self, d_model, h, d_ff, dropout, n, slots, rm_d):
+        super().__init__()
+        self.layers = nn.ModuleList([DecoderLayer(d_model, h, d_ff, dropout, slots, rm_d) for _ in range(n)])
+        self.norm = R2LayerNorm(d_model)
+
+    def forward(self, x, enc, src_mask, tgt_key_mask, memory):
+        for layer in self.layers:
+            x = layer(x, enc, src_mask, tgt_key_mask, memory)
+        return self.norm(x)
+
+
+class EmbeddingsP(nn.Module):
+    def __init__(self, d_model, vocab):
+        super().__init__()
+        self.lut = EmbP(vocab, d_model, std=1.0)
+        self.d_model = d_model
+
+
+class PositionalEncodingP(nn.Module):
+    def __init__(self, d_model, max_len=5000):
+        super().__init__()
+        pe = torch.zeros(max_len, d_model)
+        position = torch.arange(0, max_len).unsqueeze(1).float()
+        div_term = torch.exp(torch.arange(0, d_model, 2).float() * -(math.log(10000.0) / d_model))
+        pe[:, 0::2] = torch.sin(position * div_term)
+        pe[:, 1::2] = torch.cos(position * div_term)
+        self.register_buffer('pe', pe.unsqueeze(0))
+
+
+class _RMGate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gw, gu, nm, m):
+        B, S, D = m.shape
+        out = torch.empty_like(m)
+        si, sf, t = torch.empty_like(m), torch.empty_like(m), torch.empty_like(m)
+        H.check(H.lib.evk_rm_gate_fwd(H.ptr(gw), H.ptr(gu), H.ptr(nm), H.ptr(m), H.ptr(out), H.ptr(si), H.ptr(sf), H.ptr(t),
+                                      B, S, D, H.stream()), 'rm_gate_fwd')
+        ctx.save_for_backward(si, sf, t, m)
+        return out
+
+    @staticmethod
+    def backward(ctx, dnext):
+        si, sf, t, m = ctx.saved_tensors
+        B, S, D = m.shape
+        dnext = dnext.contiguous()
+        dnm, dm = torch.empty_like(m), torch.empty_like(m)
+        dg = torch.empty(B, S, 2 * D, dtype=BF16, device=m.device)
+        H.check(H.lib.evk_rm_gate_bwd(H.ptr(dnext), H.ptr(si), H.ptr(sf), H.ptr(t), H.ptr(m), H.ptr(dnm), H.ptr(dm), H.ptr(dg),
+                                      B, S, D, H.stream()), 'rm_gate_bwd')
+        return dg.sum(dim=1), dg, dnm, dm
+
+
+class RelationalMemory(nn.Module):
+    """encoder_decoder.py:246-300."""
+
+    def __init__(self, num_slots, d_model, num_heads=1):
+        super().__init__()
+        self.num_slots, self.num_heads, self.d_model = num_slots, num_heads, d_model
+        self.attn = MultiHeadedAttention(num_heads, d_model)
+        self.mlp = nn.Sequential(LinearP(d_model, d_model), _Empty(), LinearP(d_model, d_model), _Empty())
+        self.W = LinearP(d_model, d_model * 2)
+        self.U = LinearP(d_model, d_model * 2)
+
+    def init_memory(self, batch_size, device):
+        m = torch.zeros(batch_size, self.num_slots, self.d_model, dtype=BF16, device=device)
+        m[:, :, :self.num_slots] = torch.eye(self.num_slots, dtype=BF16, device=device)
+        return m
+
+    def step(self, x_t, gw_t, m):
+        """x_t (B, d), gw_t = W(x_t) (B, 2d), m (B, slots, d) -> next memory (B, slots, d)."""
+        kv = torch.cat([m, x_t.unsqueeze(1)], 1)
+        nm = self.attn(m, kv, kv, resid=m)
+        h = self.mlp[2](self.mlp[0](nm, act=H.ACT_RELU), act=H.ACT_RELU)
+        nm = nm + h
+        gu = self.U(ops.activation(m, H.ACT_TANH))
+        return _RMGate.apply(gw_t, gu, nm, m)
+
+    def forward(self, emb):
+        """emb (B, L, d) -> (B, L, slots*d): serial over tokens (encoder_decoder.py:293-300)."""
+        B, L, _ = emb.shape
+        m = self.init_memory(B, emb.device)
+        gw = self.W(emb)                      # W(x_t) for every t in one GEMM
+        outs = []
+        for t in range(L):
+            m = self.step(emb[:, t].contiguous(), gw[:, t].contiguous(), m)
+            outs.append(m.view(B, self.num_slots * self.d_model))
+        return torch.stack(outs, dim=1)
+
+
+class Transformer(nn.Module):
+    def __init__(self, cfg, tgt_vocab):
+        super().__init__()
+        d, h, dff, p, n = cfg['d_model'], cfg['num_heads'], cfg['d_ff'], cfg['dropout'], cfg['num_layers']
+        self.encoder = Encoder(d, h, dff, p, n)
+        self.decoder = Decoder(d, h, dff, p, n, cfg['rm_num_slots'], cfg['rm_d_model'])
+        self.tgt_embed = nn.Sequential(EmbeddingsP(d, tgt_vocab), PositionalEncodingP(d))
+        self.rm = RelationalMemory(cfg['rm_num_slots'], cfg['rm_d_model'], cfg['rm_num_heads'])
+        self.d_model, self.p = d, p
+        for prm in self.parameters():
+            if prm.dim() > 1:
+                nn.init.xavier_uniform_(prm)
+
+    def embed(self, ids):
+        x = ops.embedding(ids.contiguous(), self.tgt_embed[0].lut.weight, pos=self.tgt_embed[1].pe[0],
+                          scale=math.sqrt(self.d_model))
+        return ops.dropout(x, self.p, self.training)
+
+    def decode(self, enc, src_mask, ids, tgt_key_mask):
+        emb = self.embed(ids)
+        memory = self.rm(emb)
+        return self.decoder(emb, enc, src_mask, tgt_key_mask, memory)
+
+
+class EncoderDecoder(nn.Module):
+    """modules/encoder_decoder.py:303-404 + the AttModel pieces it relies on (att_model.py:38-72)."""
+
+    def __init__(self, args, tokenizer):
+        super().__init__()
+        self.args = args
+        self.vocab_size = tokenizer.get_vocab_size()
+        self.max_seq_length = args['max_seq_len']
+        self.bos_idx = tokenizer.token_to_id('[BOS]')
+        self.eos_idx = tokenizer.token_to_id('[EOS]')
+        self.pad_idx = tokenizer.token_to_id('[PAD]')
+        self.drop_prob_lm = args['drop_prob_lm']
+        if args.get('use_bn', 0):
+            raise NotImplementedError('use_bn != 0 is not on the path (config/finetune_config.yaml:43)')
+        self.att_embed = nn.Sequential(LinearP(args['d_vf'], args['d_model']), _Empty(), _Empty())
+        self.model = Transformer(args, self.vocab_size + 1)
+        self.logit = LinearP(args['d_model'], self.vocab_size + 1)
+
+    def encode(self, enc_states, enc_mask):
+        """_prepare_feature_forward + Transformer.encode: drops the global token, att_embed, 3-layer encoder."""
+        att = enc_states[:, 1:, :].contiguous()
+        am = enc_mask[:, 1:]
+        all_on = bool(am.all()) if am.numel() else True
+        if not all_on:
+            att = att * am.unsqueeze(-1).to(att.dtype)
+        feats = ops.dropout(self.att_embed[0](att, act=H.ACT_RELU), self.drop_prob_lm, self.training)
+        src_mask = None if all_on else key_mask(am)
+        return self.model.encoder(feats, src_mask), src_mask
+
+    def forward_logits(self, input_ids, enc_states, attention_mask, enc_mask):
+        """-> f32 logits (B, L, pad8(V+1)); the log_softmax is fused into the loss / the decode step."""
+        enc, src_mask = self.encode(enc_states, enc_mask)
+        out = self.model.decode(enc, src_mask, input_ids, key_mask(attention_mask))
+        return self.logit(out, out_f32=True)

@@ -1,0 +1,166 @@
+"""Drop-in mirror of models/model_pretrain_finetune_v0623_large_res.py (FineTune 21-217, Pretrain 220-395) on the
+MI355X engine: same constructor (args dict, tokenizer, data_name), same forward signatures / return values, same
+state_dict keys -- main_224.py / main_384.py can import these classes instead of the reference's.
+
+The compute runs on hand-written HIP kernels (evoke_amd.ops / trunk / layers -> libevoke_hip.so).  There is no CPU
+path: calling forward without a GPU and the built library raises.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip as H
+from . import losses, ops
+from .layers import (BertLayer, EncoderDecoder, LayerNormP, ProjectionHead, ScaledDotProductAttention, TextEncoderModel,
+                     key_mask, multiview_fusion)
+from .ops import BF16, F32
+from .trunk import ResNet
+
+NO_FINDING = "there is no evidence of pulmonary."
+
+
+class _Base(nn.Module):
+    def __str__(self):
+        params = sum(int(np.prod(p.size())) for p in self.parameters() if p.requires_grad)
+        return super().__str__() + '\nTrainable parameters: {}'.format(params / 1e6)
+
+    def visual_forward_mimic_cxr(self, images):
+        att_feats, fc_feats = self.visual_extractor(images)
+        return fc_feats, att_feats
+
+    def _image_tokens(self, images, patient_ids, batch_size):
+        """visual_forward + (multiview_fusion | plain LN1) + visual_head -> (fc (N,D) bf16, tokens (B,T,D) bf16)."""
+        fc, att = self.visual_forward(images)
+        x = torch.cat([fc.unsqueeze(1), att], dim=1)
+        x = self.layer_norm_1(x)
+        if self.args['is_multiview_learning']:
+            x = multiview_fusion(x, patient_ids, batch_size, self.multiview_cross_attention, self.layer_norm_2)
+        elif x.shape[0] != batch_size:
+            x = x[:batch_size].contiguous()
+        return fc, self.visual_head(x)
+
+
+class FineTune(_Base):
+    def __init__(self, args: dict, tokenizer: object, data_name: str):
+        super().__init__()
+        self.args = args
+        self.tokenizer = tokenizer
+        visual_dim = 2048
+        self.visual_extractor = ResNet(args)
+        self.text_encoder = TextEncoderModel(args, tokenizer)
+        self.layer_norm_1 = LayerNormP(visual_dim)
+        self.layer_norm_2 = LayerNormP(visual_dim)
+        self.text_decoder = EncoderDecoder(args, tokenizer)
+        text_dim = self.text_encoder.encoder.hidden_size
+        self.visual_head = ProjectionHead(visual_dim, args['output_dim'], args['output_dim'], final_bn=True)
+        self.text_head = ProjectionHead(text_dim, args['output_dim'], args['output_dim'], final_bn=True)
+        self.multiview_cross_attention = ScaledDotProductAttention(visual_dim, visual_dim, visual_dim, h=8)
+        nl, heads, hid = args['sk_fusion_num_layers'], args['fusion_num_heads'], args['output_dim']
+        self.visual_self_atten_layers = nn.ModuleList([BertLayer(hid, heads) for _ in range(nl)])
+        self.multimodal_fusion_layers = nn.ModuleList([BertLayer(hid, heads, cross=True) for _ in range(nl)])
+        for layers in (self.visual_self_atten_layers, self.multimodal_fusion_layers):
+            for m in layers.modules():
+                if hasattr(m, 'weight') and isinstance(m.weight, nn.Parameter) and m.weight.dim() == 2:
+                    nn.init.normal_(m.weight, std=0.02)
+                    nn.init.zeros_(m.bias)
+        self.visual_forward = self.visual_forward_mimic_cxr
+        self.text_decoder_forward = self.text_decoder_forward_r2gen
+
+    def freeze_encoder_models(self, freeze_image_encoder: bool, freeze_text_encoder: bool):
+        if freeze_image_encoder:
+            for m in (self.visual_extractor, self.visual_head):
+                for p in m.parameters():
+                    p.requires_grad = False
+        if freeze_text_encoder:
+            for m in (self.text_encoder, self.text_head):
+                for p in m.parameters():
+                    p.requires_grad = False
+
+    def encoder_states(self, images, patient_ids, batch_size, inc_ids=None, inc_masks=None):
+        """lines 152-203: image tokens -> (indication cross-fusion | visual self-attention) -> (B,T,D) bf16."""
+        device = images.device
+        _, x = self._image_tokens(images, patient_ids, batch_size)
+        enc_mask = torch.ones(x.shape[:2], dtype=torch.long, device=device)
+        if inc_ids is not None:
+            inc_ids, inc_masks = inc_ids.to(device, non_blocking=True), inc_masks.to(device, non_blocking=True)
+            y = self.text_head(self.text_encoder(input_ids=inc_ids, attention_mask=inc_masks))
+            ym = key_mask(inc_masks)
+            for layer in self.multimodal_fusion_layers:
+                x = layer(x, y, None, ym)
+        else:
+            for layer in self.visual_self_atten_layers:
+                x = layer(x, None, None, None)
+        return x, enc_mask
+
+    def text_decoder_forward_r2gen(self, input_ids, attention_mask, encoder_hidden_states, encoder_attention_mask, mode='train'):
+        if mode == 'train':
+            logits = self.text_decoder.forward_logits(input_ids, encoder_hidden_states, attention_mask, encoder_attention_mask)
+            return losses.lm_loss(logits, input_ids, attention_mask, self.text_decoder.vocab_size + 1)
+        from .decode import beam_search
+        output = beam_search(self.text_decoder, encoder_hidden_states, encoder_attention_mask, self.args)
+        gen_texts = self.tokenizer.decode_batch(output.cpu().tolist())
+        gt_texts = self.tokenizer.decode_batch(input_ids.cpu().tolist())
+        if mode == 'sample':
+            return [[t if len(t) > 0 else NO_FINDING for t in gen_texts], gt_texts]
+        if mode == 'test':
+            return [gen_texts, gt_texts]
+        return [[t if len(t) > 0 else NO_FINDING for t in gen_texts], output]
+
+    def forward(self, images, report_ids, report_masks, patient_ids, inc_ids=None, inc_masks=None, mode='train'):
+        if mode not in ('train', 'sample', 'inference'):
+            raise ValueError
+        x, enc_mask = self.encoder_states(images, patient_ids, report_ids.shape[0], inc_ids, inc_masks)
+        ret = self.text_decoder_forward(report_ids.to(images.device), report_masks.to(images.device), x, enc_mask, mode=mode)
+        if mode == 'train':
+            return {'lm': ret, 'all_loss': ret}
+        return [ret[0], ret[1]]
+
+
+class Pretrain(_Base):
+    def __init__(self, args: dict, tokenizer: object, data_name: str):
+        super().__init__()
+        self.args = args
+        self.tokenizer = tokenizer
+        visual_dim = 2048
+        self.visual_extractor = ResNet(args)
+        self.text_encoder = TextEncoderModel(args, tokenizer)
+        self.layer_norm_1 = LayerNormP(visual_dim)
+        self.layer_norm_2 = LayerNormP(visual_dim)
+        text_dim = self.text_encoder.encoder.hidden_size
+        self.visual_head = ProjectionHead(visual_dim, args['output_dim'], args['output_dim'], final_bn=False)
+        self.text_head = ProjectionHead(text_dim, args['output_dim'], args['output_dim'], final_bn=False)
+        self.multiview_cross_attention = ScaledDotProductAttention(visual_dim, visual_dim, visual_dim, h=8)
+        self.visual_forward = self.visual_forward_mimic_cxr
+        self.gather = None          # set by evoke_amd.distributed for the cross-rank contrastive negatives
+
+    def obtain_text_embeds(self, input_ids, attention_mask):
+        t = self.text_head(self.text_encoder(input_ids=input_ids, attention_mask=attention_mask))
+        return t[:, 0, :], t[:, 1:, :]
+
+    def multi_pos_contra_images_v0401(self, global_image_embed, patient_ids):
+        return losses.multi_pos_contra_images(global_image_embed, patient_ids, self.args['region_temp'], self.gather)
+
+    def global_alignment_loss(self, global_image_embed, global_text_embed, patient_ids):
+        return losses.global_alignment(global_image_embed, global_text_embed, patient_ids, self.args['instance_temp'], self.gather)
+
+    def local_text_token_alignment_loss(self, local_image_embed, local_text_embed):
+        return losses.local_text_token_alignment(local_image_embed, local_text_embed, self.args['region_temp'])
+
+    def forward(self, images, radgraph_ids, radgraph_masks, patient_ids):
+        device = images.device
+        b = radgraph_ids.shape[0]
+        fc, tok = self._image_tokens(images, patient_ids, b)
+        mul_pos_loss = torch.tensor([0.0])
+        if self.args['is_multiview_learning']:
+            mul_pos_loss = self.multi_pos_contra_images_v0401(fc, patient_ids)
+        v_fc, v_att = tok[:, 0, :], tok[:, 1:, :]
+        t_fc, t_att = self.obtain_text_embeds(radgraph_ids.to(device), radgraph_masks.to(device))
+        instance_loss = self.global_alignment_loss(v_fc, t_fc, patient_ids)
+        sen_text_loss = self.local_text_token_alignment_loss(v_att, t_att)
+        all_loss = instance_loss + sen_text_loss
+        if self.args['is_multiview_learning']:
+            all_loss = all_loss + mul_pos_loss
+        return {'sen_image_loss': torch.tensor([0.0]), 'sen_text_loss': sen_text_loss, 'instance_loss': instance_loss,
+                'multiview_loss': mul_pos_loss, 'all_loss': all_loss}

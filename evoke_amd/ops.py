@@ -1,0 +1,459 @@
+"""Host-side operators of the engine: torch.autograd.Function wrappers whose forward AND backward enqueue
+hand-written HIP kernels through the C ABI (evoke_amd/hip.py -> libevoke_hip.so).  PyTorch is plumbing here:
+device memory, streams, the autograd tape.  No op in this file computes on the CPU or through torch math
+kernels for the heavy work; tiny O(C) vector updates (e.g. adding a [C] partial into a .grad) use torch.
+
+Conventions: activations are contiguous bf16 CUDA tensors [rows.., features]; parameters are f32 masters with a
+cached bf16 "shadow" that the GEMMs read; parameter gradients are accumulated in f32 directly into ``p.grad``
+(the backward returns None for them and fires ``grad_ready`` callbacks, which the DDP reducer listens to).
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import hip as H
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+# ----------------------------------------------------------------------------------------------------
+# parameter shadows + direct gradient accumulation
+# ----------------------------------------------------------------------------------------------------
+_shadows = {}
+_grad_callbacks = []
+
+
+def register_grad_callback(fn):
+    _grad_callbacks.append(fn)
+
+
+def clear_grad_callbacks():
+    del _grad_callbacks[:]
+
+
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+def shadow(p, pad_rows=False):
+    """bf16 copy of an f32 master weight (same physical layout), refreshed when the master changed."""
+    key = id(p)
+    ent = _shadows.get(key)
+    ver = p._version
+    if ent is not None and ent[1] == ver and ent[2] is p and ent[0].device == p.device:
+        return ent[0]
+    n = p.numel()
+    if ent is not None and ent[2] is p and ent[0].device == p.device:
+        sh = ent[0]
+    else:
+        rows = p.shape[0]
+        tot = n if not pad_rows else _pad8(rows) * (n // rows)
+        sh = torch.zeros(tot, dtype=BF16, device=p.device)
+    H.check(H.lib.evk_cast(H.ptr(p), H.F32, H.ptr(sh), H.BF16, n, H.stream()), 'cast')
+    _shadows[key] = (sh, ver, p)
+    return sh
+
+
+def set_shadow_fresh(p, sh):
+    """Used by the fused optimizer, which writes the bf16 shadow itself."""
+    _shadows[id(p)] = (sh, p._version, p)
+
+
+def grad_buffer(p):
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.preserve_format)
+    return p.grad
+
+
+def grad_done(p):
+    for fn in _grad_callbacks:
+        fn(p)
+
+
+def _z(*shape, dtype=BF16, device='cuda'):
+    return torch.zeros(*shape, dtype=dtype, device=device)
+
+
+def _e(*shape, dtype=BF16, device='cuda'):
+    return torch.empty(*shape, dtype=dtype, device=device)
+
+
+# ----------------------------------------------------------------------------------------------------
+# raw GEMM helper
+# ----------------------------------------------------------------------------------------------------
+def gemm(A, B, Cm, M, N, K, a_mode=H.A_PLAIN, b_mode=H.B_PLAIN, lda=0, ldb=0, ldc=0, bias=None, resid=None, ldr=0,
+         act=H.ACT_NONE, alpha=1.0, accumulate=False, batch=(1, 1), sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0),
+         a_off=0, b_off=0, c_off=0, b_klog=0, b_tapstride=0, splitk=0):
+    d = H.Gemm()
+    d.A = A.data_ptr() + a_off * A.element_size()
+    d.B = B.data_ptr() + b_off * B.element_size()
+    d.C = Cm.data_ptr() + c_off * Cm.element_size()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.resid = resid.data_ptr() if resid is not None else None
+    d.M, d.N, d.K, d.a_mode, d.b_mode = M, N, K, a_mode, b_mode
+    d.lda, d.ldb, d.ldc, d.ldr = lda, ldb, ldc, ldr
+    d.batch_outer, d.batch_inner = batch
+    d.sAo, d.sAi = sA
+    d.sBo, d.sBi = sB
+    d.sCo, d.sCi = sC
+    d.sRo, d.sRi = sR
+    d.alpha, d.act = alpha, act
+    d.c_dtype = H.dt(Cm)
+    d.r_dtype = H.dt(resid) if resid is not None else H.BF16
+    d.accumulate = 1 if accumulate else 0
+    d.splitk = splitk
+    d.b_klog, d.b_tapstride = b_klog, b_tapstride
+    H.check(H.lib.evk_gemm_launch(C.byref(d), H.stream()), 'gemm')
+
+
+def _rows(x):
+    return x.numel() // x.shape[-1]
+
+
+# ----------------------------------------------------------------------------------------------------
+# linear:  y = act(x W^T + b) (+ resid)
+# ----------------------------------------------------------------------------------------------------
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, b, resid, act, out_f32):
+        K = x.shape[-1]
+        N = W.shape[0]
+        M = _rows(x)
+        Np = _pad8(N)
+        w = shadow(W, pad_rows=(N != Np))
+        y = _e(M, Np, dtype=F32 if out_f32 else BF16, device=x.device) if Np == N else _z(M, Np, dtype=F32 if out_f32 else BF16, device=x.device)
+        gemm(x, w, y, M, N, K, lda=K, ldb=K, ldc=Np, bias=b, resid=resid, ldr=Np, act=act)
+        ctx.save_for_backward(x, y if act == H.ACT_RELU else None)
+        ctx.W, ctx.b, ctx.act, ctx.dims = W, b, act, (M, N, K, Np)
+        ctx.has_resid = resid is not None
+        return y.view(*x.shape[:-1], Np)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        W, b = ctx.W, ctx.b
+        M, N, K, Np = ctx.dims
+        dy = dy.contiguous()
+        if dy.dtype != BF16:
+            dy = dy.to(BF16)
+        dres = dy if ctx.has_resid else None
+        if ctx.act == H.ACT_RELU:
+            g = _e(M, Np, device=dy.device)
+            H.check(H.lib.evk_act_bwd(H.ptr(dy), H.ptr(y), H.ptr(g), M * Np, H.ACT_RELU, H.stream()), 'act_bwd')
+            dy = g
+        elif ctx.act != H.ACT_NONE:
+            raise RuntimeError('fused activation %d has no fused backward; use ops.activation' % ctx.act)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            w = shadow(W, pad_rows=(N != Np))
+            dx = _e(M, K, device=dy.device)
+            gemm(dy, w, dx, M, K, Np, b_mode=H.B_KSTR, lda=Np, ldb=K, ldc=K)
+            dx = dx.view(x.shape)
+        if W.requires_grad:
+            gw = grad_buffer(W)
+            gemm(dy, x, gw, N, K, M, a_mode=H.A_KSTR, b_mode=H.B_KSTR, lda=Np, ldb=K, ldc=K, accumulate=True)
+            grad_done(W)
+        if b is not None and b.requires_grad:
+            H.check(H.lib.evk_colsum(H.ptr(dy), H.ptr(grad_buffer(b)), M, N, Np, H.stream()), 'colsum')
+            grad_done(b)
+        return dx, None, None, dres, None, None
+
+
+def linear(x, W, b=None, resid=None, act=H.ACT_NONE, out_f32=False):
+    """nn.Linear / Conv1d(k=1) on the last dim.  Returns [.., pad8(N)] (pad columns are zero)."""
+    if W.dim() == 3:                      # Conv1d weight (out, in, 1): same memory as (out, in)
+        assert W.shape[2] == 1
+    assert x.dtype == BF16 and x.is_contiguous()
+    if resid is not None:
+        assert resid.is_contiguous() and resid.shape[-1] == _pad8(W.shape[0]) and act != H.ACT_RELU
+    return _Linear.apply(x, W, b, resid, act, out_f32)
+
+
+# ----------------------------------------------------------------------------------------------------
+# activations / dropout
+# ----------------------------------------------------------------------------------------------------
+class _Act(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        y = torch.empty_like(x)
+        H.check(H.lib.evk_act_fwd(H.ptr(x), H.ptr(y), x.numel(), act, H.stream()), 'act_fwd')
+        ctx.act = act
+        ctx.save_for_backward(x if act == H.ACT_GELU else y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ref, = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        H.check(H.lib.evk_act_bwd(H.ptr(dy), H.ptr(ref), H.ptr(dx), dy.numel(), ctx.act, H.stream()), 'act_bwd')
+        return dx, None
+
+
+def activation(x, act):
+    assert x.dtype == BF16 and x.is_contiguous()
+    return _Act.apply(x, act)
+
+
+_seed_state = [0x5EED5EED]
+DROPOUT_ENABLED = [True]      # tests switch the reference's dropout layers off (parity is defined without dropout)
+
+
+def set_dropout_enabled(on):
+    DROPOUT_ENABLED[0] = bool(on)
+
+
+def next_seed():
+    _seed_state[0] = (_seed_state[0] * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+    return _seed_state[0]
+
+
+def manual_seed(s):
+    _seed_state[0] = (int(s) * 2654435761 + 0x5EED5EED) & 0xFFFFFFFFFFFFFFFF
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, resid, p, seed):
+        y = torch.empty_like(x)
+        H.check(H.lib.evk_dropout(H.ptr(x), H.ptr(resid), H.ptr(y), x.numel(), C.c_float(p), C.c_uint64(seed), H.stream()), 'dropout')
+        ctx.p, ctx.seed, ctx.has_res = p, seed, resid is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        H.check(H.lib.evk_dropout(H.ptr(dy), None, H.ptr(dx), dy.numel(), C.c_float(ctx.p), C.c_uint64(ctx.seed), H.stream()), 'dropout')
+        return dx, (dy if ctx.has_res else None), None, None
+
+
+def dropout(x, p, training, resid=None):
+    """nn.Dropout (+ optional fused residual add: y = dropout(x) + resid)."""
+    if not training or p <= 0.0 or not DROPOUT_ENABLED[0]:
+        assert resid is None, 'fuse the residual into the producing GEMM when dropout is inactive'
+        return x
+    assert x.dtype == BF16 and x.is_contiguous() and (resid is None or resid.is_contiguous())
+    return _Dropout.apply(x, resid, float(p), next_seed())
+
+
+def linear_dropout_resid(x, W, b, resid, p, training):
+    """dense -> dropout -> + residual (HF BertSelfOutput/BertOutput): GEMM-epilogue residual when dropout is off."""
+    if training and p > 0.0 and DROPOUT_ENABLED[0]:
+        return dropout(linear(x, W, b), p, True, resid=resid)
+    return linear(x, W, b, resid=resid)
+
+
+# ----------------------------------------------------------------------------------------------------
+# LayerNorm family
+# ----------------------------------------------------------------------------------------------------
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, dgam, dbet, mode, eps):
+        D = x.shape[-1]
+        rows = _rows(x)
+        y = _e(*x.shape, device=x.device)
+        mean = _e(rows, dtype=F32, device=x.device)
+        rstd = _e(rows, dtype=F32, device=x.device)
+        H.check(H.lib.evk_layernorm_fwd(H.ptr(x), H.dt(x), H.ptr(y), H.BF16, H.ptr(gamma), H.ptr(beta), H.ptr(dgam), H.ptr(dbet),
+                                        H.BF16, H.ptr(mean), H.ptr(rstd), rows, D, mode, C.c_float(eps), H.stream()), 'ln_fwd')
+        ctx.save_for_backward(x, mean, rstd, dgam)
+        ctx.gamma, ctx.beta, ctx.mode, ctx.eps = gamma, beta, mode, eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, dgam = ctx.saved_tensors
+        gamma, beta = ctx.gamma, ctx.beta
+        D = x.shape[-1]
+        rows = _rows(x)
+        dy = dy.contiguous()
+        dx = _e(*x.shape, dtype=x.dtype, device=x.device)
+        want_vec = gamma.requires_grad
+        gg = grad_buffer(gamma) if want_vec else None
+        gb = grad_buffer(beta) if want_vec else None
+        ddg = ddb = None
+        if dgam is not None:
+            ddg = _e(*dgam.shape, device=x.device)
+            ddb = _e(*dgam.shape, device=x.device)
+        H.check(H.lib.evk_layernorm_bwd(H.ptr(dy), H.dt(dy), H.ptr(x), H.dt(x), H.ptr(gamma), H.ptr(dgam), H.BF16, H.ptr(mean),
+                                        H.ptr(rstd), H.ptr(dx), H.dt(dx), H.ptr(gg), H.ptr(gb), H.ptr(ddg), H.ptr(ddb), rows, D,
+                                        ctx.mode, C.c_float(ctx.eps), H.stream()), 'ln_bwd')
+        if want_vec:
+            grad_done(gamma)
+            grad_done(beta)
+        return dx, None, None, ddg, ddb, None, None
+
+
+def layernorm(x, gamma, beta, eps=1e-5, mode=0, dgam=None, dbet=None):
+    """mode 0: torch.nn.LayerNorm; mode 1: R2Gen LayerNorm (encoder_decoder.py:93-103); dgam/dbet: CLN deltas."""
+    assert x.is_contiguous() and x.dtype in (BF16, F32)
+    return _LayerNorm.apply(x, gamma, beta, dgam, dbet, mode, eps)
+
+
+# ----------------------------------------------------------------------------------------------------
+# multi-head attention core on projected q/k/v ([B,T,H*dh] / [B,S,H*dh] bf16, heads interleaved)
+# ----------------------------------------------------------------------------------------------------
+class _Attention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, mask, heads, scale, causal, p_drop, seed):
+        B, T, HD = q.shape
+        S = k.shape[1]
+        dh = HD // heads
+        Sp = _pad8(S)
+        dev = q.device
+        sc = _e(B, heads, T, Sp, dtype=F32, device=dev)
+        gemm(q, k, sc, T, S, dh, lda=HD, ldb=HD, ldc=Sp, alpha=scale, batch=(B, heads),
+             sA=(T * HD, dh), sB=(S * HD, dh), sC=(heads * T * Sp, T * Sp))
+        P = _e(B, heads, T, Sp, device=dev)
+        Pd = _e(B, heads, T, Sp, device=dev) if p_drop > 0 else None
+        mb = mq = 0
+        if mask is not None:
+            assert mask.dtype == torch.uint8 and mask.is_contiguous()
+            if mask.dim() == 2:
+                mb, mq = mask.shape[1], 0
+            else:
+                mb, mq = mask.shape[1] * mask.shape[2], mask.shape[2]
+        H.check(H.lib.evk_softmax_fwd(H.ptr(sc), H.ptr(P), H.ptr(Pd), H.BF16, H.ptr(mask), mb, mq, int(causal), B, heads, T, S, Sp, Sp,
+                                      C.c_float(p_drop), C.c_uint64(seed), H.stream()), 'softmax_fwd')
+        Pv = Pd if Pd is not None else P
+        # V rows beyond S are never multiplied by a non-zero probability, but must be readable: K = S (KSTR has no K%8 rule
+        # on B; A_PLAIN needs K%8 -> use Sp and rely on zero pad columns of P with k < S guard on V via kend = Sp?)
+        out = _e(B, T, HD, device=dev)
+        vv = v
+        if Sp != S:
+            vv = _z(B, Sp, HD, device=dev)
+            vv[:, :S].copy_(v)
+        gemm(Pv, vv, out, T, dh, Sp, b_mode=H.B_KSTR, lda=Sp, ldb=HD, ldc=HD, batch=(B, heads),
+             sA=(heads * T * Sp, T * Sp), sB=(Sp * HD, dh), sC=(T * HD, dh))
+        ctx.save_for_backward(q, k, vv, P, Pv)
+        ctx.cfg = (B, T, S, Sp, HD, heads, dh, scale, p_drop, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, vv, P, Pv = ctx.saved_tensors
+        B, T, S, Sp, HD, heads, dh, scale, p_drop, seed = ctx.cfg
+        dev = q.device
+        dout = dout.contiguous()
+        # dP' = dO . V^T   (f32 [B,h,T,Sp])
+        dP = _e(B, heads, T, Sp, dtype=F32, device=dev)
+        gemm(dout, vv, dP, T, Sp, dh, lda=HD, ldb=HD, ldc=Sp, batch=(B, heads),
+             sA=(T * HD, dh), sB=(Sp * HD, dh), sC=(heads * T * Sp, T * Sp))
+        # dV = P'^T . dO
+        dV = _e(B, S, HD, device=dev)
+        gemm(Pv, dout, dV, S, dh, T, a_mode=H.A_KSTR, b_mode=H.B_KSTR, lda=Sp, ldb=HD, ldc=HD, batch=(B, heads),
+             sA=(heads * T * Sp, T * Sp), sB=(T * HD, dh), sC=(S * HD, dh))
+        dS = _e(B, heads, T, Sp, device=dev)
+        H.check(H.lib.evk_softmax_bwd(H.ptr(dP), H.F32, Sp, H.ptr(P), H.ptr(dS), H.BF16, B * heads * T, S, Sp, C.c_float(scale),
+                                      C.c_float(p_drop), C.c_uint64(seed), H.stream()), 'softmax_bwd')
+        # dQ = dS . K   ;  dK = dS^T . Q      (dS already carries the 1/sqrt(d) factor)
+        dQ = _e(B, T, HD, device=dev)
+        kk = k
+        if Sp != S:
+            kk = _z(B, Sp, HD, device=dev)
+            kk[:, :S].copy_(k)
+        gemm(dS, kk, dQ, T, dh, Sp, b_mode=H.B_KSTR, lda=Sp, ldb=HD, ldc=HD, batch=(B, heads),
+             sA=(heads * T * Sp, T * Sp), sB=(Sp * HD, dh), sC=(T * HD, dh))
+        dK = _e(B, S, HD, device=dev)
+        gemm(dS, q, dK, S, dh, T, a_mode=H.A_KSTR, b_mode=H.B_KSTR, lda=Sp, ldb=HD, ldc=HD, batch=(B, heads),
+             sA=(heads * T * Sp, T * Sp), sB=(T * HD, dh), sC=(S * HD, dh))
+        return dQ, dK, dV, None, None, None, None, None, None
+
+
+def attention(q, k, v, heads, mask=None, causal=False, p_drop=0.0, training=False, scale=None):
+    """softmax(q k^T * scale [masked]) v per head.  mask: uint8 [B,S] (keys) or [B,T,S], 1 = attend."""
+    assert q.dtype == BF16 and q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
+    dh = q.shape[-1] // heads
+    if scale is None:
+        scale = 1.0 / math.sqrt(dh)
+    p = float(p_drop) if (training and DROPOUT_ENABLED[0]) else 0.0
+    return _Attention.apply(q, k, v, mask, heads, float(scale), causal, p, next_seed() if p > 0 else 0)
+
+
+# ----------------------------------------------------------------------------------------------------
+# embedding (f32 table -> bf16 rows), optional scale / positional table / constant row
+# ----------------------------------------------------------------------------------------------------
+class _Embedding(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids, table, pos, extra, scale, padding_idx):
+        rows, L = ids.numel(), ids.shape[-1]
+        D = table.shape[1]
+        out = _e(*ids.shape, D, device=table.device)
+        H.check(H.lib.evk_embedding_fwd(H.ptr(table), H.ptr(ids), H.ptr(pos), H.ptr(extra), H.ptr(out), H.BF16, rows, D, L,
+                                        C.c_float(scale), H.stream()), 'embedding_fwd')
+        ctx.save_for_backward(ids)
+        ctx.table, ctx.pos, ctx.extra, ctx.scale, ctx.padding_idx = table, pos, extra, scale, padding_idx
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ids, = ctx.saved_tensors
+        dout = dout.contiguous()
+        rows, L = ids.numel(), ids.shape[-1]
+        table, pos, extra = ctx.table, ctx.pos, ctx.extra
+        D = table.shape[1]
+        st = H.stream()
+        if table.requires_grad:
+            H.check(H.lib.evk_embedding_bwd(H.ptr(dout), H.dt(dout), H.ptr(ids), H.ptr(grad_buffer(table)), rows, D,
+                                            C.c_float(ctx.scale), ctx.padding_idx, st), 'embedding_bwd')
+            grad_done(table)
+        if pos is not None and pos.requires_grad:
+            pid = torch.arange(L, device=ids.device).repeat(rows // L)
+            H.check(H.lib.evk_embedding_bwd(H.ptr(dout), H.dt(dout), H.ptr(pid), H.ptr(grad_buffer(pos)), rows, D,
+                                            C.c_float(1.0), -1, st), 'embedding_bwd')
+            grad_done(pos)
+        if extra is not None and extra.requires_grad:
+            zid = torch.zeros(rows, dtype=torch.long, device=ids.device)
+            # `extra` is row 0 of a (types, D) table: accumulate into that row
+            H.check(H.lib.evk_embedding_bwd(H.ptr(dout), H.dt(dout), H.ptr(zid), H.ptr(grad_buffer(extra)), rows, D,
+                                            C.c_float(1.0), -1, st), 'embedding_bwd')
+            grad_done(extra)
+        return None, None, None, None, None, None
+
+
+def embedding(ids, table, pos=None, extra=None, scale=1.0, padding_idx=-1):
+    """out[r] = table[ids[r]]*scale + pos[r % L] + extra[0]; `pos` is a (>=L, D) table, `extra` a (types, D) table (row 0 used)."""
+    assert ids.dtype == torch.long and ids.is_contiguous()
+    return _Embedding.apply(ids, table, pos, extra, float(scale), int(padding_idx))
+
+
+# ----------------------------------------------------------------------------------------------------
+# masked NLL over padded f32 logits  (encoder_decoder.py:393 + loss.py:9-22)
+# ----------------------------------------------------------------------------------------------------
+class _NllLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, wmask, V):
+        rows = _rows(logits)
+        ld = logits.shape[-1]
+        lse = _e(rows, dtype=F32, device=logits.device)
+        acc = _z(2, dtype=F32, device=logits.device)
+        H.check(H.lib.evk_log_softmax_nll_fwd(H.ptr(logits), None, H.ptr(lse), H.ptr(target), H.ptr(wmask), H.ptr(acc), rows, V,
+                                              ld, ld, H.stream()), 'nll_fwd')
+        ctx.save_for_backward(logits, lse, target, wmask, acc)
+        ctx.V = V
+        return acc[0] / acc[1]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        logits, lse, target, wmask, acc = ctx.saved_tensors
+        rows, ld = _rows(logits), logits.shape[-1]
+        gs = (dloss.to(F32) / acc[1]).reshape(1).contiguous()
+        dl = _e(*logits.shape, device=logits.device)
+        H.check(H.lib.evk_nll_bwd(H.ptr(logits), H.ptr(lse), H.ptr(target), H.ptr(wmask), H.ptr(gs), H.ptr(dl), rows, ctx.V, ld, ld,
+                                  H.stream()), 'nll_bwd')
+        return dl, None, None, None
+
+
+def nll_loss(logits, target, wmask, V):
+    """logits f32 [rows.., ld>=V]; target int64 [rows]; wmask f32 [rows] -> sum(-logp[target]*w)/sum(w)."""
+    assert logits.dtype == F32 and logits.is_contiguous() and target.dtype == torch.long and wmask.dtype == F32
+    return _NllLoss.apply(logits, target.contiguous(), wmask.contiguous(), V)
+
+
+def log_softmax(logits, V):
+    """f32 [rows, ld] -> f32 log-probs [rows, V] (decode path, no autograd)."""
+    rows, ld = _rows(logits), logits.shape[-1]
+    out = _e(rows, V, dtype=F32, device=logits.device)
+    H.check(H.lib.evk_log_softmax_nll_fwd(H.ptr(logits), H.ptr(out), None, None, None, None, rows, V, ld, V, H.stream()), 'log_softmax')
+    return out

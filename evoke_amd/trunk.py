@@ -1,0 +1,294 @@
+"""ResNet-101 trunk of the visual extractor on the HIP engine (NHWC bf16, implicit-GEMM convolutions).
+
+Mirrors modules/visual_extractor.py:27-43 (ResNetTemp) -> torchvision resnet101 children 0-7; the parameter
+container keeps torchvision's names so ``visual_extractor.model.<idx>...`` state_dict keys match the reference.
+Conv weights are stored channels_last (physical [Co][KH][KW][Ci]) which is exactly the KRSC operand layout of the
+implicit-GEMM kernels; their logical shape stays (Co, Ci, KH, KW) for state_dict compatibility.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import hip as H
+from . import ops
+from .ops import BF16, F32, _e, _z, grad_buffer, grad_done, shadow
+
+RESNET_LAYERS = ((64, 3, 1), (128, 4, 2), (256, 23, 2), (512, 3, 2))
+
+
+# ----------------------------------------------------------------------------------------------------
+# autograd wrappers
+# ----------------------------------------------------------------------------------------------------
+class _Conv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, stride, pad):
+        N, Hi, Wi, Ci = x.shape
+        Co, _, KH, KW = W.shape
+        g = H.conv_geom(N, Hi, Wi, Ci, Co, KH, KW, stride, pad)
+        y = _e(N, g.Ho, g.Wo, Co, device=x.device)
+        H.check(H.lib.evk_conv2d_fwd(H.ptr(x), H.ptr(shadow(W)), H.ptr(y), C.byref(g), H.stream()), 'conv_fwd')
+        ctx.save_for_backward(x)
+        ctx.W, ctx.g = W, g
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        W, g = ctx.W, ctx.g
+        dy = dy.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _e(*x.shape, device=x.device)
+            H.check(H.lib.evk_conv2d_dgrad(H.ptr(dy), H.ptr(shadow(W)), H.ptr(dx), C.byref(g), H.stream()), 'conv_dgrad')
+        if W.requires_grad:
+            H.check(H.lib.evk_conv2d_wgrad(H.ptr(dy), H.ptr(x), H.ptr(grad_buffer(W)), C.byref(g), H.stream()), 'conv_wgrad')
+            grad_done(W)
+        return dx, None, None, None
+
+
+def conv2d(x, W, stride=1, pad=0):
+    assert x.dtype == BF16 and x.is_contiguous() and W.is_contiguous(memory_format=torch.channels_last)
+    return _Conv.apply(x, W, stride, pad)
+
+
+class _Stem(torch.autograd.Function):
+    """conv 7x7 s2 p3 (3 -> 64) from f32 NCHW images; no data gradient (images are inputs)."""
+
+    @staticmethod
+    def forward(ctx, images, W):
+        N, _, Hh, Ww = images.shape
+        st = H.stream()
+        xpad = _e(N, Hh + 6, Ww + 8, 4, device=images.device)
+        H.check(H.lib.evk_stem_pack_image(H.ptr(images), H.ptr(xpad), N, Hh, Ww, st), 'stem_pack_image')
+        wp = _e(64 * 224, device=images.device)
+        H.check(H.lib.evk_stem_pack_weight(H.ptr(W), H.ptr(wp), st), 'stem_pack_weight')
+        y = _e(N, Hh // 2, Ww // 2, 64, device=images.device)
+        H.check(H.lib.evk_stem_fwd(H.ptr(xpad), H.ptr(wp), H.ptr(y), N, Hh, Ww, st), 'stem_fwd')
+        ctx.save_for_backward(xpad)
+        ctx.W, ctx.dims = W, (N, Hh, Ww)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xpad, = ctx.saved_tensors
+        W = ctx.W
+        N, Hh, Ww = ctx.dims
+        if W.requires_grad:
+            st = H.stream()
+            dy = dy.contiguous()
+            dwp = _z(64 * 224, dtype=F32, device=dy.device)
+            H.check(H.lib.evk_stem_wgrad(H.ptr(dy), H.ptr(xpad), H.ptr(dwp), N, Hh, Ww, st), 'stem_wgrad')
+            H.check(H.lib.evk_stem_unpack_wgrad(H.ptr(dwp), H.ptr(grad_buffer(W)), st), 'stem_unpack_wgrad')
+            grad_done(W)
+        return None, None
+
+
+class _BatchNorm(torch.autograd.Function):
+    """y = relu?(bn(x) + resid) over x[M][C]; train: batch statistics + running-stat update, eval: running stats."""
+
+    @staticmethod
+    def forward(ctx, x, resid, gamma, beta, rmean, rvar, training, relu, eps, momentum):
+        Cc = x.shape[-1]
+        M = x.numel() // Cc
+        dev = x.device
+        st = H.stream()
+        stats = _z(6, Cc, dtype=F32, device=dev)          # sum, sumsq, scale, shift, mean, invstd
+        if training:
+            H.check(H.lib.evk_bn_stats(H.ptr(x), H.ptr(stats[0]), H.ptr(stats[1]), M, Cc, st), 'bn_stats')
+        H.check(H.lib.evk_bn_finalize(H.ptr(stats[0]), H.ptr(stats[1]), H.ptr(gamma), H.ptr(beta), H.ptr(rmean), H.ptr(rvar),
+                                      H.ptr(stats[2]), H.ptr(stats[3]), H.ptr(stats[4]), H.ptr(stats[5]), Cc, C.c_float(M),
+                                      C.c_float(momentum), C.c_float(eps), int(training), st), 'bn_finalize')
+        y = _e(*x.shape, device=dev)
+        H.check(H.lib.evk_bn_apply(H.ptr(x), H.ptr(stats[2]), H.ptr(stats[3]), H.ptr(resid), H.ptr(y), M, Cc, int(relu), st), 'bn_apply')
+        ctx.save_for_backward(x, y if relu else None, stats)
+        ctx.gamma, ctx.beta, ctx.cfg = gamma, beta, (M, Cc, relu, training, resid is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, z, stats = ctx.saved_tensors
+        M, Cc, relu, training, has_res = ctx.cfg
+        gamma, beta = ctx.gamma, ctx.beta
+        dev = x.device
+        st = H.stream()
+        dz = dz.contiguous()
+        sums = _z(2, Cc, dtype=F32, device=dev)
+        H.check(H.lib.evk_bn_bwd_reduce(H.ptr(dz), H.ptr(z), H.ptr(x), H.ptr(stats[4]), H.ptr(stats[5]), H.ptr(sums[0]),
+                                        H.ptr(sums[1]), M, Cc, int(relu), st), 'bn_bwd_reduce')
+        if gamma is not None and gamma.requires_grad:
+            grad_buffer(gamma).add_(sums[1])
+            grad_buffer(beta).add_(sums[0])
+            grad_done(gamma)
+            grad_done(beta)
+        dx = _e(*x.shape, device=dev)
+        dres = _e(*x.shape, device=dev) if has_res else None
+        if training:
+            sg, sgx = sums[0], sums[1]
+        else:                         # eval-mode BN is a fixed affine map: no batch-statistics terms
+            sg = sgx = _z(Cc, dtype=F32, device=dev)
+        H.check(H.lib.evk_bn_bwd_apply(H.ptr(dz), H.ptr(z), H.ptr(x), H.ptr(stats[2]), H.ptr(stats[4]), H.ptr(stats[5]),
+                                       H.ptr(sg), H.ptr(sgx), H.ptr(dx), H.ptr(dres), M, Cc, int(relu), st), 'bn_bwd_apply')
+        return dx, dres, None, None, None, None, None, None, None, None
+
+
+def batchnorm(x, bn, training, relu=False, resid=None):
+    """bn: a BatchNorm parameter holder (weight/bias may be None for affine=False)."""
+    assert x.dtype == BF16 and x.is_contiguous()
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return _BatchNorm.apply(x, resid, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, relu, bn.eps, bn.momentum)
+
+
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        N, Hh, Ww, Cc = x.shape
+        y = _e(N, (Hh - 1) // 2 + 1, (Ww - 1) // 2 + 1, Cc, device=x.device)
+        H.check(H.lib.evk_maxpool3x3s2_fwd(H.ptr(x), H.ptr(y), N, Hh, Ww, Cc, H.stream()), 'maxpool_fwd')
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        N, Hh, Ww, Cc = x.shape
+        dx = _e(*x.shape, device=x.device)
+        H.check(H.lib.evk_maxpool3x3s2_bwd(H.ptr(x), H.ptr(dy.contiguous()), H.ptr(dx), N, Hh, Ww, Cc, H.stream()), 'maxpool_bwd')
+        return dx
+
+
+class _PatchMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, att):
+        N, P, Cc = att.shape
+        fc = _e(N, Cc, device=att.device)
+        H.check(H.lib.evk_patch_mean_fwd(H.ptr(att), H.ptr(fc), N, P, Cc, H.stream()), 'patch_mean_fwd')
+        ctx.dims = (N, P, Cc)
+        return fc
+
+    @staticmethod
+    def backward(ctx, dfc):
+        N, P, Cc = ctx.dims
+        datt = _e(N, P, Cc, device=dfc.device)
+        H.check(H.lib.evk_patch_mean_bwd(None, H.ptr(dfc.contiguous()), H.ptr(datt), N, P, Cc, H.stream()), 'patch_mean_bwd')
+        return datt
+
+
+# ----------------------------------------------------------------------------------------------------
+# parameter containers with torchvision's names
+# ----------------------------------------------------------------------------------------------------
+class ConvP(nn.Module):
+    """Conv2d weight holder.  channels_last=True keeps the physical layout KRSC (the implicit-GEMM operand layout);
+    the 7x7 stem keeps plain OIHW because its pack kernels re-lay it out anyway."""
+
+    def __init__(self, cin, cout, k, stride=1, pad=0, channels_last=True):
+        super().__init__()
+        w = torch.empty(cout, cin, k, k)
+        nn.init.kaiming_normal_(w, mode='fan_out', nonlinearity='relu')
+        self.fmt = torch.channels_last if channels_last else torch.contiguous_format
+        self.weight = nn.Parameter(w.contiguous(memory_format=self.fmt))
+        self.stride, self.pad = stride, pad
+
+    def _apply(self, fn, recurse=True):
+        super()._apply(fn, recurse)
+        if not self.weight.is_contiguous(memory_format=self.fmt):
+            self.weight.data = self.weight.data.contiguous(memory_format=self.fmt)
+        return self
+
+    def forward(self, x):
+        return conv2d(x, self.weight, self.stride, self.pad)
+
+
+class BNP(nn.Module):
+    def __init__(self, c, affine=True, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.eps, self.momentum = eps, momentum
+        if affine:
+            self.weight = nn.Parameter(torch.ones(c))
+            self.bias = nn.Parameter(torch.zeros(c))
+        else:
+            self.register_parameter('weight', None)
+            self.register_parameter('bias', None)
+        self.register_buffer('running_mean', torch.zeros(c))
+        self.register_buffer('running_var', torch.ones(c))
+        self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+
+    def forward(self, x, relu=False, resid=None):
+        return batchnorm(x, self, self.training, relu, resid)
+
+
+class Bottleneck(nn.Module):
+    def __init__(self, inpl, planes, stride, down):
+        super().__init__()
+        self.conv1 = ConvP(inpl, planes, 1)
+        self.bn1 = BNP(planes)
+        self.conv2 = ConvP(planes, planes, 3, stride, 1)
+        self.bn2 = BNP(planes)
+        self.conv3 = ConvP(planes, planes * 4, 1)
+        self.bn3 = BNP(planes * 4)
+        self.downsample = None
+        if down:
+            self.downsample = nn.Sequential(ConvP(inpl, planes * 4, 1, stride), BNP(planes * 4))
+
+    def forward(self, x):
+        idt = x
+        if self.downsample is not None:
+            idt = self.downsample[1](self.downsample[0](x))
+        y = self.bn1(self.conv1(x), relu=True)
+        y = self.bn2(self.conv2(y), relu=True)
+        return self.bn3(self.conv3(y), relu=True, resid=idt)
+
+
+class _Tag(nn.Module):
+    """placeholder so that Sequential indices 2 (relu) and 3 (maxpool) exist as in torchvision's children()[:-2]."""
+
+    def forward(self, x):
+        return x
+
+
+class ResNetTrunk(nn.Sequential):
+    def __init__(self):
+        mods = [ConvP(3, 64, 7, 2, 3, channels_last=False), BNP(64), _Tag(), _Tag()]
+        inpl = 64
+        for planes, blocks, stride in RESNET_LAYERS:
+            layer = [Bottleneck(inpl, planes, stride, True)]
+            inpl = planes * 4
+            layer += [Bottleneck(inpl, planes, 1, False) for _ in range(blocks - 1)]
+            mods.append(nn.Sequential(*layer))
+        super().__init__(*mods)
+
+    def forward(self, images):
+        """images f32 NCHW on the GPU -> NHWC bf16 feature map (N, h, w, 2048)."""
+        assert images.dtype == F32 and images.is_cuda and images.dim() == 4 and images.shape[1] == 3
+        x = _Stem.apply(images.contiguous(), self[0].weight)
+        x = self[1](x, relu=True)
+        x = _MaxPool.apply(x)
+        for li in range(4, 8):
+            for blk in self[li]:
+                x = blk(x)
+        return x
+
+
+class ResNet(nn.Module):
+    """modules/visual_extractor.py:27-43 (ResNetTemp; `ResNet` with AvgPool2d(7) is identical at 224^2)."""
+
+    def __init__(self, args=None):
+        super().__init__()
+        self.model = ResNetTrunk()
+        ck = (args or {}).get('resnet_checkpoint', '')
+        if ck:
+            sd = torch.load(ck, map_location='cpu')
+            keys = ['conv1', 'bn1', None, None, 'layer1', 'layer2', 'layer3', 'layer4']
+            new = {}
+            for k, v in sd.items():
+                head = k.split('.')[0]
+                if head in keys:
+                    new['%d%s' % (keys.index(head), k[len(head):])] = v
+            self.model.load_state_dict(new)
+
+    def forward(self, images):
+        f = self.model(images)
+        n, h, w, c = f.shape
+        patch = f.view(n, h * w, c)             # NHWC is already (N, P, C): the reference's reshape+permute is free
+        return patch, _PatchMean.apply(patch)

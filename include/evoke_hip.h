@@ -95,6 +95,85 @@ int evk_stem_unpack_wgrad(const float* dw_packed, float* dw_oihw, evk_stream_t s
 int evk_stem_fwd(const void* xpad, const void* w_packed, void* y, int32_t N, int32_t H, int32_t W, evk_stream_t stream);
 int evk_stem_wgrad(const void* dy, const void* xpad, float* dw_packed, int32_t N, int32_t H, int32_t W, evk_stream_t stream);
 
+/* ---- row-wise kernels (norm.hip): one wavefront per row, shuffle reductions ----------------------------
+ * LayerNorm family.  mode 0 = torch.nn.LayerNorm (biased variance, eps inside the sqrt; bert_model.py:355,433,
+ * ...v0623_large_res.py:34-35); mode 1 = R2Gen LayerNorm / ConditionalLayerNorm (encoder_decoder.py:93-103,
+ * 166-179: unbiased std, eps added to the std).  dgam/dbet: optional per-row deltas [rows][D] added to gamma/beta.
+ * mean/rstd [rows] f32 are saved for the backward.  D % 8 == 0, D <= 2048.                                   */
+int evk_layernorm_fwd(const void* x, int x_dtype, void* y, int y_dtype, const float* gamma, const float* beta,
+                      const void* dgam, const void* dbet, int d_dtype, float* mean, float* rstd,
+                      int64_t rows, int32_t D, int32_t mode, float eps, evk_stream_t stream);
+/* dgamma/dbeta (f32 [D]) are accumulated (+=); ddgam/ddbet (per-row, dtype d_dtype) are written.            */
+int evk_layernorm_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, const void* dgam, int d_dtype,
+                      const float* mean, const float* rstd, void* dx, int dx_dtype, float* dgamma, float* dbeta,
+                      void* ddgam, void* ddbet, int64_t rows, int32_t D, int32_t mode, float eps, evk_stream_t stream);
+/* softmax over scores[batch][heads][Tq][ld_in] f32 (S valid columns) -> probabilities (p_dtype) [..][ld_out] (pad = 0).
+ * mask: uint8, 1 = attend, element (b, q, col) at mask[b*mask_batch_stride + q*mask_q_stride + col]; masked or
+ * (causal && col > q) entries get probability 0 (== the reference's -1e9 fill / finfo.min add whenever a row keeps
+ * at least one key: encoder_decoder.py:24, bert_model.py:322-325).  p_drop > 0 writes the dropped copy to pdrop_out.*/
+int evk_softmax_fwd(const float* scores, void* p_out, void* pdrop_out, int p_dtype, const unsigned char* mask, int64_t mask_batch_stride,
+                    int32_t mask_q_stride, int32_t causal, int64_t batch, int32_t heads, int32_t Tq, int32_t S,
+                    int32_t ld_in, int32_t ld_out, float p_drop, uint64_t seed, evk_stream_t stream);
+/* dS = alpha * P * (dP - sum_j dP_j P_j), dP first passed through the same dropout mask                      */
+int evk_softmax_bwd(const void* dp, int dp_dtype, int32_t ld_dp, const void* probs, void* ds, int p_dtype, int64_t rows, int32_t S, int32_t ld,
+                    float alpha, float p_drop, uint64_t seed, evk_stream_t stream);
+/* log_softmax over logits[rows][ld] (V valid); optional outputs: logp [rows][ld_out], lse [rows]; with target:
+ * acc2[0] += sum(-logp[target]*wmask), acc2[1] += sum(wmask)   (encoder_decoder.py:393 + loss.py:9-16)       */
+int evk_log_softmax_nll_fwd(const float* logits, float* logp, float* lse, const int64_t* target, const float* wmask, float* acc2,
+                            int64_t rows, int32_t V, int32_t ld, int32_t ld_out, evk_stream_t stream);
+int evk_nll_bwd(const float* logits, const float* lse, const int64_t* target, const float* wmask, const float* gscale,
+                void* dlogits, int64_t rows, int32_t V, int32_t ld, int32_t ld_out, evk_stream_t stream);
+/* F.normalize(p=2, eps=1e-12) rows, f32 */
+int evk_l2norm_fwd(const float* x, float* y, float* nrm, int64_t rows, int32_t D, evk_stream_t stream);
+int evk_l2norm_bwd(const float* dy, const float* y, const float* nrm, float* dx, int64_t rows, int32_t D, evk_stream_t stream);
+/* soft-label cross entropy (F.cross_entropy with probability targets; ...v0623_large_res.py:271-281,316-328,343-349):
+ * loss_acc[0] += scale * sum_rows(lse*sum(t) - sum(t*z)); dz = scale*gscale[0]*(softmax*sum(t) - t);
+ * diag_mask: z[r][r] treated as -1e9 (fill_diagonal_, line 276)                                                 */
+int evk_softce(const float* z, const float* t, float* loss_acc, float* dz, const float* gscale, int64_t rows, int32_t Cn,
+               float scale, int32_t diag_mask, evk_stream_t stream);
+
+/* ---- BatchNorm / pooling (bn.hip): x[M][C] bf16 channels-last, C a power-of-two multiple of 8 <= 2048 --------
+ * train-mode torch.nn.BatchNorm2d/1d (torchvision resnet101 via visual_extractor.py:30-38; utils_v0511.py:137,177-181) */
+int evk_bn_stats(const void* x, float* sum, float* sumsq, int64_t M, int32_t C, evk_stream_t stream);
+int evk_bn_finalize(const float* sum, const float* sumsq, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, float* scale, float* shift, float* mean, float* invstd, int32_t C, float count,
+                    float momentum, float eps, int32_t training, evk_stream_t stream);
+int evk_bn_apply(const void* x, const float* scale, const float* shift, const void* resid, void* y, int64_t M, int32_t C,
+                 int32_t relu, evk_stream_t stream);
+int evk_bn_bwd_reduce(const void* dz, const void* z, const void* x, const float* mean, const float* invstd, float* sum_g,
+                      float* sum_gx, int64_t M, int32_t C, int32_t relu, evk_stream_t stream);
+int evk_bn_bwd_apply(const void* dz, const void* z, const void* x, const float* scale, const float* mean, const float* invstd,
+                     const float* sum_g, const float* sum_gx, void* dx, void* dres, int64_t M, int32_t C, int32_t relu,
+                     evk_stream_t stream);
+int evk_maxpool3x3s2_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, evk_stream_t stream);
+int evk_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, evk_stream_t stream);
+/* visual_extractor.py:40-42: avg_feats = mean over patches */
+int evk_patch_mean_fwd(const void* att, void* fc, int32_t N, int32_t P, int32_t C, evk_stream_t stream);
+int evk_patch_mean_bwd(const void* datt_in, const void* dfc, void* datt, int32_t N, int32_t P, int32_t C, evk_stream_t stream);
+
+/* ---- elementwise / gather / optimizer (eltwise.hip) ------------------------------------------------------- */
+int evk_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, evk_stream_t stream);
+int evk_act_fwd(const void* x, void* y, int64_t n, int32_t act, evk_stream_t stream);
+/* ref = output (relu/tanh/sigmoid) or pre-activation (gelu) */
+int evk_act_bwd(const void* dy, const void* ref, void* dx, int64_t n, int32_t act, evk_stream_t stream);
+/* y = x * keep / (1-p) (+ resid), keep from a stateless hash of (seed, index): the backward is the same call on dy
+ * (HF BertSelfOutput / BertOutput: dense -> dropout -> + residual, bert_model.py:359-362,437-440)               */
+int evk_dropout(const void* x, const void* resid, void* y, int64_t n, float p, uint64_t seed, evk_stream_t stream);
+int evk_embedding_fwd(const float* table, const int64_t* ids, const float* pos, const float* extra, void* out, int out_dtype,
+                      int64_t rows, int32_t D, int32_t L, float scale, evk_stream_t stream);
+int evk_embedding_bwd(const void* dout, int d_dtype, const int64_t* ids, float* dtable, int64_t rows, int32_t D, float scale,
+                      int64_t padding_idx, evk_stream_t stream);
+int evk_colsum(const void* x, float* out, int64_t M, int32_t N, int64_t ld, evk_stream_t stream);
+/* RelationalMemory gate, encoder_decoder.py:282-289 */
+int evk_rm_gate_fwd(const void* gw, const void* gu, const void* nm, const void* m, void* out, void* sig_i, void* sig_f, void* tnm,
+                    int64_t B, int32_t S, int32_t D, evk_stream_t stream);
+int evk_rm_gate_bwd(const void* dnext, const void* sig_i, const void* sig_f, const void* tnm, const void* m, void* dnm, void* dm,
+                    void* dgates, int64_t B, int32_t S, int32_t D, evk_stream_t stream);
+/* fused clip_grad_value_ + optimizer step + bf16 shadow refresh over a flat buffer (trainer_v0401.py:262,434;
+ * optimizers.py:17-53).  kind 0 = torch.optim.RAdam, kind 1 = torch.optim.Adam (vmax != NULL -> amsgrad)      */
+int evk_optim_step(float* p, const float* g, float* m, float* v, float* vmax, void* shadow, int64_t n, int32_t kind, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, float clip, int64_t step, evk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,35 @@
+"""Shared helpers of the GPU parity tests."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+V = 1444
+
+ARGS = dict(
+    resnet_checkpoint='', text_checkpoint=None, fusion_checkpoint=None, vocab_size=V, encoder_hidden_size=768,
+    encoder_num_hidden_layers=6, output_dim=2048, fusion_num_heads=8, sk_fusion_num_layers=1, max_seq_len=100,
+    is_multiview_learning=True, is_add_indication=True, instance_temp=0.5, region_temp=0.5, num_layers=3, d_model=512,
+    d_ff=512, d_vf=2048, num_heads=8, dropout=0.0, drop_prob_lm=0.5, use_bn=0, rm_num_slots=3, rm_num_heads=8,
+    rm_d_model=512, sample_method='beam_search', beam_size=3, temperature=1.0, sample_n=1, group_size=1,
+    output_logsoftmax=1, decoding_constraint=0, block_trigrams=1, length_penalty='', diversity_lambda=0.5, suppress_UNK=0)
+
+
+def load_tokenizer():
+    from evoke_amd.tokenizer import load_tokenizer as lt
+    return lt(os.path.join(GOLDEN, 'iu_xray_wordlevel_uncased_tokenizer.json'))
+
+
+def load_procedural(model, spec, device='cuda'):
+    from oracle import spec as S
+    sd = S.procedural_state(spec)
+    res = model.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys[:5]
+    assert all(k.endswith('position_ids') for k in res.missing_keys), res.missing_keys[:5]
+    return model.to(device)
+
+
+def rel_err(got, want):
+    got, want = got.detach().double().cpu().reshape(-1), want.detach().double().cpu().reshape(-1)
+    return float((got - want).norm() / (want.norm() + 1e-30))

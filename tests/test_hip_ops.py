@@ -1,0 +1,305 @@
+"""GPU unit parity of the row-wise / BN / elementwise kernels and the autograd wrappers (evoke_amd.ops, trunk,
+losses) against plain torch fp32 references evaluated on the same bf16-rounded inputs."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def close(got, want, rtol, atol, what=''):
+    got, want = got.detach().float().cpu(), want.detach().float()
+    err = (got - want).abs()
+    tol = atol + rtol * want.abs()
+    assert bool((err <= tol).all()), '%s max err %.4g (tol %.4g), rel-norm %.3g' % (
+        what, err.max().item(), tol.flatten()[err.argmax()].item(), (err.norm() / (want.norm() + 1e-30)).item())
+
+
+def leaf(t, dtype=BF):
+    return t.to(dtype).cuda().requires_grad_(True)
+
+
+def ref(t):
+    return t.to(BF).float().requires_grad_(True)
+
+
+@pytest.mark.parametrize('mode,D', [(0, 2048), (0, 768), (1, 512)])
+def test_layernorm(mode, D):
+    from evoke_amd import ops
+    x, g, b = rnd(37, D, seed=1), 1 + 0.2 * rnd(D, seed=2), 0.1 * rnd(D, seed=3)
+    dy = rnd(37, D, seed=4)
+    xd, gd, bd = leaf(x), g.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    eps = 1e-5 if mode == 0 else 1e-6
+    y = ops.layernorm(xd, gd, bd, eps=eps, mode=mode)
+    y.backward(dy.to(BF).cuda())
+    xr, gr, br = ref(x), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    if mode == 0:
+        yr = F.layer_norm(xr, (D,), gr, br, eps)
+    else:
+        yr = gr * (xr - xr.mean(-1, keepdim=True)) / (xr.std(-1, keepdim=True) + eps) + br
+    yr.backward(dy.to(BF).float())
+    close(y, yr, 1e-2, 1e-2, 'y')
+    close(xd.grad, xr.grad, 2e-2, 2e-2, 'dx')
+    close(gd.grad, gr.grad, 1e-2, 5e-2, 'dgamma')
+    close(bd.grad, br.grad, 1e-2, 5e-2, 'dbeta')
+
+
+def test_conditional_layernorm():
+    from evoke_amd import ops
+    D, R = 512, 45
+    x, g, b = rnd(R, D, seed=1), 1 + 0.2 * rnd(D, seed=2), 0.1 * rnd(D, seed=3)
+    dg_, db_ = 0.3 * rnd(R, D, seed=5), 0.3 * rnd(R, D, seed=6)
+    dy = rnd(R, D, seed=4)
+    xd, gd, bd, dgd, dbd = leaf(x), g.cuda().requires_grad_(True), b.cuda().requires_grad_(True), leaf(dg_), leaf(db_)
+    y = ops.layernorm(xd, gd, bd, eps=1e-6, mode=1, dgam=dgd, dbet=dbd)
+    y.backward(dy.to(BF).cuda())
+    xr, gr, br, dgr, dbr = ref(x), g.clone().requires_grad_(True), b.clone().requires_grad_(True), ref(dg_), ref(db_)
+    yr = (gr + dgr) * (xr - xr.mean(-1, keepdim=True)) / (xr.std(-1, keepdim=True) + 1e-6) + (br + dbr)
+    yr.backward(dy.to(BF).float())
+    close(y, yr, 1e-2, 1e-2, 'y')
+    close(xd.grad, xr.grad, 2e-2, 2e-2, 'dx')
+    close(dgd.grad, dgr.grad, 1e-2, 1e-2, 'ddgam')
+    close(dbd.grad, dbr.grad, 1e-2, 1e-2, 'ddbet')
+    close(gd.grad, gr.grad, 1e-2, 5e-2, 'dgamma')
+
+
+@pytest.mark.parametrize('act', ['none', 'relu'])
+def test_linear_fwd_bwd(act):
+    from evoke_amd import hip as H, ops
+    M, K, N = 290, 512, 1445
+    x, W, b = rnd(2, M // 2, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), 0.1 * rnd(N, seed=3)
+    xd, Wd, bd = leaf(x), W.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    y = ops.linear(xd, Wd, bd, act=H.ACT_RELU if act == 'relu' else H.ACT_NONE, out_f32=(act == 'none'))
+    assert y.shape[-1] == 1448 and float(y[..., N:].abs().sum()) == 0
+    dy = rnd(2, M // 2, 1448, seed=4)
+    dy[..., N:] = 0
+    y.backward(dy.to(y.dtype).cuda())
+    xr, Wr, br = ref(x), W.to(BF).float().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.linear(xr, Wr, br)
+    if act == 'relu':
+        yr = F.relu(yr)
+    yr.backward(dy[..., :N].to(BF).float())
+    close(y[..., :N], yr, 1e-2, 1e-2, 'y')
+    close(xd.grad, xr.grad, 2e-2, 3e-2, 'dx')
+    close(Wd.grad, Wr.grad, 2e-2, 5e-2, 'dW')
+    close(bd.grad, br.grad, 2e-2, 5e-2, 'db')
+
+
+@pytest.mark.parametrize('cfg', [dict(B=3, T=37, S=50, Hh=12, dh=64, mask='key'), dict(B=2, T=20, S=20, Hh=8, dh=64, mask='causal'),
+                                 dict(B=2, T=145, S=290, Hh=8, dh=256, mask=None), dict(B=4, T=3, S=4, Hh=8, dh=64, mask=None)])
+def test_attention(cfg):
+    from evoke_amd import ops
+    B, T, S, Hh, dh = cfg['B'], cfg['T'], cfg['S'], cfg['Hh'], cfg['dh']
+    q, k, v = rnd(B, T, Hh * dh, seed=1), rnd(B, S, Hh * dh, seed=2), rnd(B, S, Hh * dh, seed=3)
+    do = rnd(B, T, Hh * dh, seed=4)
+    mask = None
+    if cfg['mask']:
+        mask = torch.ones(B, S, dtype=torch.uint8)
+        for i in range(B):
+            mask[i, S - 3 * i:] = 0
+    qd, kd, vd = leaf(q), leaf(k), leaf(v)
+    o = ops.attention(qd, kd, vd, Hh, mask=mask.cuda() if mask is not None else None, causal=cfg['mask'] == 'causal')
+    o.backward(do.to(BF).cuda())
+    qr, kr, vr = ref(q), ref(k), ref(v)
+    sc = torch.einsum('bthd,bshd->bhts', qr.view(B, T, Hh, dh), kr.view(B, S, Hh, dh)) / math.sqrt(dh)
+    if mask is not None:
+        sc = sc.masked_fill(mask[:, None, None, :] == 0, -1e9)
+    if cfg['mask'] == 'causal':
+        sc = sc.masked_fill(torch.tril(torch.ones(T, S)) == 0, -1e9)
+    orf = torch.einsum('bhts,bshd->bthd', torch.softmax(sc, -1), vr.view(B, S, Hh, dh)).reshape(B, T, Hh * dh)
+    orf.backward(do.to(BF).float())
+    close(o, orf, 2e-2, 2e-2, 'o')
+    close(qd.grad, qr.grad, 3e-2, 3e-2, 'dq')
+    close(kd.grad, kr.grad, 3e-2, 3e-2, 'dk')
+    close(vd.grad, vr.grad, 3e-2, 3e-2, 'dv')
+
+
+@pytest.mark.parametrize('C_,relu,res', [(64, True, False), (256, True, True), (2048, False, False)])
+def test_batchnorm_train(C_, relu, res):
+    from evoke_amd.trunk import BNP
+    M = 600
+    x, r = rnd(M, C_, seed=1, scale=2.0) + 0.5, rnd(M, C_, seed=2)
+    dz = rnd(M, C_, seed=3)
+    bn = BNP(C_).cuda().train()
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.2 * rnd(C_, seed=4))
+        bn.bias.copy_(0.1 * rnd(C_, seed=5))
+    xd = leaf(x)
+    rd = leaf(r) if res else None
+    z = bn(xd, relu=relu, resid=rd)
+    z.backward(dz.to(BF).cuda())
+    tb = torch.nn.BatchNorm1d(C_).train()
+    with torch.no_grad():
+        tb.weight.copy_(bn.weight.cpu())
+        tb.bias.copy_(bn.bias.cpu())
+    xr = ref(x)
+    rr = ref(r) if res else None
+    zr = tb(xr)
+    if res:
+        zr = zr + rr
+    if relu:
+        zr = F.relu(zr)
+    zr.backward(dz.to(BF).float())
+    close(z, zr, 2e-2, 2e-2, 'z')
+    close(xd.grad, xr.grad, 3e-2, 3e-2, 'dx')
+    if res:
+        close(rd.grad, rr.grad, 1e-2, 1e-2, 'dres')
+    close(bn.weight.grad, tb.weight.grad, 2e-2, 0.3, 'dgamma')
+    close(bn.bias.grad, tb.bias.grad, 2e-2, 0.3, 'dbeta')
+    close(bn.running_mean, tb.running_mean, 1e-2, 1e-3, 'running_mean')
+    close(bn.running_var, tb.running_var, 1e-2, 1e-3, 'running_var')
+    bn.eval()
+    tb.eval()
+    close(bn(xd.detach(), relu=relu, resid=rd.detach() if res else None),
+          (F.relu(tb(xr.detach()) + (rr.detach() if res else 0)) if relu else tb(xr.detach()) + (rr.detach() if res else 0)), 2e-2, 2e-2, 'eval')
+
+
+def test_maxpool_and_patch_mean():
+    from evoke_amd.trunk import _MaxPool, _PatchMean
+    x = rnd(2, 12, 10, 64, seed=1)
+    x = torch.relu(x)                      # many exact ties at 0, like the real post-ReLU input
+    dy = rnd(2, 6, 5, 64, seed=2)
+    xd = leaf(x)
+    y = _MaxPool.apply(xd)
+    y.backward(dy.to(BF).cuda())
+    xr = x.to(BF).float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    yr.backward(dy.to(BF).float().permute(0, 3, 1, 2))
+    close(y, yr.permute(0, 2, 3, 1), 0, 0, 'maxpool')
+    close(xd.grad, xr.grad.permute(0, 2, 3, 1), 1e-2, 1e-2, 'maxpool dx')
+    a = rnd(3, 49, 2048, seed=3)
+    ad = leaf(a)
+    fc = _PatchMean.apply(ad)
+    fc.backward(torch.ones_like(fc))
+    close(fc, a.to(BF).float().mean(1), 1e-2, 1e-2, 'patch mean')
+    close(ad.grad, torch.full_like(a, 1 / 49.0), 1e-2, 1e-4, 'patch mean bwd')
+
+
+def test_embedding_and_nll():
+    from evoke_amd import ops
+    Vv, D, B, L = 50, 512, 3, 7
+    table, pos = rnd(Vv, D, seed=1), rnd(20, D, seed=2)
+    ids = torch.randint(0, Vv, (B, L), generator=torch.Generator().manual_seed(3))
+    ids[0, -2:] = 0
+    td = table.cuda().requires_grad_(True)
+    out = ops.embedding(ids.cuda(), td, pos=pos.cuda(), scale=2.0, padding_idx=0)
+    dy = rnd(B, L, D, seed=4)
+    out.backward(dy.to(BF).cuda())
+    tr = table.clone().requires_grad_(True)
+    orf = F.embedding(ids, tr, padding_idx=0) * 2.0 + pos[:L]
+    orf.backward(dy.to(BF).float())
+    close(out, orf, 1e-2, 1e-2, 'emb')
+    close(td.grad, tr.grad, 1e-2, 1e-2, 'demb')
+    # masked NLL over padded logits
+    Vn, ld = 1445, 1448
+    lg = torch.zeros(B * L, ld)
+    lg[:, :Vn] = rnd(B * L, Vn, seed=5)
+    tgt = torch.randint(0, Vn, (B * L,), generator=torch.Generator().manual_seed(6))
+    w = (torch.rand(B * L, generator=torch.Generator().manual_seed(7)) > 0.3).float()
+    lgd = lg.cuda().requires_grad_(True)
+    loss = ops.nll_loss(lgd, tgt.cuda(), w.cuda(), Vn)
+    (loss * 3.0).backward()
+    lr = lg[:, :Vn].clone().requires_grad_(True)
+    lossr = (-(F.log_softmax(lr, -1).gather(1, tgt[:, None])[:, 0]) * w).sum() / w.sum()
+    (lossr * 3.0).backward()
+    assert abs(loss.item() - lossr.item()) < 1e-5
+    close(lgd.grad[:, :Vn], lr.grad, 1e-2, 1e-4, 'dlogits')
+    close(ops.log_softmax(lgd.detach(), Vn), F.log_softmax(lg[:, :Vn], -1), 1e-5, 1e-5, 'log_softmax')
+
+
+def test_dropout_statistics_and_backward():
+    from evoke_amd import ops
+    x = torch.ones(1 << 16, dtype=BF).cuda().requires_grad_(True)
+    y = ops.dropout(x, 0.3, True)
+    keep = (y > 0).float().mean().item()
+    assert abs(keep - 0.7) < 0.01
+    assert abs(float(y.float().max()) - 1 / 0.7) < 1e-2
+    y.backward(torch.ones_like(y))
+    assert torch.equal((x.grad > 0), (y > 0))
+    r = torch.full_like(x, 2.0).detach().requires_grad_(True)
+    z = ops.dropout(x.detach().requires_grad_(True), 0.5, True, resid=r)
+    assert float(z.float().min()) == 2.0 and float(z.float().max()) == 4.0
+
+
+def test_contrastive_losses_match_oracle():
+    from evoke_amd import losses
+    from oracle import functional as O
+    pid = np.array(['a', 'b', 'c', 'a', 'c', 'a'])
+    g = rnd(6, 2048, seed=1)
+    gd = g.cuda().requires_grad_(True)
+    gr = g.clone().requires_grad_(True)
+    l, lr_ = losses.multi_pos_contra_images(gd, pid, 0.5), O.multi_pos_contra_images(gr, pid, 0.5)
+    l.backward(); lr_.backward()
+    assert abs(l.item() - lr_.item()) < 2e-5, (l.item(), lr_.item())
+    close(gd.grad, gr.grad, 2e-3, 1e-6, 'multi_pos grad')
+    assert tuple(losses.multi_pos_contra_images(gd, np.array(list('abcdef')), 0.5).shape) == (1,)
+    v, t = rnd(3, 2048, seed=2), rnd(3, 2048, seed=3)
+    vd, td = v.cuda().requires_grad_(True), t.cuda().requires_grad_(True)
+    vr, tr = v.clone().requires_grad_(True), t.clone().requires_grad_(True)
+    l, lr_ = losses.global_alignment(vd, td, pid, 0.5), O.global_alignment_loss(vr, tr, pid, 0.5)
+    l.backward(); lr_.backward()
+    assert abs(l.item() - lr_.item()) < 2e-5, (l.item(), lr_.item())
+    close(vd.grad, vr.grad, 2e-3, 1e-6, 'global grad v')
+    close(td.grad, tr.grad, 2e-3, 1e-6, 'global grad t')
+    p, tk = rnd(3, 49, 2048, seed=4), rnd(3, 9, 2048, seed=5)
+    pd, tkd = p.cuda().requires_grad_(True), tk.cuda().requires_grad_(True)
+    pr, tkr = p.clone().requires_grad_(True), tk.clone().requires_grad_(True)
+    l, lr_ = losses.local_text_token_alignment(pd, tkd, 0.5), O.local_text_token_alignment_loss(pr, tkr, 0.5)
+    l.backward(); lr_.backward()
+    assert abs(l.item() - lr_.item()) < 2e-5, (l.item(), lr_.item())
+    close(pd.grad, pr.grad, 5e-3, 1e-7, 'local grad p')
+    close(tkd.grad, tkr.grad, 5e-3, 1e-7, 'local grad t')
+
+
+def test_relational_memory_step_matches_oracle():
+    from evoke_amd import ops
+    from evoke_amd.layers import RelationalMemory
+    from oracle import functional as O
+    ops.set_dropout_enabled(False)
+    rm = RelationalMemory(3, 512, 8).cuda().train()
+    P = {'text_decoder.model.rm.' + k: v.detach().cpu().to(BF).float() if v.dim() > 1 else v.detach().cpu().clone()
+         for k, v in rm.state_dict().items()}
+    for k in P:
+        P[k].requires_grad_(True)
+    emb = rnd(2, 5, 512, seed=1)
+    ed = leaf(emb)
+    out = rm(ed)
+    out.float().sum().backward()
+    er = ref(emb)
+    cfg = dict(rm_num_slots=3, rm_d_model=512, rm_num_heads=8)
+    outr = O.rm_forward(P, er, cfg, O.Ctx(train=True))
+    outr.sum().backward()
+    ops.set_dropout_enabled(True)
+    close(out, outr, 3e-2, 3e-2, 'rm out')
+    close(ed.grad, er.grad, 8e-2, 8e-2, 'rm demb')
+    close(rm.W.weight.grad, P['text_decoder.model.rm.W.weight'].grad, 8e-2, 8e-2, 'rm dW')
+
+
+def test_optim_step_matches_torch():
+    import ctypes as C
+    from evoke_amd import hip as H
+    n = 1000
+    for kind, mk in ((0, lambda p: torch.optim.RAdam(p, lr=5e-3, weight_decay=1e-4)),
+                     (1, lambda p: torch.optim.Adam(p, lr=5e-3, weight_decay=1e-4, amsgrad=True))):
+        p0, gs = rnd(n, seed=1), [rnd(n, seed=10 + i, scale=0.3) for i in range(8)]
+        pr = p0.clone().requires_grad_(True)
+        opt = mk([pr])
+        pd = p0.clone().cuda()
+        m, v, vm = torch.zeros(n).cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+        sh = torch.zeros(n, dtype=BF).cuda()
+        for step, g in enumerate(gs, 1):
+            pr.grad = g.clamp(-0.1, 0.1)
+            opt.step()
+            H.check(H.lib.evk_optim_step(H.ptr(pd), H.ptr(g.cuda()), H.ptr(m), H.ptr(v), H.ptr(vm) if kind == 1 else None, H.ptr(sh), n,
+                                         kind, 5e-3, 0.9, 0.999, 1e-8, 1e-4, 0.1, step, H.stream()))
+        close(pd, pr, 1e-5, 1e-6, 'optim kind %d' % kind)
+        close(sh, pr, 1e-2, 1e-3, 'shadow')
