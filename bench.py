@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the EVOKE hot path on MI355X (contract: see the task statement / DESIGN.md "Measurement").
+
+    python bench.py --gpus N --steps K --warmup W           (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = one full training step of FineTune on one synthetic batch per rank: forward + backward + gradient
+all-reduce + clip_grad_value_(0.1) + two-group RAdam (the reference's FTrainer._train_epoch body,
+modules/trainer_v0401.py:426-435).  Workload at N=1 = BASELINE.json configs[2] per GPU: 2-view 384x384, 32 studies
+(64 images) per GPU, report length 100, indication length 30, V = 1444 (the shipped IU-Xray tokenizer; the MIMIC vocab is
+not shipped), random-init weights, inputs resident in HBM before the timed region.  Weak scaling: every rank processes
+its own 32 studies; value = all ranks' studies / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 with the metric plus `roofline` (GEMM / implicit-GEMM kernel family, HIP-event timed
+inside the library over the timed region) and `cpu_baseline` (the CPU oracle = restatement of the reference, timed on
+this box's host cores on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+V = 1444
+# algorithmic forward+backward FLOPs per study counted on the reference (SURVEY.md section 8d / BASELINE.md section 2)
+ALG_GFLOP_PER_STUDY = {('finetune', 384): 453.2, ('finetune', 224): 60.3 * 2.868, ('pretrain', 384): 394.2, ('pretrain', 224): 141.4}
+MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md, chip-level parameters (dense; 5 PF is 2:1 sparse)
+
+
+def make_args(task):
+    from tests.helpers import ARGS
+    a = dict(ARGS)
+    a.update(task=task, optim='RAdam', pt_lr=5e-6, ft_lr=5e-5, weight_decay=1e-4, amsgrad=True)
+    return a
+
+
+def synth_batch(kind, B, views, res, L, Li, device, seed):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    N = B * views
+    images = torch.randn(N, 3, res, res, generator=g)
+    ids = torch.randint(5, V - 2, (B, L), generator=g)
+    if kind == 'finetune':
+        ids[:, 0], ids[:, -1] = V - 2, V - 1          # [BOS] ... [EOS]
+    else:
+        ids[:, 0] = 1                                  # [CLS]
+    masks = torch.ones(B, L, dtype=torch.long)
+    inc = torch.randint(5, V - 2, (B, Li), generator=g)
+    inc[:, 0] = 1
+    inc_masks = torch.ones(B, Li, dtype=torch.long)
+    studies = list(range(B)) * views                   # anchors first, then the other views of the same studies
+    pids = np.array(['p%08d_s%08d' % (seed * 1000 + s, s) for s in studies])
+    return dict(images=images.to(device), ids=ids.to(device), masks=masks.to(device), inc=inc.to(device),
+                inc_masks=inc_masks.to(device), pids=pids)
+
+
+def cpu_baseline(model, kind, res, L, Li, seconds_budget=25.0):
+    """The CPU oracle (oracle/, restatement of the reference pinned by tests/golden) timed on the host cores."""
+    from oracle import functional as O
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    P = {k: v.detach().float().cpu().clone().contiguous() for k, v in model.state_dict().items() if not k.endswith('position_ids')}
+    train_keys = [k for k, v in P.items() if v.is_floating_point() and not any(s in k for s in ('running_', '.pe'))]
+    for k in train_keys:
+        P[k].requires_grad_(True)
+    opt = torch.optim.RAdam([P[k] for k in train_keys], lr=5e-6, weight_decay=1e-4)
+    B = 2
+    b = synth_batch(kind, B, 2, res, L, Li, 'cpu', 7)
+    ctx = O.Ctx(train=True, dropout=True)
+    times = []
+    t_all = time.time()
+    for it in range(4):
+        t0 = time.time()
+        opt.zero_grad()
+        if kind == 'finetune':
+            ret = O.finetune_forward_train(P, b['images'], b['ids'], b['masks'], b['pids'], b['inc'], b['inc_masks'], O.DEFAULT_CFG, ctx)
+        else:
+            ret = O.pretrain_forward(P, b['images'], b['ids'], b['masks'], b['pids'], O.DEFAULT_CFG, ctx)
+        ret['all_loss'].backward()
+        torch.nn.utils.clip_grad_value_([P[k] for k in train_keys], 0.1)
+        opt.step()
+        times.append(time.time() - t0)
+        if time.time() - t_all > seconds_budget and it >= 1:
+            break
+    t = float(np.median(times[1:])) if len(times) > 1 else times[0]
+    return dict(value=B / t, unit='studies/s', cores=threads, kind='port',
+                sample='oracle (CPU restatement of the reference, fp32 eager) %s train step, batch %d x 2 views %dx%d, '
+                       'median of %d steps after 1 warm-up' % (kind, B, res, res, max(1, len(times) - 1)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='finetune', choices=['finetune', 'pretrain'])
+    ap.add_argument('--res', type=int, default=384)
+    ap.add_argument('--batch', type=int, default=32, help='studies per GPU')
+    ap.add_argument('--views', type=int, default=2)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-prof', action='store_true', help='disable the in-library HIP-event timing of kernel families')
+    a = ap.parse_args()
+
+    from evoke_amd import distributed as D
+    rank, world, local = D.init_distributed()
+    if world != a.gpus:
+        raise SystemExit('WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run --nproc-per-node %d' % (world, a.gpus, a.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    from evoke_amd import hip as H, ops, optim
+    from evoke_amd.model_pretrain_finetune import FineTune, Pretrain
+    from tests.helpers import load_tokenizer
+    torch.manual_seed(9233)
+    ops.manual_seed(9233 + rank)
+    args = make_args(a.workload)
+    kind = a.workload
+    L, Li = (100, 30) if kind == 'finetune' else (40, 0)
+    model = (FineTune if kind == 'finetune' else Pretrain)(args, load_tokenizer(), 'mimic_cxr').to(dev)
+    model.train()
+    if kind == 'pretrain' and world > 1:
+        model.gather = D.gather_rows
+    opt = optim.build_two_stage_optimizer(args, model, clip_value=0.1)
+    red = D.GradReducer.for_optimizer(opt)
+    batch = synth_batch(kind, a.batch, a.views, a.res, L, Li, dev, 1000 + rank)
+
+    def step():
+        opt.zero_grad()
+        red.begin(kind)
+        if kind == 'finetune':
+            ret = model(batch['images'], batch['ids'], batch['masks'], batch['pids'], batch['inc'], batch['inc_masks'], mode='train')
+        else:
+            ret = model(batch['images'], batch['ids'], batch['masks'], batch['pids'])
+        loss = ret['all_loss']
+        (loss / world).backward()
+        red.finish()
+        opt.step()
+        return loss.detach()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    if not a.no_prof:
+        H.prof_enable(True)
+    t0 = time.perf_counter()
+    losses = []
+    for _ in range(a.steps):
+        losses.append(step())
+    barrier()
+    dt = time.perf_counter() - t0
+    fam, launched_flops = ({}, 0.0)
+    if not a.no_prof:
+        fam, launched_flops = H.prof_collect()
+        H.prof_enable(False)
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tt.item())
+    if rank != 0:
+        return
+    studies = a.batch * world * a.steps
+    out = {
+        'metric': 'studies/sec (train step, 2-view 384^2)', 'value': studies / dt, 'unit': 'studies/s', 'n_gpus': world,
+        'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'config': {'workload': 'EVOKE-%d two-view %s train step (fwd+bwd+allreduce+clip+RAdam), %d studies (%d images) per GPU, '
+                               'L=%d, Li=%d, V=%d, random-init weights' % (a.res, kind, a.batch, a.batch * a.views, L, Li, V),
+                   'parallelism': 'dp%d' % world, 'loss_last': float(losses[-1].item())},
+    }
+    if fam:
+        ms, n = fam['gemm']
+        alg = ALG_GFLOP_PER_STUDY.get((kind, a.res))
+        alg_flops = (alg * 1e9 * a.batch * a.steps) if alg else launched_flops
+        ach = alg_flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_kernel (MFMA GEMM / implicit-GEMM conv family)', 'achieved': ach,
+                           'peak': MFMA_BF16_DENSE_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / MFMA_BF16_DENSE_PEAK_TFLOPS,
+                           'traffic': None, 'launches_per_step': n / a.steps, 'avg_launch_us': 1e3 * ms / max(n, 1),
+                           'gemm_ms_per_step': ms / a.steps, 'launched_tflops': launched_flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+                           'family_ms_per_step': {k: v[0] / a.steps for k, v in fam.items()}}
+    if world == 1 and not a.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(model, kind, a.res, L, Li)
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

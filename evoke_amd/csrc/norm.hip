@@ -383,6 +383,48 @@ __global__ __launch_bounds__(256) void softce_kernel(const SceP p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// beam step: per row, the k (<= 8) largest of x[row][0..n) in descending order; ties -> lowest index first
+// (replaces the flat torch.sort over beam*(V+1) candidates, caption_model.py:70-74)
+// ------------------------------------------------------------------------------------------------
+constexpr int TOPK_MAX = 8;
+__global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ x, float* __restrict__ vals,
+                                                        long long* __restrict__ idx, int n, int k) {
+  __shared__ float sv[256 * TOPK_MAX];
+  __shared__ int si[256 * TOPK_MAX];
+  const float* in = x + (long)blockIdx.x * n;
+  float bv[TOPK_MAX]; int bi[TOPK_MAX];
+#pragma unroll
+  for (int j = 0; j < TOPK_MAX; ++j) { bv[j] = -INFINITY; bi[j] = 0x7fffffff; }
+  for (int c = threadIdx.x; c < n; c += 256) {
+    float v = in[c]; int id = c;
+#pragma unroll
+    for (int j = 0; j < TOPK_MAX; ++j) {       // insertion into the sorted local list
+      if (j < k && (v > bv[j] || (v == bv[j] && id < bi[j]))) { const float tv = bv[j]; const int ti = bi[j]; bv[j] = v; bi[j] = id; v = tv; id = ti; }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < TOPK_MAX; ++j) { sv[threadIdx.x * TOPK_MAX + j] = bv[j]; si[threadIdx.x * TOPK_MAX + j] = bi[j]; }
+  __syncthreads();
+  if (threadIdx.x < 64) {        // one wave selects the k winners, one per round
+    for (int r = 0; r < k; ++r) {
+      float best = -INFINITY; int bid = 0x7fffffff, slot = -1;
+      for (int c = threadIdx.x; c < 256 * TOPK_MAX; c += 64) {
+        const float v = sv[c]; const int id = si[c];
+        if (id != 0x7fffffff && (v > best || (v == best && id < bid))) { best = v; bid = id; slot = c; }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bid, o, 64); const int os = __shfl_xor(slot, o, 64);
+        if (oi != 0x7fffffff && (ov > best || (ov == best && oi < bid))) { best = ov; bid = oi; slot = os; }
+      }
+      if (threadIdx.x == 0) { vals[(long)blockIdx.x * k + r] = best; idx[(long)blockIdx.x * k + r] = bid; if (slot >= 0) si[slot] = 0x7fffffff; }
+      __syncthreads();
+    }
+  }
+}
+
 inline int row_blocks(long rows) { return (int)cdiv(rows, WPB); }
 
 }  // namespace
@@ -477,6 +519,14 @@ int evk_l2norm_bwd(const float* dy, const float* y, const float* nrm, float* dx,
   ProfScope ps(EVK_FAM_NORM, s);
   hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(row_blocks(rows)), dim3(256), 0, s, dy, y, nrm, dx, (long)rows, D);
   return evk_check_launch("l2norm_bwd");
+}
+
+int evk_topk_rows(const float* x, float* vals, int64_t* idx, int64_t rows, int32_t n, int32_t k, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(x && vals && idx && rows > 0 && n > 0 && k >= 1 && k <= TOPK_MAX && k <= n, "topk_rows: bad args (k <= %d)", TOPK_MAX);
+  ProfScope ps(EVK_FAM_NORM, s);
+  hipLaunchKernelGGL(topk_rows_kernel, dim3((int)rows), dim3(256), 0, s, x, vals, (long long*)idx, n, k);
+  return evk_check_launch("topk_rows");
 }
 
 int evk_softce(const float* z, const float* t, float* loss_acc, float* dz, const float* gscale, int64_t rows, int32_t Cn,

@@ -1,0 +1,138 @@
+"""Optimizers of the training step on the HIP engine -- mirror of modules/optimizers.py:17-68.
+
+`build_two_stage_optimizer(args, model)` keeps the reference's rules: non-finetune tasks use one group at pt_lr;
+finetune splits parameters by name into {ResNet, text encoder, LN1/LN2, multi-view attention} at pt_lr and
+{text_decoder, visual_self_atten_layers, multimodal_fusion_layers, visual_head, text_head} at ft_lr
+(optimizers.py:27-33); 'AdamW' means torch.optim.Adam(weight_decay, amsgrad) (L2-coupled), 'RAdam' torch.optim.RAdam.
+
+The engine flattens every group into contiguous f32 buffers (params / grads / exp_avg / exp_avg_sq [/ max]) plus the
+bf16 GEMM-operand shadow, so that one fused kernel per group does clip_grad_value_ (trainer_v0401.py:262,434,455) +
+the update + the shadow refresh, and the DDP all-reduce runs on the flat gradient buffer without copies.
+"""
+import torch
+
+from . import hip as H
+from . import ops
+
+
+def split_param_groups(args, model):
+    """optimizers.py:17-46 -> [(lr, [(name, param), ...]), ...]."""
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    if args.get('task', 'finetune') != 'finetune':
+        return [(args['pt_lr'], named)]
+    keys = ('text_decoder', 'visual_self_atten_layers', 'multimodal_fusion_layers', 'visual_head', 'text_head')
+    ft = [(n, p) for n, p in named if any(k in n for k in keys)]
+    pt = [(n, p) for n, p in named if not any(k in n for k in keys)]
+    return [(args['pt_lr'], pt), (args['ft_lr'], ft)]
+
+
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+def _view_like(flat_chunk, p):
+    """A view of `flat_chunk` (numel elements) with p's logical shape AND physical layout."""
+    if p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last) and not p.is_contiguous():
+        co, ci, kh, kw = p.shape
+        return flat_chunk.view(co, kh, kw, ci).permute(0, 3, 1, 2)
+    return flat_chunk.view(p.shape)
+
+
+class FusedOptimizer(torch.optim.Optimizer):
+    """kind: 'RAdam' | 'AdamW' (= Adam + amsgrad flag, as the reference names it) | 'Adam'."""
+
+    def __init__(self, groups, kind='RAdam', weight_decay=0.0, amsgrad=False, betas=(0.9, 0.999), eps=1e-8, clip_value=0.1):
+        param_groups = [{'params': [p for _, p in named], 'lr': lr} for lr, named in groups]
+        super().__init__(param_groups, dict(lr=groups[0][0], weight_decay=weight_decay, betas=betas, eps=eps))
+        self.kind = 0 if kind == 'RAdam' else 1
+        self.amsgrad = bool(amsgrad) and kind == 'AdamW'
+        self.clip_value = clip_value
+        self.steps = 0
+        self.flat = []
+        self._touched = set()
+        self._pstep = {}
+        ops.register_grad_callback(self._on_grad)
+        for g in self.param_groups:
+            ps = g['params']
+            dev = ps[0].device
+            offs, tot = [], 0
+            for p in ps:
+                offs.append(tot)
+                rows = p.shape[0] if p.dim() >= 2 else 1
+                n = p.numel()
+                if p.dim() == 2 and rows % 8:
+                    n = _pad8(rows) * (p.numel() // rows)      # room for the zero-padded rows of the bf16 shadow
+                tot += _pad8(n)
+            fp = torch.zeros(tot, dtype=torch.float32, device=dev)
+            fg = torch.zeros(tot, dtype=torch.float32, device=dev)
+            sh = torch.zeros(tot, dtype=torch.bfloat16, device=dev) if dev.type == 'cuda' else None
+            for p, o in zip(ps, offs):
+                n = p.numel()
+                v = _view_like(fp[o:o + n], p)
+                v.copy_(p.data)
+                p.data = v
+                p.grad = _view_like(fg[o:o + n], p)
+            st = dict(p=fp, g=fg, m=torch.zeros_like(fp), v=torch.zeros_like(fp), vmax=torch.zeros_like(fp) if self.amsgrad else None,
+                      shadow=sh, offsets=offs)
+            self.flat.append(st)
+            if sh is not None:
+                H.check(H.lib.evk_cast(H.ptr(fp), H.F32, H.ptr(sh), H.BF16, tot, H.stream()), 'cast')
+                for p, o in zip(ps, offs):
+                    rows = p.shape[0] if p.dim() >= 2 else 1
+                    n = p.numel() if not (p.dim() == 2 and rows % 8) else _pad8(rows) * (p.numel() // rows)
+                    ops.set_shadow_fresh(p, sh[o:o + n])
+
+    def _on_grad(self, p):
+        self._touched.add(id(p))
+
+    def flat_grads(self):
+        return [st['g'] for st in self.flat]
+
+    def zero_grad(self, set_to_none=False):
+        """Gradients live in the flat buffers the kernels accumulate into: they are zeroed, never freed."""
+        for st in self.flat:
+            st['g'].zero_()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        """torch.optim semantics: parameters that received no gradient this step are skipped (no weight decay, no
+        step-count increment) -- e.g. the BERT pooler always, visual_self_atten_layers on indication batches.  Runs of
+        consecutive updated parameters with the same step count share one fused launch."""
+        self.steps += 1
+        for g, st in zip(self.param_groups, self.flat):
+            b1, b2 = g['betas']
+            ps, offs = g['params'], st['offsets']
+            total = st['p'].numel()
+            runs, cur = [], None
+            for i, p in enumerate(ps):
+                if id(p) not in self._touched:
+                    cur = None
+                    continue
+                k = self._pstep.get(id(p), 0) + 1
+                self._pstep[id(p)] = k
+                end = offs[i + 1] if i + 1 < len(ps) else total
+                if cur is not None and cur[2] == k and cur[1] == offs[i]:
+                    cur[1] = end
+                else:
+                    cur = [offs[i], end, k]
+                    runs.append(cur)
+            for a, b, k in runs:
+                es, eb = 4 * a, 2 * a
+                H.check(H.lib.evk_optim_step(st['p'].data_ptr() + es, st['g'].data_ptr() + es, st['m'].data_ptr() + es,
+                                             st['v'].data_ptr() + es, (st['vmax'].data_ptr() + es) if st['vmax'] is not None else None,
+                                             (st['shadow'].data_ptr() + eb) if st['shadow'] is not None else None, b - a, self.kind,
+                                             float(g['lr']), b1, b2, g['eps'], g['weight_decay'], float(self.clip_value or 0.0), k,
+                                             H.stream()), 'optim_step')
+        self._touched.clear()
+
+
+def build_two_stage_optimizer(args, model, clip_value=0.1):
+    kind = args.get('optim', 'RAdam')
+    return FusedOptimizer(split_param_groups(args, model), kind=kind, weight_decay=args.get('weight_decay', 0.0),
+                          amsgrad=args.get('amsgrad', False), clip_value=clip_value)
+
+
+def build_lr_scheduler(args, optimizer):
+    if args.get('lr_scheduler') == 'StepLR':
+        return torch.optim.lr_scheduler.StepLR(optimizer, step_size=args['step_size'], gamma=args['gamma'])
+    return torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, mode=args.get('monitor_mode', 'min'))

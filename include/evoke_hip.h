@@ -123,6 +123,8 @@ int evk_log_softmax_nll_fwd(const float* logits, float* logp, float* lse, const 
                             int64_t rows, int32_t V, int32_t ld, int32_t ld_out, evk_stream_t stream);
 int evk_nll_bwd(const float* logits, const float* lse, const int64_t* target, const float* wmask, const float* gscale,
                 void* dlogits, int64_t rows, int32_t V, int32_t ld, int32_t ld_out, evk_stream_t stream);
+/* beam step (caption_model.py:70-74): k <= 8 largest of each row, descending, ties -> lowest index first */
+int evk_topk_rows(const float* x, float* vals, int64_t* idx, int64_t rows, int32_t n, int32_t k, evk_stream_t stream);
 /* F.normalize(p=2, eps=1e-12) rows, f32 */
 int evk_l2norm_fwd(const float* x, float* y, float* nrm, int64_t rows, int32_t D, evk_stream_t stream);
 int evk_l2norm_bwd(const float* dy, const float* y, const float* nrm, float* dx, int64_t rows, int32_t D, evk_stream_t stream);

@@ -59,7 +59,7 @@ N_SAMPLES = 61
 
 def reduce_tensor(t):
     """[n, sum, sum of squares, 61 strided samples] in float64 -- small enough to commit."""
-    x = t.detach().to(torch.float64).reshape(-1)
+    x = t.detach().cpu().to(torch.float64).reshape(-1)
     n = x.numel()
     idx = (torch.arange(N_SAMPLES, dtype=torch.int64) * (n - 1)) // (N_SAMPLES - 1)
     return torch.cat([torch.tensor([float(n), x.sum().item(), (x * x).sum().item()], dtype=torch.float64),

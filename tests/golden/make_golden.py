@@ -196,12 +196,12 @@ def run_case(name, case, tmp, tokenizer):
             out['%s/tap/vhead' % mode] = reduce_tensor(taps['vhead'])
             out['%s/tap/enc_states' % mode] = reduce_tensor(taps['fusion'][0])
             out['%s/tap/logp' % mode] = reduce_tensor(taps['logp'])
+            ret['all_loss'].backward()
+            g = dict(model.named_parameters())
+            for k in GRAD_KEYS:
+                if g[k].grad is not None:
+                    out['%s/grad/%s' % (mode, k)] = reduce_tensor(g[k].grad)
             if mode == 'train':
-                ret['all_loss'].backward()
-                g = dict(model.named_parameters())
-                for k in GRAD_KEYS:
-                    if g[k].grad is not None:
-                        out['train/grad/' + k] = reduce_tensor(g[k].grad)
                 sd = model.state_dict()
                 out['train/bn/running_mean'] = reduce_tensor(sd['visual_extractor.model.7.2.bn3.running_mean'])
                 out['train/bn/running_var'] = reduce_tensor(sd['visual_extractor.model.7.2.bn3.running_var'])
@@ -216,12 +216,11 @@ def run_case(name, case, tmp, tokenizer):
             out['%s/tap/fc' % mode] = reduce_tensor(taps['resnet'][1])
             out['%s/tap/vhead' % mode] = reduce_tensor(taps['vhead'])
             out['%s/tap/thead' % mode] = reduce_tensor(taps['thead'])
-            if mode == 'train':
-                ret['all_loss'].backward()
-                g = dict(model.named_parameters())
-                for k in GRAD_KEYS:
-                    if k in g and g[k].grad is not None:
-                        out['train/grad/' + k] = reduce_tensor(g[k].grad)
+            ret['all_loss'].backward()
+            g = dict(model.named_parameters())
+            for k in GRAD_KEYS:
+                if k in g and g[k].grad is not None:
+                    out['%s/grad/%s' % (mode, k)] = reduce_tensor(g[k].grad)
             for h in hs:
                 h.remove()
         elif kind == 'beam':
