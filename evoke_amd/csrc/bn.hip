@@ -16,64 +16,110 @@ __device__ __forceinline__ void st8(bf16_t* p, const float (&v)[8]) {
 }
 
 // Column reductions over rows of x[M][C] (C % 8 == 0, C <= 2048): thread -> channel group cg = tid % (C/8),
-// row lane rl = tid / (C/8); a block sweeps rows rl, rl+RPB, ... of its slice.
+// row lane rl = tid / (C/8); a block sweeps rows rl, rl+RPB, ... of its slice, 4 rows (independent 16-byte loads) per
+// iteration.  Two stages, no atomics (deterministic): per-block partials [nblk][2][C], then colreduce_final sums them.
 // kind 0: {sum x, sum x^2}      kind 1 (bn backward): {sum g, sum g*xhat} with g = dz * (z > 0 if relu)
 struct RedP {
   const bf16_t* x; const bf16_t* dz; const bf16_t* z; const float* mean; const float* invstd;
-  float* out0; float* out1; long M; int C; int kind; int relu; long rows_per_block;
+  float* part; long M; int C; int kind; int relu; long rows_per_block;
 };
 
 __global__ __launch_bounds__(256) void colreduce_kernel(const RedP p) {
   __shared__ float red[2][256 * 8];
-  const int G = p.C >> 3;                 // channel groups
-  const int tpr = G < 256 ? G : 256;      // threads per row
+  const int G = p.C >> 3;                 // channel groups (<= 256)
+  const int tpr = G;                      // threads per row
   const int rpb = 256 / tpr;              // rows in flight per block
-  const int cg0 = threadIdx.x % tpr, rl = threadIdx.x / tpr;
+  const int cg = threadIdx.x % tpr, rl = threadIdx.x / tpr;
   const long r0 = blockIdx.x * p.rows_per_block;
   const long r1 = min(p.M, r0 + p.rows_per_block);
-  for (int cg = cg0; cg < G; cg += tpr) {  // (only loops when C > 2048; kept for generality)
-    float a[8], b[8];
+  float a[8], b[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) a[j] = b[j] = 0.f;
-    float mu[8], is[8];
-    if (p.kind == 1) {
+  for (int j = 0; j < 8; ++j) a[j] = b[j] = 0.f;
+  float mu[8], is[8];
+  if (p.kind == 1) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { mu[j] = p.mean[cg * 8 + j]; is[j] = p.invstd[cg * 8 + j]; }
+    for (int j = 0; j < 8; ++j) { mu[j] = p.mean[cg * 8 + j]; is[j] = p.invstd[cg * 8 + j]; }
+  }
+  constexpr int U = 4;
+  for (long rb = r0 + rl; rb < r1; rb += (long)rpb * U) {
+    uint4 xv[U], gv[U], zv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long r = rb + (long)u * rpb;
+      const bool ok = r < r1;
+      const long o = (ok ? r : r0) * p.C + cg * 8;
+      xv[u] = *reinterpret_cast<const uint4*>(p.x + o);
+      if (p.kind == 1) {
+        gv[u] = *reinterpret_cast<const uint4*>(p.dz + o);
+        if (p.relu) zv[u] = *reinterpret_cast<const uint4*>(p.z + o);
+      }
+      if (!ok) { xv[u] = make_uint4(0, 0, 0, 0); gv[u] = make_uint4(0, 0, 0, 0); }
     }
-    if (rl < rpb) {
-      for (long r = r0 + rl; r < r1; r += rpb) {
-        float xv[8];
-        ld8(p.x + r * p.C + cg * 8, xv);
-        if (p.kind == 0) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) { a[j] += xv[j]; b[j] += xv[j] * xv[j]; }
-        } else {
-          float g[8];
-          ld8(p.dz + r * p.C + cg * 8, g);
-          if (p.relu) {
-            float zv[8];
-            ld8(p.z + r * p.C + cg * 8, zv);
+    for (int u = 0; u < U; ++u) {
+      const uint32_t xw[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+      if (p.kind == 0) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) g[j] = zv[j] > 0.f ? g[j] : 0.f;
-          }
+        for (int j = 0; j < 4; ++j) {
+          const float lo = lo_bf(xw[j]), hi = hi_bf(xw[j]);
+          a[2 * j] += lo; b[2 * j] += lo * lo; a[2 * j + 1] += hi; b[2 * j + 1] += hi * hi;
+        }
+      } else {
+        const uint32_t gw[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+        const uint32_t zw[4] = {zv[u].x, zv[u].y, zv[u].z, zv[u].w};
+        const bool valid = (rb + (long)u * rpb) < r1;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) { a[j] += g[j]; b[j] += g[j] * (xv[j] - mu[j]) * is[j]; }
+        for (int j = 0; j < 4; ++j) {
+          float g0 = lo_bf(gw[j]), g1 = hi_bf(gw[j]);
+          if (p.relu) { g0 = lo_bf(zw[j]) > 0.f ? g0 : 0.f; g1 = hi_bf(zw[j]) > 0.f ? g1 : 0.f; }
+          if (!valid) { g0 = 0.f; g1 = 0.f; }
+          a[2 * j] += g0; b[2 * j] += g0 * (lo_bf(xw[j]) - mu[2 * j]) * is[2 * j];
+          a[2 * j + 1] += g1; b[2 * j + 1] += g1 * (hi_bf(xw[j]) - mu[2 * j + 1]) * is[2 * j + 1];
         }
       }
     }
-    __syncthreads();
+  }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { red[0][threadIdx.x * 8 + j] = a[j]; red[1][threadIdx.x * 8 + j] = b[j]; }
-    __syncthreads();
-    if (rl == 0) {
+  for (int j = 0; j < 8; ++j) { red[0][threadIdx.x * 8 + j] = a[j]; red[1][threadIdx.x * 8 + j] = b[j]; }
+  __syncthreads();
+  if (rl == 0) {
+    float* o0 = p.part + (long)blockIdx.x * 2 * p.C;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float sa = 0.f, sb = 0.f;
-        for (int q = 0; q < rpb; ++q) { sa += red[0][(q * tpr + cg0) * 8 + j]; sb += red[1][(q * tpr + cg0) * 8 + j]; }
-        unsafeAtomicAdd(p.out0 + cg * 8 + j, sa);
-        unsafeAtomicAdd(p.out1 + cg * 8 + j, sb);
-      }
+    for (int j = 0; j < 8; ++j) {
+      float sa = 0.f, sb = 0.f;
+      for (int q = 0; q < rpb; ++q) { sa += red[0][(q * tpr + cg) * 8 + j]; sb += red[1][(q * tpr + cg) * 8 + j]; }
+      o0[cg * 8 + j] = sa;
+      o0[p.C + cg * 8 + j] = sb;
     }
+  }
+}
+
+// out0[c] = sum_blk part[blk][0][c], out1[c] = sum_blk part[blk][1][c].  Block = 16 columns x 16 row-lanes: every
+// thread sums nblk/16 partials with 8 independent loads in flight, then the 16 row-lanes are combined in LDS.
+__global__ __launch_bounds__(256) void colreduce_final_kernel(const float* __restrict__ part, float* __restrict__ out0,
+                                                              float* __restrict__ out1, int nblk, int C) {
+  __shared__ float red[16][17];
+  const int col = blockIdx.x * 16 + (threadIdx.x & 15);
+  const int rl = threadIdx.x >> 4;
+  const long ld = 2L * C;
+  float acc[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+  if (col < 2 * C) {
+    int b = rl;
+    for (; b + 16 * 7 < nblk; b += 16 * 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += part[(long)(b + 16 * u) * ld + col];
+    }
+    for (; b < nblk; b += 16) acc[0] += part[(long)b * ld + col];
+  }
+  red[rl][threadIdx.x & 15] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (threadIdx.x < 16 && col < 2 * C) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += red[q][threadIdx.x];
+    if (col < C) out0[col] = s; else out1[col - C] = s;
   }
 }
 
@@ -270,18 +316,23 @@ __global__ __launch_bounds__(256) void patch_mean_bwd_kernel(const bf16_t* __res
 
 inline int ew_blocks(long work) { long b = cdiv(work, 256); return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); }
 
-int launch_reduce(const RedP& p0, hipStream_t s) {
+constexpr int RED_MAX_BLOCKS = 1024;
+
+int launch_reduce(const RedP& p0, float* out0, float* out1, void* ws, long ws_bytes, hipStream_t s) {
   RedP p = p0;
   const int G = p.C >> 3;
-  const int tpr = G < 256 ? G : 256;
-  const int rpb = 256 / tpr;
-  long blocks = cdiv(p.M, (long)rpb * 8);      // >= 8 rows per thread-row
-  if (blocks > 1024) blocks = 1024;
+  const int rpb = 256 / G;
+  long blocks = cdiv(p.M, (long)rpb * 32);     // >= 32 rows per thread-row (8 iterations of 4 independent loads)
+  if (blocks > RED_MAX_BLOCKS) blocks = RED_MAX_BLOCKS;
   if (blocks < 1) blocks = 1;
   p.rows_per_block = cdiv(p.M, blocks);
   blocks = cdiv(p.M, p.rows_per_block);
+  EVK_REQUIRE(ws && ws_bytes >= blocks * 2 * p.C * (long)sizeof(float), "colreduce: workspace too small (%ld bytes needed)",
+              blocks * 2 * p.C * (long)sizeof(float));
+  p.part = reinterpret_cast<float*>(ws);
   ProfScope ps(EVK_FAM_REDUCE, s);
   hipLaunchKernelGGL(colreduce_kernel, dim3((int)blocks), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(colreduce_final_kernel, dim3((int)cdiv(2 * p.C, 16)), dim3(256), 0, s, p.part, out0, out1, (int)blocks, p.C);
   return evk_check_launch("colreduce");
 }
 
@@ -289,12 +340,14 @@ int launch_reduce(const RedP& p0, hipStream_t s) {
 
 extern "C" {
 
-// out0[c] += sum_rows x, out1[c] += sum_rows x^2     (outputs must be zeroed by the caller)
-int evk_bn_stats(const void* x, float* sum, float* sumsq, int64_t M, int32_t C, evk_stream_t stream) {
-  EVK_REQUIRE(x && sum && sumsq && M > 0 && C % 8 == 0 && C >= 8 && C <= 2048 && (C / 8 >= 256 || 256 % (C / 8) == 0),
+int64_t evk_colreduce_ws_bytes(int32_t C) { return (int64_t)RED_MAX_BLOCKS * 2 * C * (int64_t)sizeof(float); }
+
+// sum[c] = sum_rows x, sumsq[c] = sum_rows x^2   (two-stage, deterministic; ws >= evk_colreduce_ws_bytes(C))
+int evk_bn_stats(const void* x, float* sum, float* sumsq, void* ws, int64_t ws_bytes, int64_t M, int32_t C, evk_stream_t stream) {
+  EVK_REQUIRE(x && sum && sumsq && M > 0 && C % 8 == 0 && C >= 8 && C <= 2048 && 256 % (C / 8) == 0,
               "bn_stats: bad args (C=%d must be a power-of-two multiple of 8, <= 2048)", C);
-  RedP p{(const bf16_t*)x, nullptr, nullptr, nullptr, nullptr, sum, sumsq, M, C, 0, 0, 0};
-  return launch_reduce(p, reinterpret_cast<hipStream_t>(stream));
+  RedP p{(const bf16_t*)x, nullptr, nullptr, nullptr, nullptr, nullptr, M, C, 0, 0, 0};
+  return launch_reduce(p, sum, sumsq, ws, ws_bytes, reinterpret_cast<hipStream_t>(stream));
 }
 
 int evk_bn_finalize(const float* sum, const float* sumsq, const float* gamma, const float* beta, float* running_mean,
@@ -320,13 +373,13 @@ int evk_bn_apply(const void* x, const float* scale, const float* shift, const vo
   return evk_check_launch("bn_apply");
 }
 
-// sum_g[c] += sum_rows g, sum_gx[c] += sum_rows g*xhat  with g = dz * (z > 0 if relu)    (zeroed by the caller)
+// sum_g[c] = sum_rows g, sum_gx[c] = sum_rows g*xhat  with g = dz * (z > 0 if relu)
 int evk_bn_bwd_reduce(const void* dz, const void* z, const void* x, const float* mean, const float* invstd, float* sum_g,
-                      float* sum_gx, int64_t M, int32_t C, int32_t relu, evk_stream_t stream) {
-  EVK_REQUIRE(dz && x && mean && invstd && sum_g && sum_gx && (!relu || z) && M > 0 && C % 8 == 0 && C <= 2048 &&
-              (C / 8 >= 256 || 256 % (C / 8) == 0), "bn_bwd_reduce: bad args");
-  RedP p{(const bf16_t*)x, (const bf16_t*)dz, (const bf16_t*)z, mean, invstd, sum_g, sum_gx, M, C, 1, relu, 0};
-  return launch_reduce(p, reinterpret_cast<hipStream_t>(stream));
+                      float* sum_gx, void* ws, int64_t ws_bytes, int64_t M, int32_t C, int32_t relu, evk_stream_t stream) {
+  EVK_REQUIRE(dz && x && mean && invstd && sum_g && sum_gx && (!relu || z) && M > 0 && C % 8 == 0 && C >= 8 && C <= 2048 &&
+              256 % (C / 8) == 0, "bn_bwd_reduce: bad args");
+  RedP p{(const bf16_t*)x, (const bf16_t*)dz, (const bf16_t*)z, mean, invstd, nullptr, M, C, 1, relu, 0};
+  return launch_reduce(p, sum_g, sum_gx, ws, ws_bytes, reinterpret_cast<hipStream_t>(stream));
 }
 
 int evk_bn_bwd_apply(const void* dz, const void* z, const void* x, const float* scale, const float* mean, const float* invstd,

@@ -94,10 +94,8 @@ int evk_conv2d_dgrad(const void* dy, const void* w, void* dx, const evk_conv_geo
   return evk_gemm_launch(&d, stream);
 }
 
-int evk_conv2d_wgrad(const void* dy, const void* x, float* dw, const evk_conv_geom* g, evk_stream_t stream) {
-  if (int e = check_geom(g)) return e;
+static int wgrad_desc(evk_gemm& d, const void* dy, const void* x, float* dw, const evk_conv_geom* g) {
   const int T = g->KH * g->KW;
-  evk_gemm d{};
   d.A = dy; d.B = x; d.C = dw;
   d.M = g->Co; d.N = g->Ci; d.K = g->N * g->Ho * g->Wo;
   d.a_mode = EVK_A_KSTR; d.lda = g->Co;
@@ -109,6 +107,21 @@ int evk_conv2d_wgrad(const void* dy, const void* x, float* dw, const evk_conv_ge
     d.b_mode = EVK_B_WGATHER;
     d.g.sN = (int64_t)g->Hi * g->Wi * g->Ci; d.g.sH = (int64_t)g->Wi * g->Ci; d.g.sW = g->Ci;
   }
+  return EVK_OK;
+}
+
+int64_t evk_conv2d_wgrad_ws_bytes(const evk_conv_geom* g) {
+  if (!g) return 0;
+  evk_gemm d{};
+  wgrad_desc(d, nullptr, nullptr, nullptr, g);
+  return evk_gemm_workspace_bytes(&d);
+}
+
+int evk_conv2d_wgrad(const void* dy, const void* x, float* dw, const evk_conv_geom* g, void* ws, int64_t ws_bytes, evk_stream_t stream) {
+  if (int e = check_geom(g)) return e;
+  evk_gemm d{};
+  wgrad_desc(d, dy, x, dw, g);
+  d.workspace = ws; d.workspace_bytes = ws_bytes;
   return evk_gemm_launch(&d, stream);
 }
 
@@ -147,15 +160,26 @@ int evk_stem_fwd(const void* xpad, const void* wp, void* y, int32_t N, int32_t H
   return evk_gemm_launch(&d, stream);
 }
 
-int evk_stem_wgrad(const void* dy, const void* xpad, float* dwp, int32_t N, int32_t H, int32_t W, evk_stream_t stream) {
-  EVK_REQUIRE(H % 2 == 0 && W % 2 == 0, "stem: H and W must be even");
-  evk_gemm d{};
+static void stem_wgrad_desc(evk_gemm& d, const void* dy, const void* xpad, float* dwp, int N, int H, int W) {
   stem_geom(&d.g, N, H, W);
   d.A = dy; d.B = xpad; d.C = dwp;
   d.M = 64; d.N = 32; d.K = N * d.g.Ho * d.g.Wo;
   d.a_mode = EVK_A_KSTR; d.lda = 64; d.b_mode = EVK_B_WGATHER;
   d.ldc = 224; d.sCi = 32; d.batch_outer = 1; d.batch_inner = 7;
   d.alpha = 1.f; d.c_dtype = EVK_F32; d.accumulate = 1;
+}
+
+int64_t evk_stem_wgrad_ws_bytes(int32_t N, int32_t H, int32_t W) {
+  evk_gemm d{};
+  stem_wgrad_desc(d, nullptr, nullptr, nullptr, N, H, W);
+  return evk_gemm_workspace_bytes(&d);
+}
+
+int evk_stem_wgrad(const void* dy, const void* xpad, float* dwp, int32_t N, int32_t H, int32_t W, void* ws, int64_t ws_bytes, evk_stream_t stream) {
+  EVK_REQUIRE(H % 2 == 0 && W % 2 == 0, "stem: H and W must be even");
+  evk_gemm d{};
+  stem_wgrad_desc(d, dy, xpad, dwp, N, H, W);
+  d.workspace = ws; d.workspace_bytes = ws_bytes;
   return evk_gemm_launch(&d, stream);
 }
 

@@ -28,6 +28,7 @@ struct GemmP {
   long sAo, sAi, sBo, sBi, sCo, sCi, sRo, sRi;
   float alpha; int act, c_f32, r_f32, accumulate, vec_ok;
   int ksteps_per_split, tilesN;
+  float* slab; long slab_mn;        // split-K partial slabs [z][split][M][N] f32 (accumulate mode with splitk > 1)
   int b_klog, b_kmask; long b_tapstride;
   // gather geometry
   int Hi, Wi, Ho, Wo, KH, KW, sh, sw, ph, pw, lgs;
@@ -121,22 +122,38 @@ struct RowLoader {
 };
 
 // ------------------------------------------------------------------------------------------------
-// K-strided loaders (KSTR / WGATHER): a task = 2 adjacent rows x 8 consecutive k (eight 4-byte loads),
-// transposed in registers into two 16-byte K-contiguous chunks when written to LDS.
+// K-strided loaders (KSTR / WGATHER): the operand is contiguous along its row (m or n) index, strided along k
+// ("transposed").  The tile is staged AS IT LIES IN MEMORY -- LDS image [64 k][ROWS] with 16-byte global loads
+// along the contiguous dim -- and the MFMA fragments (8 consecutive k per lane) are produced by the gfx950
+// transposing LDS read ds_read_b64_tr_b16 (cdna_hip_programming.md T10): per 16-lane group a 4(k) x 16(row) block
+// comes back column-major, two reads give the 8 k of a 16x16x32 fragment.  Bank conflicts: the 8 k-rows touched by
+// one 32-lane half are spread over the eight 32-byte slots of the 256-byte bank line by XOR-ing the 32-byte chunk
+// index with s(k) = (k & 3) | ((k >> 3) & 1) << 2.
 // ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+__device__ __forceinline__ s16x4 lds_tr_read(const char* generic_lds_ptr) {
+  lds_s16x4* p = (lds_s16x4*)(__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(uintptr_t)generic_lds_ptr;
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(p);
+}
+__device__ __forceinline__ int kswz(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
 template <int ROWS, int MODE>  // MODE: 0 = plain/2-level K-strided, 1 = conv weight-gradient gather
 struct KstrLoader {
-  static constexpr int NI = ROWS / 64;
-  static constexpr int HALF = ROWS / 2;
-  static constexpr int KG_STEP = NTHR / HALF;
+  static constexpr int NI = ROWS / 32;
+  static constexpr int CPR = ROWS / 8;          // 16-byte chunks per k-row
+  static constexpr int KSTEP = NTHR / CPR;      // k-rows covered by one pass of the block
+  static constexpr int ROWB = ROWS * 2;
+  static constexpr int NCH = ROWS / 16;         // 32-byte chunks per k-row
   const bf16_t* ptr;
   long ld, tapstride;
   bool rok;
   int kh, kw, klog, kmask;
+  float inv_rpi, inv_rw;
 
   __device__ __forceinline__ void init(const GemmP& p, const bf16_t* b, long ld_, int row0, int nrows, int tid, int tap,
                                        bool two_level) {
-    const int r0 = row0 + 2 * (tid % HALF);
+    const int r0 = row0 + (tid % CPR) * 8;
     rok = r0 < nrows;
     ptr = b + (rok ? r0 : 0);
     ld = ld_;
@@ -145,53 +162,56 @@ struct KstrLoader {
     klog = two_level ? p.b_klog : 30;
     kmask = two_level ? p.b_kmask : 0x7fffffff;
     tapstride = two_level ? p.b_tapstride : 0;
+    inv_rpi = 1.f / (float)p.rows_per_img;
+    inv_rw = 1.f / (float)p.row_w;
   }
 
-  __device__ __forceinline__ void load(const GemmP& p, int k0, int kend, int tid, uint32_t (&v)[NI][8]) const {
+  __device__ __forceinline__ void load(const GemmP& p, int k0, int kend, int tid, uint4 (&v)[NI]) const {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int kb = k0 + (tid / HALF + i * KG_STEP) * 8;
+      const int k = k0 + tid / CPR + i * KSTEP;
+      bool valid = rok && k < kend;
+      long a;
       if constexpr (MODE == 0) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int k = kb + j;
-          const long a = (long)(k & kmask) * ld + (long)(k >> klog) * tapstride;
-          v[i][j] = (rok && k < kend) ? *reinterpret_cast<const uint32_t*>(ptr + a) : 0u;
-        }
+        a = (long)(k & kmask) * ld + (long)(k >> klog) * tapstride;
       } else {
-        int n = kb / p.rows_per_img;
-        int rem = kb - n * p.rows_per_img;
-        int oh = rem / p.row_w;
+        // pixel k -> (n, oh, ow) by float reciprocal + fix-up (k < 2^24)
+        int n = (int)((float)k * inv_rpi);
+        int rem = k - n * p.rows_per_img;
+        if (rem < 0) { --n; rem += p.rows_per_img; } else if (rem >= p.rows_per_img) { ++n; rem -= p.rows_per_img; }
+        int oh = (int)((float)rem * inv_rw);
         int ow = rem - oh * p.row_w;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int ih = oh * p.sh - p.ph + kh, iw = ow * p.sw - p.pw + kw;
-          const bool valid = rok && (kb + j) < kend && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
-          const long a = (long)n * p.sN + (long)ih * p.sH + (long)iw * p.sW;
-          v[i][j] = valid ? *reinterpret_cast<const uint32_t*>(ptr + a) : 0u;
-          if (++ow == p.row_w) { ow = 0; if (++oh == p.Ho) { oh = 0; ++n; } }
-        }
+        if (ow < 0) { --oh; ow += p.row_w; } else if (ow >= p.row_w) { ++oh; ow -= p.row_w; }
+        const int ih = oh * p.sh - p.ph + kh, iw = ow * p.sw - p.pw + kw;
+        valid = valid && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+        a = (long)n * p.sN + (long)ih * p.sH + (long)iw * p.sW;
       }
+      if (valid) v[i] = *reinterpret_cast<const uint4*>(ptr + a);
+      else v[i] = make_uint4(0, 0, 0, 0);
     }
   }
 
-  __device__ __forceinline__ void store(char* lds, int tid, const uint32_t (&v)[NI][8]) const {
-    const int ra = 2 * (tid % HALF), rb = ra + 1;
+  __device__ __forceinline__ void store(char* lds, int tid, const uint4 (&v)[NI]) const {
+    const int m8 = tid % CPR;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int kg = tid / HALF + i * KG_STEP;
-      uint4 lo, hi;
-      lo.x = (v[i][0] & 0xffffu) | (v[i][1] << 16);
-      lo.y = (v[i][2] & 0xffffu) | (v[i][3] << 16);
-      lo.z = (v[i][4] & 0xffffu) | (v[i][5] << 16);
-      lo.w = (v[i][6] & 0xffffu) | (v[i][7] << 16);
-      hi.x = (v[i][0] >> 16) | (v[i][1] & 0xffff0000u);
-      hi.y = (v[i][2] >> 16) | (v[i][3] & 0xffff0000u);
-      hi.z = (v[i][4] >> 16) | (v[i][5] & 0xffff0000u);
-      hi.w = (v[i][6] >> 16) | (v[i][7] & 0xffff0000u);
-      *reinterpret_cast<uint4*>(lds + ra * 128 + ((kg ^ (ra & 7)) << 4)) = lo;
-      *reinterpret_cast<uint4*>(lds + rb * 128 + ((kg ^ (rb & 7)) << 4)) = hi;
+      const int kr = tid / CPR + i * KSTEP;
+      const int ch = (m8 >> 1) ^ (kswz(kr) & (NCH - 1));
+      *reinterpret_cast<uint4*>(lds + kr * ROWB + (ch << 5) + ((m8 & 1) << 4)) = v[i];
     }
+  }
+
+  // fragment of the 16 rows [w64 + 16 i, +16) for MFMA k-step ks: lane (frow, fq) gets k = 32 ks + 8 fq + 0..7
+  static __device__ __forceinline__ bf16x8 frag(const char* tile, int w64, int i, int ks, int frow, int fq) {
+    const int q = frow >> 2, pp = frow & 3;
+    const int k1 = ks * 32 + 8 * fq + q;
+    const int ch = (((w64 >> 4) + i) ^ (kswz(k1) & (NCH - 1)));
+    const char* a = tile + k1 * ROWB + (ch << 5) + (pp << 3);
+    const s16x4 lo = lds_tr_read(a);
+    const s16x4 hi = lds_tr_read(a + 4 * ROWB);
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, r);
   }
 };
 
@@ -238,8 +258,8 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(const GemmP p) {
   if constexpr (BKS) lb.init(p, Bb, p.ldb, tn * TN, p.N, tid, zi, true);
   else lb.init(p, Bb, p.ldb, tn * TN, p.N, tid);
 
-  typename std::conditional<AKS, uint32_t[LA::NI][8], uint4[LA::NI]>::type ra;
-  typename std::conditional<BKS, uint32_t[LB::NI][8], uint4[LB::NI]>::type rb;
+  uint4 ra[LA::NI];
+  uint4 rb[LB::NI];
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -271,13 +291,19 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(const GemmP p) {
       bf16x8 af[4], bfr[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int row = wm * 64 + i * 16 + frow;
-        af[i] = *reinterpret_cast<const bf16x8*>(As + row * 128 + (((ks * 4 + fq) ^ (row & 7)) << 4));
+        if constexpr (AKS) af[i] = LA::frag(As, wm * 64, i, ks, frow, fq);
+        else {
+          const int row = wm * 64 + i * 16 + frow;
+          af[i] = *reinterpret_cast<const bf16x8*>(As + row * 128 + (((ks * 4 + fq) ^ (row & 7)) << 4));
+        }
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int row = wn * 64 + i * 16 + frow;
-        bfr[i] = *reinterpret_cast<const bf16x8*>(Bs + row * 128 + (((ks * 4 + fq) ^ (row & 7)) << 4));
+        if constexpr (BKS) bfr[i] = LB::frag(Bs, wn * 64, i, ks, frow, fq);
+        else {
+          const int row = wn * 64 + i * 16 + frow;
+          bfr[i] = *reinterpret_cast<const bf16x8*>(Bs + row * 128 + (((ks * 4 + fq) ^ (row & 7)) << 4));
+        }
       }
 #pragma unroll
       for (int in = 0; in < 4; ++in)
@@ -308,10 +334,26 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(const GemmP p) {
       float v[4] = {acc[in][im][0] * p.alpha, acc[in][im][1] * p.alpha, acc[in][im][2] * p.alpha, acc[in][im][3] * p.alpha};
       const bool full = p.vec_ok && (n0 + 3 < p.N);
       if (p.accumulate) {
-        float* c = reinterpret_cast<float*>(Cb) + (long)m * p.ldc + n0;
+        if (p.slab) {          // split-K partial: plain row-contiguous stores, summed into C by splitk_reduce_kernel
+          float* c = p.slab + ((long)blockIdx.z * gridDim.y + blockIdx.y) * p.slab_mn + (long)m * p.N + n0;
+          if ((p.N & 3) == 0 && n0 + 3 < p.N) *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+          else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (n0 + j < p.N) unsafeAtomicAdd(c + j, v[j]);
+            for (int j = 0; j < 4; ++j) if (n0 + j < p.N) c[j] = v[j];
+          }
+        } else if (gridDim.y == 1) {   // this block owns the tile: plain read-modify-write
+          float* c = reinterpret_cast<float*>(Cb) + (long)m * p.ldc + n0;
+          if (full) { float4 t = *reinterpret_cast<float4*>(c); t.x += v[0]; t.y += v[1]; t.z += v[2]; t.w += v[3]; *reinterpret_cast<float4*>(c) = t; }
+          else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (n0 + j < p.N) c[j] += v[j];
+          }
+        } else {               // no workspace given: f32 atomics (slow access shape, kept as a fallback)
+          float* c = reinterpret_cast<float*>(Cb) + (long)m * p.ldc + n0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (n0 + j < p.N) unsafeAtomicAdd(c + j, v[j]);
+        }
         continue;
       }
       if (p.bias) {
@@ -359,6 +401,41 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(const GemmP p) {
   }
 }
 
+// C[z][m][n] += sum_split slab[z][split][m][n].  Block = 16 float4 columns x 16 split lanes.
+struct SkrP { const float* slab; float* C; long mn; int M, N, splitk, bi; long ldc, sCo, sCi; };
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const SkrP p) {
+  __shared__ float4 red[16][17];
+  const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const long q = (long)blockIdx.x * 16 + e;          // float4 index within the M x N slab (N % 4 == 0)
+  const long nq = p.mn >> 2;
+  const int z = blockIdx.y;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (q < nq) {
+    const float4* base = reinterpret_cast<const float4*>(p.slab + (long)z * p.splitk * p.mn) + q;
+    int sp = sl;
+    for (; sp + 48 < p.splitk; sp += 64) {
+      const float4 t0 = base[(long)sp * nq], t1 = base[(long)(sp + 16) * nq], t2 = base[(long)(sp + 32) * nq], t3 = base[(long)(sp + 48) * nq];
+      a.x += (t0.x + t1.x) + (t2.x + t3.x); a.y += (t0.y + t1.y) + (t2.y + t3.y);
+      a.z += (t0.z + t1.z) + (t2.z + t3.z); a.w += (t0.w + t1.w) + (t2.w + t3.w);
+    }
+    for (; sp < p.splitk; sp += 16) { const float4 t = base[(long)sp * nq]; a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; }
+  }
+  red[sl][e] = a;
+  __syncthreads();
+  if (sl == 0 && q < nq) {
+    float4 s4 = red[0][e];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) { const float4 t = red[i][e]; s4.x += t.x; s4.y += t.y; s4.z += t.z; s4.w += t.w; }
+    const long idx = q << 2;
+    const int m = (int)(idx / p.N), n = (int)(idx - (long)m * p.N);
+    const int zo = z / p.bi, zi = z - zo * p.bi;
+    float* c = p.C + zo * p.sCo + zi * p.sCi + (long)m * p.ldc + n;
+    c[0] += s4.x; c[1] += s4.y; c[2] += s4.z; c[3] += s4.w;
+  }
+}
+
+constexpr long SLAB_MAX_BYTES = 192L << 20;
+
 template <int WM, int WN, int AMODE, int BMODE>
 int launch_cfg(const GemmP& p, dim3 grid, hipStream_t s) {
   constexpr int LDS = 2 * (64 * WM + 64 * WN) * BK * 2;
@@ -372,30 +449,58 @@ int launch_cfg(const GemmP& p, dim3 grid, hipStream_t s) {
   return evk_check_launch("gemm_kernel");
 }
 
+// split-K choice shared by the launcher and evk_gemm_workspace_bytes
+inline int choose_splitk(int M, int N, int K, int batch, int splitk_req) {
+  const bool narrow = N <= 64;
+  const int TM = narrow ? 256 : 128, TN = narrow ? 64 : 128;
+  const long tiles = cdiv(M, TM) * cdiv(N, TN) * batch;
+  const int ksteps = (int)cdiv(K, BK);
+  long splitk = splitk_req > 0 ? splitk_req : cdiv(1024, tiles);
+  if (splitk > 512) splitk = 512;
+  const long per_split = (long)M * N * batch * 4;
+  if (splitk * per_split > SLAB_MAX_BYTES) splitk = SLAB_MAX_BYTES / per_split;
+  if (splitk > ksteps) splitk = ksteps;
+  if (splitk < 1) splitk = 1;
+  const int per = (int)cdiv(ksteps, splitk);
+  return (int)cdiv(ksteps, per);
+}
+
 template <int AMODE, int BMODE>
-int launch_modes(GemmP& p, int batch, int splitk_req, hipStream_t s) {
+int launch_modes(GemmP& p, int batch, int splitk_req, void* ws, long ws_bytes, const evk_gemm* d, hipStream_t s) {
   const bool narrow = p.N <= 64;
   const int TM = narrow ? 256 : 128, TN = narrow ? 64 : 128;
   const int tilesM = (int)cdiv(p.M, TM);
   p.tilesN = (int)cdiv(p.N, TN);
   const int ksteps = (int)cdiv(p.K, BK);
   int splitk = 1;
+  p.slab = nullptr;
   if (p.accumulate) {
-    const long tiles = (long)tilesM * p.tilesN * batch;
-    splitk = splitk_req > 0 ? splitk_req : (int)cdiv(1024, tiles);
-    if (splitk > ksteps) splitk = ksteps;
-    if (splitk < 1) splitk = 1;
+    splitk = choose_splitk(p.M, p.N, p.K, batch, splitk_req);
+    p.slab_mn = (long)p.M * p.N;
+    if (splitk > 1 && ws && (p.N % 4 == 0) && ws_bytes >= (long)splitk * batch * p.slab_mn * 4) p.slab = reinterpret_cast<float*>(ws);
   }
   p.ksteps_per_split = (int)cdiv(ksteps, splitk);
   splitk = (int)cdiv(ksteps, p.ksteps_per_split);
   dim3 grid(tilesM * p.tilesN, splitk, batch);
-  if (narrow) return launch_cfg<4, 1, AMODE, BMODE>(p, grid, s);
-  return launch_cfg<2, 2, AMODE, BMODE>(p, grid, s);
+  int rc = narrow ? launch_cfg<4, 1, AMODE, BMODE>(p, grid, s) : launch_cfg<2, 2, AMODE, BMODE>(p, grid, s);
+  if (rc == EVK_OK && p.slab) {
+    SkrP r{p.slab, reinterpret_cast<float*>(p.C), p.slab_mn, p.M, p.N, splitk, p.bi, p.ldc, p.sCo, p.sCi};
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)cdiv(p.slab_mn / 4, 16), batch), dim3(256), 0, s, r);
+    rc = evk_check_launch("splitk_reduce");
+  }
+  return rc;
 }
 
 inline bool al(const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 }  // namespace
+
+extern "C" int64_t evk_gemm_workspace_bytes(const evk_gemm* d) {
+  if (!d || !d->accumulate || d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->N % 4)) return 0;
+  const int batch = d->batch_outer * d->batch_inner;
+  const int sk = choose_splitk(d->M, d->N, d->K, batch, d->splitk);
+  return sk > 1 ? (int64_t)sk * batch * d->M * d->N * 4 : 0;
+}
 
 extern "C" int evk_gemm_launch(const evk_gemm* d, evk_stream_t stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -441,27 +546,27 @@ extern "C" int evk_gemm_launch(const evk_gemm* d, evk_stream_t stream) {
   if (d->a_mode == EVK_A_PLAIN) EVK_REQUIRE(d->K % 8 == 0 && d->lda % 8 == 0 && d->sAo % 8 == 0 && d->sAi % 8 == 0, "A_PLAIN: K, lda, batch strides must be multiples of 8 (K=%d lda=%ld)", d->K, (long)d->lda);
   if (d->a_mode == EVK_A_CONV || d->a_mode == EVK_A_DGRAD) EVK_REQUIRE(d->K % 8 == 0, "A gather: K %% 8");
   if (d->a_mode == EVK_A_CONV) EVK_REQUIRE(g.sW % 8 == 0 && g.sH % 8 == 0 && g.sN % 8 == 0, "A_CONV: strides %% 8");
-  if (d->a_mode == EVK_A_KSTR) EVK_REQUIRE(d->lda % 2 == 0 && d->sAo % 2 == 0 && d->sAi % 2 == 0 && (d->M % 2 == 0 || d->lda > d->M), "A_KSTR: lda even and padded (M=%d lda=%ld)", d->M, (long)d->lda);
+  if (d->a_mode == EVK_A_KSTR) EVK_REQUIRE(d->lda % 8 == 0 && d->sAo % 8 == 0 && d->sAi % 8 == 0 && d->lda >= (d->M + 7) / 8 * 8, "A_KSTR: lda must be a multiple of 8 and >= pad8(M) (M=%d lda=%ld)", d->M, (long)d->lda);
   if (d->b_mode == EVK_B_PLAIN) EVK_REQUIRE(d->K % 8 == 0 && d->ldb % 8 == 0 && d->sBo % 8 == 0 && d->sBi % 8 == 0, "B_PLAIN: K, ldb, batch strides must be multiples of 8 (K=%d ldb=%ld)", d->K, (long)d->ldb);
   if (d->b_mode == EVK_B_KSTR) {
-    EVK_REQUIRE(d->ldb % 2 == 0 && d->sBo % 2 == 0 && d->sBi % 2 == 0 && d->b_tapstride % 2 == 0 && (d->N % 2 == 0 || d->ldb > d->N), "B_KSTR: ldb even and padded (N=%d ldb=%ld)", d->N, (long)d->ldb);
+    EVK_REQUIRE(d->ldb % 8 == 0 && d->sBo % 8 == 0 && d->sBi % 8 == 0 && d->b_tapstride % 8 == 0 && (d->b_klog > 0 || d->ldb >= (d->N + 7) / 8 * 8), "B_KSTR: ldb must be a multiple of 8 and >= pad8(N) (N=%d ldb=%ld)", d->N, (long)d->ldb);
     p.b_klog = d->b_klog > 0 ? d->b_klog : 30;
     p.b_kmask = d->b_klog > 0 ? ((1 << d->b_klog) - 1) : 0x7fffffff;
     p.b_tapstride = d->b_tapstride;
   }
   if (d->b_mode != EVK_B_KSTR) { p.b_klog = 30; p.b_kmask = 0x7fffffff; p.b_tapstride = 0; }
-  if (d->b_mode == EVK_B_WGATHER) EVK_REQUIRE(d->N % 2 == 0, "B_WGATHER: N even");
+  if (d->b_mode == EVK_B_WGATHER) EVK_REQUIRE(d->N % 8 == 0 && g.sW % 8 == 0 && g.sH % 8 == 0 && g.sN % 8 == 0 && (long)d->K < (1L << 24), "B_WGATHER: N %% 8, strides %% 8, K < 2^24");
 
   const int batch = d->batch_outer * d->batch_inner;
   const double flops = 2.0 * d->M * (double)d->N * d->K * batch;
   ProfScope ps(EVK_FAM_GEMM, s, flops);
   const int am = d->a_mode, bm = d->b_mode;
-  if (am == EVK_A_PLAIN && bm == EVK_B_PLAIN) return launch_modes<EVK_A_PLAIN, EVK_B_PLAIN>(p, batch, d->splitk, s);
-  if (am == EVK_A_CONV && bm == EVK_B_PLAIN) return launch_modes<EVK_A_CONV, EVK_B_PLAIN>(p, batch, d->splitk, s);
-  if (am == EVK_A_PLAIN && bm == EVK_B_KSTR) return launch_modes<EVK_A_PLAIN, EVK_B_KSTR>(p, batch, d->splitk, s);
-  if (am == EVK_A_DGRAD && bm == EVK_B_KSTR) return launch_modes<EVK_A_DGRAD, EVK_B_KSTR>(p, batch, d->splitk, s);
-  if (am == EVK_A_KSTR && bm == EVK_B_KSTR) return launch_modes<EVK_A_KSTR, EVK_B_KSTR>(p, batch, d->splitk, s);
-  if (am == EVK_A_KSTR && bm == EVK_B_WGATHER) return launch_modes<EVK_A_KSTR, EVK_B_WGATHER>(p, batch, d->splitk, s);
+  if (am == EVK_A_PLAIN && bm == EVK_B_PLAIN) return launch_modes<EVK_A_PLAIN, EVK_B_PLAIN>(p, batch, d->splitk, d->workspace, d->workspace_bytes, d, s);
+  if (am == EVK_A_CONV && bm == EVK_B_PLAIN) return launch_modes<EVK_A_CONV, EVK_B_PLAIN>(p, batch, d->splitk, d->workspace, d->workspace_bytes, d, s);
+  if (am == EVK_A_PLAIN && bm == EVK_B_KSTR) return launch_modes<EVK_A_PLAIN, EVK_B_KSTR>(p, batch, d->splitk, d->workspace, d->workspace_bytes, d, s);
+  if (am == EVK_A_DGRAD && bm == EVK_B_KSTR) return launch_modes<EVK_A_DGRAD, EVK_B_KSTR>(p, batch, d->splitk, d->workspace, d->workspace_bytes, d, s);
+  if (am == EVK_A_KSTR && bm == EVK_B_KSTR) return launch_modes<EVK_A_KSTR, EVK_B_KSTR>(p, batch, d->splitk, d->workspace, d->workspace_bytes, d, s);
+  if (am == EVK_A_KSTR && bm == EVK_B_WGATHER) return launch_modes<EVK_A_KSTR, EVK_B_WGATHER>(p, batch, d->splitk, d->workspace, d->workspace_bytes, d, s);
   evk_set_error("evk_gemm: unsupported mode pair a=%d b=%d", am, bm);
   return EVK_EUNSUPPORTED;
 }

@@ -31,7 +31,7 @@ class Gemm(C.Structure):
                 ('sCo', C.c_int64), ('sCi', C.c_int64), ('sRo', C.c_int64), ('sRi', C.c_int64),
                 ('alpha', C.c_float), ('act', C.c_int32), ('c_dtype', C.c_int32), ('r_dtype', C.c_int32),
                 ('accumulate', C.c_int32), ('splitk', C.c_int32), ('b_klog', C.c_int32), ('b_tapstride', C.c_int64),
-                ('g', ConvGeom)]
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64), ('g', ConvGeom)]
 
 
 _CTYPES = {'int': C.c_int32, 'int32_t': C.c_int32, 'int64_t': C.c_int64, 'uint64_t': C.c_uint64, 'float': C.c_float,
@@ -44,7 +44,7 @@ def _prototypes():
     hdr = os.path.join(os.path.dirname(_HERE), 'include', 'evoke_hip.h')
     txt = re.sub(r'/\*.*?\*/', '', open(hdr).read(), flags=re.S)
     out = {}
-    for m in re.finditer(r'\bint\s+(evk_[a-z0-9_]+)\s*\(([^)]*)\)\s*;', txt):
+    for m in re.finditer(r'\bint(?:64_t)?\s+(evk_[a-z0-9_]+)\s*\(([^)]*)\)\s*;', txt):
         args = []
         for a in m.group(2).split(','):
             a = a.strip()
@@ -67,7 +67,7 @@ def _load():
     for name, args in _prototypes().items():
         fn = getattr(lib, name)
         fn.argtypes = args
-        fn.restype = C.c_int
+        fn.restype = C.c_int64 if name.endswith('_bytes') else C.c_int
     return lib
 
 

@@ -73,7 +73,7 @@ def _mm_nn(a, b):
     N = b.shape[2]
     ah, al = _split(_pad_last(a, 8))
     Sp = ah.shape[2]
-    bp = _pad_last(b, 2)
+    bp = _pad_last(b, 8)
     if Sp != S:
         t = bp.new_zeros(G, Sp, bp.shape[2])
         t[:, :S] = bp
@@ -92,8 +92,8 @@ def _mm_tn(a, b):
     """(G,S,M)^T x (G,S,N) -> (G,M,N)."""
     G, S, M = a.shape
     N = b.shape[2]
-    ah, al = _split(_pad_last(a, 2))
-    bh, bl = _split(_pad_last(b, 2))
+    ah, al = _split(_pad_last(a, 8))
+    bh, bl = _split(_pad_last(b, 8))
     A = torch.cat([ah, ah, al], dim=1).contiguous()
     Bm = torch.cat([bh, bl, bh], dim=1).contiguous()
     lda, ldb = A.shape[2], Bm.shape[2]

@@ -103,6 +103,11 @@ def gemm(A, B, Cm, M, N, K, a_mode=H.A_PLAIN, b_mode=H.B_PLAIN, lda=0, ldb=0, ld
     d.accumulate = 1 if accumulate else 0
     d.splitk = splitk
     d.b_klog, d.b_tapstride = b_klog, b_tapstride
+    if accumulate:
+        nb = H.lib.evk_gemm_workspace_bytes(C.byref(d))
+        if nb > 0:
+            ws = torch.empty(nb // 4, dtype=F32, device=Cm.device)
+            d.workspace, d.workspace_bytes = ws.data_ptr(), nb
     H.check(H.lib.evk_gemm_launch(C.byref(d), H.stream()), 'gemm')
 
 

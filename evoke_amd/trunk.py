@@ -42,7 +42,9 @@ class _Conv(torch.autograd.Function):
             dx = _e(*x.shape, device=x.device)
             H.check(H.lib.evk_conv2d_dgrad(H.ptr(dy), H.ptr(shadow(W)), H.ptr(dx), C.byref(g), H.stream()), 'conv_dgrad')
         if W.requires_grad:
-            H.check(H.lib.evk_conv2d_wgrad(H.ptr(dy), H.ptr(x), H.ptr(grad_buffer(W)), C.byref(g), H.stream()), 'conv_wgrad')
+            nb = H.lib.evk_conv2d_wgrad_ws_bytes(C.byref(g))
+            ws = torch.empty(max(nb // 4, 1), dtype=F32, device=x.device)
+            H.check(H.lib.evk_conv2d_wgrad(H.ptr(dy), H.ptr(x), H.ptr(grad_buffer(W)), C.byref(g), H.ptr(ws), nb, H.stream()), 'conv_wgrad')
             grad_done(W)
         return dx, None, None, None
 
@@ -78,10 +80,17 @@ class _Stem(torch.autograd.Function):
             st = H.stream()
             dy = dy.contiguous()
             dwp = _z(64 * 224, dtype=F32, device=dy.device)
-            H.check(H.lib.evk_stem_wgrad(H.ptr(dy), H.ptr(xpad), H.ptr(dwp), N, Hh, Ww, st), 'stem_wgrad')
+            nb = H.lib.evk_stem_wgrad_ws_bytes(N, Hh, Ww)
+            ws = torch.empty(max(nb // 4, 1), dtype=F32, device=dy.device)
+            H.check(H.lib.evk_stem_wgrad(H.ptr(dy), H.ptr(xpad), H.ptr(dwp), N, Hh, Ww, H.ptr(ws), nb, st), 'stem_wgrad')
             H.check(H.lib.evk_stem_unpack_wgrad(H.ptr(dwp), H.ptr(grad_buffer(W)), st), 'stem_unpack_wgrad')
             grad_done(W)
         return None, None
+
+
+def _reduce_ws(C_, dev):
+    """workspace for the two-stage column reductions (per-block partials)"""
+    return torch.empty(H.lib.evk_colreduce_ws_bytes(C_) // 4, dtype=F32, device=dev)
 
 
 class _BatchNorm(torch.autograd.Function):
@@ -95,7 +104,8 @@ class _BatchNorm(torch.autograd.Function):
         st = H.stream()
         stats = _z(6, Cc, dtype=F32, device=dev)          # sum, sumsq, scale, shift, mean, invstd
         if training:
-            H.check(H.lib.evk_bn_stats(H.ptr(x), H.ptr(stats[0]), H.ptr(stats[1]), M, Cc, st), 'bn_stats')
+            ws = _reduce_ws(Cc, dev)
+            H.check(H.lib.evk_bn_stats(H.ptr(x), H.ptr(stats[0]), H.ptr(stats[1]), H.ptr(ws), ws.numel() * 4, M, Cc, st), 'bn_stats')
         H.check(H.lib.evk_bn_finalize(H.ptr(stats[0]), H.ptr(stats[1]), H.ptr(gamma), H.ptr(beta), H.ptr(rmean), H.ptr(rvar),
                                       H.ptr(stats[2]), H.ptr(stats[3]), H.ptr(stats[4]), H.ptr(stats[5]), Cc, C.c_float(M),
                                       C.c_float(momentum), C.c_float(eps), int(training), st), 'bn_finalize')
@@ -113,9 +123,10 @@ class _BatchNorm(torch.autograd.Function):
         dev = x.device
         st = H.stream()
         dz = dz.contiguous()
-        sums = _z(2, Cc, dtype=F32, device=dev)
+        sums = _e(2, Cc, dtype=F32, device=dev)
+        ws = _reduce_ws(Cc, dev)
         H.check(H.lib.evk_bn_bwd_reduce(H.ptr(dz), H.ptr(z), H.ptr(x), H.ptr(stats[4]), H.ptr(stats[5]), H.ptr(sums[0]),
-                                        H.ptr(sums[1]), M, Cc, int(relu), st), 'bn_bwd_reduce')
+                                        H.ptr(sums[1]), H.ptr(ws), ws.numel() * 4, M, Cc, int(relu), st), 'bn_bwd_reduce')
         if gamma is not None and gamma.requires_grad:
             grad_buffer(gamma).add_(sums[1])
             grad_buffer(beta).add_(sums[0])

@@ -63,6 +63,8 @@ typedef struct evk_gemm {
   int32_t accumulate;            /* 1: C is f32 and receives += (atomics); allows split-K              */
   int32_t splitk;                /* <=0: chosen by the library                                          */
   int32_t b_klog; int64_t b_tapstride;   /* EVK_B_KSTR two-level K (see enum)                           */
+  void* workspace; int64_t workspace_bytes; /* accumulate + split-K: partial slabs (evk_gemm_workspace_bytes);
+                                            without it split-K falls back to f32 atomics                  */
   evk_conv_geom g;               /* used by the gather modes                                            */
 } evk_gemm;
 
@@ -80,12 +82,14 @@ int evk_prof_collect(double* ms_per_family, int64_t* launches_per_family, double
  * utils_v0511.py:263-278), nn.Conv1d k=1 (utils_v0511.py:135-147), nn.Conv2d of the ResNet-101 trunk
  * (visual_extractor.py:30-38 -> torchvision), and their autograd backward passes.                      */
 int evk_gemm_launch(const evk_gemm* desc, evk_stream_t stream);
+int64_t evk_gemm_workspace_bytes(const evk_gemm* desc);   /* 0 when no workspace is needed */
 
 /* NHWC bf16 convolution, weights KRSC bf16 ([Co][KH][KW][Ci]); y = conv(x, w) [+ nothing]: BN is separate.
  * fwd:   y[N,Ho,Wo,Co]      dgrad: dx[N,Hi,Wi,Ci]      wgrad: dw[Co,KH,KW,Ci] (f32, accumulated)       */
 int evk_conv2d_fwd(const void* x, const void* w, void* y, const evk_conv_geom* g, evk_stream_t stream);
 int evk_conv2d_dgrad(const void* dy, const void* w, void* dx, const evk_conv_geom* g, evk_stream_t stream);
-int evk_conv2d_wgrad(const void* dy, const void* x, float* dw, const evk_conv_geom* g, evk_stream_t stream);
+int evk_conv2d_wgrad(const void* dy, const void* x, float* dw, const evk_conv_geom* g, void* ws, int64_t ws_bytes, evk_stream_t stream);
+int64_t evk_conv2d_wgrad_ws_bytes(const evk_conv_geom* g);
 
 /* ResNet stem (conv 7x7 s2 p3, 3->64): images f32 NCHW -> zero-padded NHWC4 bf16 staging buffer
  * [N][H+6][W+8][4]; the conv then runs as an implicit GEMM with K = 7 x (8 taps x 4 ch) = 224.        */
@@ -93,7 +97,8 @@ int evk_stem_pack_image(const float* img_nchw, void* xpad, int32_t N, int32_t H,
 int evk_stem_pack_weight(const float* w_oihw, void* w_packed, evk_stream_t stream);        /* [64][7][8][4] bf16 */
 int evk_stem_unpack_wgrad(const float* dw_packed, float* dw_oihw, evk_stream_t stream);    /* += into OIHW grad  */
 int evk_stem_fwd(const void* xpad, const void* w_packed, void* y, int32_t N, int32_t H, int32_t W, evk_stream_t stream);
-int evk_stem_wgrad(const void* dy, const void* xpad, float* dw_packed, int32_t N, int32_t H, int32_t W, evk_stream_t stream);
+int evk_stem_wgrad(const void* dy, const void* xpad, float* dw_packed, int32_t N, int32_t H, int32_t W, void* ws, int64_t ws_bytes, evk_stream_t stream);
+int64_t evk_stem_wgrad_ws_bytes(int32_t N, int32_t H, int32_t W);
 
 /* ---- row-wise kernels (norm.hip): one wavefront per row, shuffle reductions ----------------------------
  * LayerNorm family.  mode 0 = torch.nn.LayerNorm (biased variance, eps inside the sqrt; bert_model.py:355,433,
@@ -136,14 +141,16 @@ int evk_softce(const float* z, const float* t, float* loss_acc, float* dz, const
 
 /* ---- BatchNorm / pooling (bn.hip): x[M][C] bf16 channels-last, C a power-of-two multiple of 8 <= 2048 --------
  * train-mode torch.nn.BatchNorm2d/1d (torchvision resnet101 via visual_extractor.py:30-38; utils_v0511.py:137,177-181) */
-int evk_bn_stats(const void* x, float* sum, float* sumsq, int64_t M, int32_t C, evk_stream_t stream);
+/* column reductions are two-stage (per-block partials in `ws`, then a final sum): deterministic, no atomics */
+int64_t evk_colreduce_ws_bytes(int32_t C);
+int evk_bn_stats(const void* x, float* sum, float* sumsq, void* ws, int64_t ws_bytes, int64_t M, int32_t C, evk_stream_t stream);
 int evk_bn_finalize(const float* sum, const float* sumsq, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float* scale, float* shift, float* mean, float* invstd, int32_t C, float count,
                     float momentum, float eps, int32_t training, evk_stream_t stream);
 int evk_bn_apply(const void* x, const float* scale, const float* shift, const void* resid, void* y, int64_t M, int32_t C,
                  int32_t relu, evk_stream_t stream);
 int evk_bn_bwd_reduce(const void* dz, const void* z, const void* x, const float* mean, const float* invstd, float* sum_g,
-                      float* sum_gx, int64_t M, int32_t C, int32_t relu, evk_stream_t stream);
+                      float* sum_gx, void* ws, int64_t ws_bytes, int64_t M, int32_t C, int32_t relu, evk_stream_t stream);
 int evk_bn_bwd_apply(const void* dz, const void* z, const void* x, const float* scale, const float* mean, const float* invstd,
                      const float* sum_g, const float* sum_gx, void* dx, void* dres, int64_t M, int32_t C, int32_t relu,
                      evk_stream_t stream);

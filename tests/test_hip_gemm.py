@@ -118,6 +118,9 @@ def test_gemm_tn_dw_accumulate(H, M, N, K):
     dyd, xd = dy.cuda(), x.cuda()
     d = base_desc(H, dyd, xd, c, M, N, K, a_mode=H.A_KSTR, b_mode=H.B_KSTR, lda=ldy, ldb=N, ldc=N)
     d.accumulate = 1
+    nb = H.lib.evk_gemm_workspace_bytes(C.byref(d))
+    ws = torch.empty(max(nb // 4, 1), dtype=torch.float32, device='cuda')
+    d.workspace, d.workspace_bytes = ws.data_ptr(), nb
     H.gemm_launch(d)
     want = c0 + dy[:, :M].float().t() @ x.float()
     close(c, want, 2e-4, 3e-3 * K ** 0.5)
@@ -153,7 +156,12 @@ def test_conv_fwd_dgrad_wgrad(H, cfg):
     H.check(H.lib.evk_conv2d_dgrad(H.ptr(dyd), H.ptr(wd), H.ptr(dx), C.byref(g), H.stream()))
     close(dx, xr.grad.permute(0, 2, 3, 1), 1e-2, 2e-2 * (KH * KH * Co / 64) ** 0.5 * w.float().std().item())
     dw = torch.zeros(Co, KH, KH, Ci, dtype=torch.float32, device='cuda')
-    H.check(H.lib.evk_conv2d_wgrad(H.ptr(dyd), H.ptr(xd), H.ptr(dw), C.byref(g), H.stream()))
+    nb = H.lib.evk_conv2d_wgrad_ws_bytes(C.byref(g))
+    ws = torch.empty(max(nb // 4, 1), dtype=torch.float32, device='cuda')
+    H.check(H.lib.evk_conv2d_wgrad(H.ptr(dyd), H.ptr(xd), H.ptr(dw), C.byref(g), H.ptr(ws), nb, H.stream()))
+    dw2 = torch.zeros_like(dw)          # fallback path without workspace (f32 atomics)
+    H.check(H.lib.evk_conv2d_wgrad(H.ptr(dyd), H.ptr(xd), H.ptr(dw2), C.byref(g), None, 0, H.stream()))
+    close(dw2, wr.grad.permute(0, 2, 3, 1), 2e-4, 3e-3 * (N * g.Ho * g.Wo) ** 0.5)
     close(dw, wr.grad.permute(0, 2, 3, 1), 2e-4, 3e-3 * (N * g.Ho * g.Wo) ** 0.5)
 
 
@@ -177,7 +185,9 @@ def test_stem(H, N, Hh, W):
     yr.backward(dy.float().permute(0, 3, 1, 2))
     dwp = torch.zeros(64, 7, 8, 4, dtype=torch.float32, device='cuda')
     dyd = dy.cuda()
-    H.check(H.lib.evk_stem_wgrad(H.ptr(dyd), H.ptr(xpad), H.ptr(dwp), N, Hh, W, H.stream()))
+    nb = H.lib.evk_stem_wgrad_ws_bytes(N, Hh, W)
+    ws = torch.empty(max(nb // 4, 1), dtype=torch.float32, device='cuda')
+    H.check(H.lib.evk_stem_wgrad(H.ptr(dyd), H.ptr(xpad), H.ptr(dwp), N, Hh, W, H.ptr(ws), nb, H.stream()))
     dw = torch.ones(64, 3, 7, 7, dtype=torch.float32, device='cuda')
     H.check(H.lib.evk_stem_unpack_wgrad(H.ptr(dwp), H.ptr(dw), H.stream()))
     close(dw - 1.0, wr.grad, 2e-4, 3e-3 * (N * Hh * W / 4) ** 0.5)
