@@ -67,9 +67,7 @@ class _DecoderState:
         h = model.decoder.layers[0].self_attn.h
         pe = model.tgt_embed[1].pe[0][t:t + 1]
         emb = ops.embedding(it.view(-1, 1).contiguous(), model.tgt_embed[0].lut.weight, pos=pe, scale=math.sqrt(model.d_model))
-        gw = model.rm.W(emb)
-        self.mem = model.rm.step(emb[:, 0].contiguous(), gw[:, 0].contiguous(), self.mem)
-        memory = self.mem.view(self.mem.shape[0], 1, -1)
+        memory, self.mem = model.rm.run(emb, self.mem)          # (R, 1, slots*d), carried memory
         x = emb
         for i, layer in enumerate(model.decoder.layers):
             n = layer.sublayer[0].norm(x, memory)

@@ -475,34 +475,66 @@ class PositionalEncodingP(nn.Module):
         self.register_buffer('pe', pe.unsqueeze(0))
 
 
-class _RMGate(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, gw, gu, nm, m):
-        B, S, D = m.shape
-        out = torch.empty_like(m)
-        si, sf, t = torch.empty_like(m), torch.empty_like(m), torch.empty_like(m)
-        H.check(H.lib.evk_rm_gate_fwd(H.ptr(gw), H.ptr(gu), H.ptr(nm), H.ptr(m), H.ptr(out), H.ptr(si), H.ptr(sf), H.ptr(t),
-                                      B, S, D, H.stream()), 'rm_gate_fwd')
-        ctx.save_for_backward(si, sf, t, m)
-        return out
+class _RMRecurrence(torch.autograd.Function):
+    """The token recurrence of RelationalMemory.forward as ONE native call each way (evk_rm_forward / evk_rm_backward)."""
 
     @staticmethod
-    def backward(ctx, dnext):
-        si, sf, t, m = ctx.saved_tensors
-        B, S, D = m.shape
-        dnext = dnext.contiguous()
-        dnm, dm = torch.empty_like(m), torch.empty_like(m)
-        dg = torch.empty(B, S, 2 * D, dtype=BF16, device=m.device)
-        H.check(H.lib.evk_rm_gate_bwd(H.ptr(dnext), H.ptr(si), H.ptr(sf), H.ptr(t), H.ptr(m), H.ptr(dnm), H.ptr(dm), H.ptr(dg),
-                                      B, S, D, H.stream()), 'rm_gate_bwd')
-        return dg.sum(dim=1), dg, dnm, dm
+    def forward(ctx, xk, xv, gw, m0, rm, p_drop, seed):
+        B, L, d = xk.shape
+        dev = xk.device
+        lin = rm.attn.linears
+        wqkv = torch.cat([ops.shadow(lin[i].weight).view(d, d) for i in range(3)], 0)
+        bqkv = torch.cat([lin[i].bias.detach() for i in range(3)], 0).contiguous()
+        nb = H.lib.evk_rm_ws_bytes(B, L)
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        out = torch.empty(B, L, rm.num_slots * d, dtype=BF16, device=dev)
+        m_last = torch.empty(B, rm.num_slots, d, dtype=BF16, device=dev)
+        H.check(H.lib.evk_rm_forward(H.ptr(xk), H.ptr(xv), H.ptr(gw), H.ptr(m0), H.ptr(wqkv), H.ptr(bqkv), H.ptr(ops.shadow(lin[3].weight)),
+                                     H.ptr(lin[3].bias), H.ptr(ops.shadow(rm.mlp[0].weight)), H.ptr(rm.mlp[0].bias),
+                                     H.ptr(ops.shadow(rm.mlp[2].weight)), H.ptr(rm.mlp[2].bias), H.ptr(ops.shadow(rm.U.weight)),
+                                     H.ptr(rm.U.bias), H.ptr(out), H.ptr(m_last), H.ptr(ws), nb, B, L, p_drop, seed, H.stream()), 'rm_forward')
+        ctx.save_for_backward(xk, xv, wqkv, ws)
+        ctx.rm, ctx.cfg = rm, (B, L, d, p_drop, seed, nb)
+        ctx.mark_non_differentiable(m_last)
+        return out, m_last
+
+    @staticmethod
+    def backward(ctx, dout, _dm_last):
+        xk, xv, wqkv, ws = ctx.saved_tensors
+        rm = ctx.rm
+        B, L, d, p_drop, seed, nb = ctx.cfg
+        lin = rm.attn.linears
+        dev = xk.device
+        dout = dout.contiguous()
+        dxk, dxv = torch.empty_like(xk), torch.empty_like(xv)
+        dgw = torch.empty(B, L, 2 * d, dtype=BF16, device=dev)
+        dWqkv = torch.zeros(3 * d, d, dtype=F32, device=dev)
+        dbqkv = torch.zeros(3 * d, dtype=F32, device=dev)
+        gb = ops.grad_buffer
+        H.check(H.lib.evk_rm_backward(H.ptr(dout), H.ptr(xk), H.ptr(xv), H.ptr(wqkv), H.ptr(ops.shadow(lin[3].weight)),
+                                      H.ptr(ops.shadow(rm.mlp[0].weight)), H.ptr(ops.shadow(rm.mlp[2].weight)), H.ptr(ops.shadow(rm.U.weight)),
+                                      H.ptr(dxk), H.ptr(dxv), H.ptr(dgw), H.ptr(dWqkv), H.ptr(dbqkv), H.ptr(gb(lin[3].weight)),
+                                      H.ptr(gb(lin[3].bias)), H.ptr(gb(rm.mlp[0].weight)), H.ptr(gb(rm.mlp[0].bias)),
+                                      H.ptr(gb(rm.mlp[2].weight)), H.ptr(gb(rm.mlp[2].bias)), H.ptr(gb(rm.U.weight)), H.ptr(gb(rm.U.bias)),
+                                      H.ptr(ws), nb, B, L, p_drop, seed, H.stream()), 'rm_backward')
+        for i in range(3):
+            gb(lin[i].weight).add_(dWqkv[i * d:(i + 1) * d])
+            gb(lin[i].bias).add_(dbqkv[i * d:(i + 1) * d])
+        for p in (lin[0], lin[1], lin[2], lin[3], rm.mlp[0], rm.mlp[2], rm.U):
+            ops.grad_done(p.weight)
+            ops.grad_done(p.bias)
+        return dxk, dxv, dgw, None, None, None, None
 
 
 class RelationalMemory(nn.Module):
-    """encoder_decoder.py:246-300."""
+    """encoder_decoder.py:246-300.  Everything that does not depend on the recurrence (x_t.Wk, x_t.Wv, W(x_t) for all
+    tokens) is three ordinary batched GEMMs; the recurrence itself runs inside the library (csrc/rm.hip)."""
 
     def __init__(self, num_slots, d_model, num_heads=1):
         super().__init__()
+        if (num_slots, d_model, num_heads) != (3, 512, 8):
+            raise NotImplementedError('the native relational-memory runner is built for rm_num_slots=3, rm_d_model=512, rm_num_heads=8 '
+                                      '(config/finetune_config.yaml:45-47)')
         self.num_slots, self.num_heads, self.d_model = num_slots, num_heads, d_model
         self.attn = MultiHeadedAttention(num_heads, d_model)
         self.mlp = nn.Sequential(LinearP(d_model, d_model), _Empty(), LinearP(d_model, d_model), _Empty())
@@ -514,25 +546,16 @@ class RelationalMemory(nn.Module):
         m[:, :, :self.num_slots] = torch.eye(self.num_slots, dtype=BF16, device=device)
         return m
 
-    def step(self, x_t, gw_t, m):
-        """x_t (B, d), gw_t = W(x_t) (B, 2d), m (B, slots, d) -> next memory (B, slots, d)."""
-        kv = torch.cat([m, x_t.unsqueeze(1)], 1)
-        nm = self.attn(m, kv, kv, resid=m)
-        h = self.mlp[2](self.mlp[0](nm, act=H.ACT_RELU), act=H.ACT_RELU)
-        nm = nm + h
-        gu = self.U(ops.activation(m, H.ACT_TANH))
-        return _RMGate.apply(gw_t, gu, nm, m)
+    def run(self, emb, m0):
+        """emb (B, L, d), m0 (B, slots, d) -> (memories (B, L, slots*d), last memory (B, slots, d))."""
+        xk = self.attn.linears[1](emb)
+        xv = self.attn.linears[2](emb)
+        gw = self.W(emb)
+        p = self.attn.p if (self.training and ops.DROPOUT_ENABLED[0]) else 0.0
+        return _RMRecurrence.apply(xk, xv, gw, m0.contiguous(), self, float(p), ops.next_seed() if p > 0 else 0)
 
     def forward(self, emb):
-        """emb (B, L, d) -> (B, L, slots*d): serial over tokens (encoder_decoder.py:293-300)."""
-        B, L, _ = emb.shape
-        m = self.init_memory(B, emb.device)
-        gw = self.W(emb)                      # W(x_t) for every t in one GEMM
-        outs = []
-        for t in range(L):
-            m = self.step(emb[:, t].contiguous(), gw[:, t].contiguous(), m)
-            outs.append(m.view(B, self.num_slots * self.d_model))
-        return torch.stack(outs, dim=1)
+        return self.run(emb, self.init_memory(emb.shape[0], emb.device))[0]
 
 
 class Transformer(nn.Module):

@@ -183,6 +183,22 @@ int evk_rm_gate_bwd(const void* dnext, const void* sig_i, const void* sig_f, con
 int evk_optim_step(float* p, const float* g, float* m, float* v, float* vmax, void* shadow, int64_t n, int32_t kind, float lr,
                    float beta1, float beta2, float eps, float weight_decay, float clip, int64_t step, evk_stream_t stream);
 
+/* ---- relational memory runner (rm.hip): RelationalMemory.forward / forward_step, encoder_decoder.py:274-300 ------
+ * The host loop over tokens lives in the library (5 GEMM launches + 2 fused kernels per token forward, BPTT backward,
+ * one K = L*B*slots weight-gradient GEMM per parameter).  Fixed geometry: 3 slots, d = 512, 8 heads.
+ *   xk, xv (B,L,512) = x_t.Wk^T + bk / x_t.Wv^T + bv,  gw (B,L,1024) = W(x_t): hoisted out of the recurrence by the caller.
+ *   Wqkv [1536][512] = [attn.linears.0; .1; .2] bf16, biases f32.  out (B,L,1536) bf16; m_last (B,3,512) optional.   */
+int64_t evk_rm_ws_bytes(int32_t B, int32_t L);
+int evk_rm_forward(const void* xk, const void* xv, const void* gw, const void* m0, const void* Wqkv, const float* bqkv, const void* Wo,
+                   const float* bo, const void* W0, const float* b0, const void* W2, const float* b2, const void* U, const float* bU,
+                   void* out, void* m_last, void* ws, int64_t ws_bytes, int32_t B, int32_t L, float p_drop, uint64_t seed,
+                   evk_stream_t stream);
+/* dxk, dxv, dgw are written; the f32 parameter gradients are accumulated (+=) */
+int evk_rm_backward(const void* dout, const void* xk, const void* xv, const void* Wqkv, const void* Wo, const void* W0, const void* W2,
+                    const void* U, void* dxk, void* dxv, void* dgw, float* dWqkv, float* dbqkv, float* dWo, float* dbo, float* dW0,
+                    float* db0, float* dW2, float* db2, float* dU, float* dbU, void* ws, int64_t ws_bytes, int32_t B, int32_t L,
+                    float p_drop, uint64_t seed, evk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
