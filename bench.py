@@ -102,6 +102,7 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='studies per GPU')
     ap.add_argument('--views', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dump-launches', default='', help='write one CSV row per profiled launch (GEMM shapes + ms) to this path')
     ap.add_argument('--no-prof', action='store_true', help='disable the in-library HIP-event timing of kernel families')
     a = ap.parse_args()
 
@@ -159,6 +160,9 @@ def main():
     dt = time.perf_counter() - t0
     fam, launched_flops = ({}, 0.0)
     if not a.no_prof:
+        if a.dump_launches:
+            H._dump_path = a.dump_launches.encode()
+            H.check(H.lib.evk_prof_dump_to(H._dump_path))
         fam, launched_flops = H.prof_collect()
         H.prof_enable(False)
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)

@@ -53,6 +53,7 @@ void evk_set_error(const char* fmt, ...);
 void evk_prof_begin(int family, hipStream_t s);
 void evk_prof_end(int family, hipStream_t s, double flops);
 int evk_check_launch(const char* what);
+void evk_prof_tag(int a, int b, int c, int d, int e, int f);   // attaches a shape tag to the next profiled launch
 
 struct ProfScope {
   int fam; hipStream_t s; double flops;

@@ -401,6 +401,108 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(const GemmP p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// latency-optimised kernel for small problems (the relational-memory recurrence, decode steps):
+// C[M][N] = act(alpha*A[M][K].B[N][K]^T + bias) + resid with A_PLAIN / B_PLAIN, K % 256 == 0.
+// Tile 128(M) x 32(N) per block so a 96 x 512 problem spreads over 16 CUs, and K is consumed in 256-deep chunks with
+// ALL loads of a chunk in flight at once (80 KB of LDS per chunk): a K = 512 product pays 2 global-load latencies
+// instead of the 8 of the throughput kernel's 64-deep pipeline.
+// ------------------------------------------------------------------------------------------------
+constexpr int SK_KC = 256, SK_TM = 128, SK_TN = 32;
+__device__ __forceinline__ int sk_off(int row, int chunk) { return row * (SK_KC * 2) + ((chunk ^ (row & 15)) << 4); }
+
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* As = smem;                               // [128][256] bf16, 512-byte rows, chunk index XOR (row & 15)
+  char* Bs = smem + SK_TM * SK_KC * 2;           // [32][256]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int frow = lane & 15, fq = lane >> 4;
+  const int m0 = blockIdx.y * SK_TM, n0 = blockIdx.x * SK_TN;
+  // staging: A chunk = 128 rows x 32 chunks(16B) = 4096 -> 16 per thread; B chunk = 32 x 32 = 1024 -> 4 per thread
+  uint4 ra[16], rb[4];
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = tid + 256 * i, row = c >> 5, ch = c & 31;
+      const int m = m0 + row;
+      ra[i] = m < p.M ? *reinterpret_cast<const uint4*>(p.A + (long)m * p.lda + k0 + ch * 8) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i, row = c >> 5, ch = c & 31;
+      const int n = n0 + row;
+      rb[i] = n < p.N ? *reinterpret_cast<const uint4*>(p.B + (long)n * p.ldb + k0 + ch * 8) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int c = tid + 256 * i; *reinterpret_cast<uint4*>(As + sk_off(c >> 5, c & 31)) = ra[i]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int c = tid + 256 * i; *reinterpret_cast<uint4*>(Bs + sk_off(c >> 5, c & 31)) = rb[i]; }
+  };
+  f32x4 acc[2][2];     // [n tile][m tile]; wave owns rows wave*32 .. +32
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  load(0);
+  for (int k0 = 0; k0 < p.K; k0 += SK_KC) {
+    store();
+    __syncthreads();
+    if (k0 + SK_KC < p.K) load(k0 + SK_KC);
+#pragma unroll
+    for (int ks = 0; ks < SK_KC / 32; ++ks) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        af[i] = *reinterpret_cast<const bf16x8*>(As + sk_off(wave * 32 + i * 16 + frow, ks * 4 + fq));
+        bfr[i] = *reinterpret_cast<const bf16x8*>(Bs + sk_off(i * 16 + frow, ks * 4 + fq));
+      }
+#pragma unroll
+      for (int in = 0; in < 2; ++in)
+#pragma unroll
+        for (int im = 0; im < 2; ++im)
+          acc[in][im] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[in], af[im], acc[in][im], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int im = 0; im < 2; ++im) {
+    const int m = m0 + wave * 32 + im * 16 + frow;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int in = 0; in < 2; ++in) {
+      const int nn = n0 + in * 16 + fq * 4;
+      if (nn >= p.N) continue;
+      float v[4] = {acc[in][im][0] * p.alpha, acc[in][im][1] * p.alpha, acc[in][im][2] * p.alpha, acc[in][im][3] * p.alpha};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (nn + j < p.N) {
+          if (p.bias) v[j] += p.bias[nn + j];
+          v[j] = act_apply(v[j], p.act);
+          if (p.resid) v[j] += p.r_f32 ? reinterpret_cast<const float*>(p.resid)[(long)m * p.ldr + nn + j]
+                                       : bf2f(reinterpret_cast<const bf16_t*>(p.resid)[(long)m * p.ldr + nn + j]);
+          if (p.c_f32) reinterpret_cast<float*>(p.C)[(long)m * p.ldc + nn + j] = v[j];
+          else reinterpret_cast<bf16_t*>(p.C)[(long)m * p.ldc + nn + j] = f2bf(v[j]);
+        }
+      }
+    }
+  }
+}
+
+int launch_skinny(const GemmP& p, hipStream_t s) {
+  constexpr int LDS = (SK_TM + SK_TN) * SK_KC * 2;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_done = true;
+  }
+  dim3 grid((unsigned)cdiv(p.N, SK_TN), (unsigned)cdiv(p.M, SK_TM), 1);
+  hipLaunchKernelGGL(gemm_skinny_kernel, grid, dim3(NTHR), LDS, s, p);
+  return evk_check_launch("gemm_skinny_kernel");
+}
+
 // C[z][m][n] += sum_split slab[z][split][m][n].  Block = 16 float4 columns x 16 split lanes.
 struct SkrP { const float* slab; float* C; long mn; int M, N, splitk, bi; long ldc, sCo, sCi; };
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const SkrP p) {
@@ -559,8 +661,12 @@ extern "C" int evk_gemm_launch(const evk_gemm* d, evk_stream_t stream) {
 
   const int batch = d->batch_outer * d->batch_inner;
   const double flops = 2.0 * d->M * (double)d->N * d->K * batch;
+  evk_prof_tag(d->M, d->N, d->K, batch, d->a_mode, d->b_mode);
   ProfScope ps(EVK_FAM_GEMM, s, flops);
   const int am = d->a_mode, bm = d->b_mode;
+  if (am == EVK_A_PLAIN && bm == EVK_B_PLAIN && batch == 1 && !p.accumulate && d->K % SK_KC == 0 &&
+      cdiv(d->M, 128) * cdiv(d->N, 128) < 48 && d->M <= 1024)
+    return launch_skinny(p, s);
   if (am == EVK_A_PLAIN && bm == EVK_B_PLAIN) return launch_modes<EVK_A_PLAIN, EVK_B_PLAIN>(p, batch, d->splitk, d->workspace, d->workspace_bytes, d, s);
   if (am == EVK_A_CONV && bm == EVK_B_PLAIN) return launch_modes<EVK_A_CONV, EVK_B_PLAIN>(p, batch, d->splitk, d->workspace, d->workspace_bytes, d, s);
   if (am == EVK_A_PLAIN && bm == EVK_B_KSTR) return launch_modes<EVK_A_PLAIN, EVK_B_KSTR>(p, batch, d->splitk, d->workspace, d->workspace_bytes, d, s);

@@ -314,14 +314,16 @@ int evk_rm_forward(const void* xk, const void* xv, const void* gw, const void* m
 }
 
 /* Backward through the recurrence (BPTT) with the workspace evk_rm_forward filled.
+ *   Wqkvt [512][1536], Wot, W0t, W2t [512][512], Ut [512][1024]: the TRANSPOSED bf16 weights (so every data-gradient
+ *   product is the K-contiguous form the latency-optimised small-GEMM kernel takes)
  *   dout (B, L, 1536) bf16 -> dxk, dxv (B, L, 512), dgw (B, L, 1024) bf16 (written), and the f32 gradients of
  *   Wqkv [1536][512], bqkv[1536], Wo, bo, W0, b0, W2, b2, U [1024][512], bU[1024] are ACCUMULATED (+=).           */
-int evk_rm_backward(const void* dout, const void* xk, const void* xv, const void* Wqkv, const void* Wo, const void* W0, const void* W2,
-                    const void* U, void* dxk, void* dxv, void* dgw, float* dWqkv, float* dbqkv, float* dWo, float* dbo, float* dW0,
+int evk_rm_backward(const void* dout, const void* xk, const void* xv, const void* Wqkvt, const void* Wot, const void* W0t, const void* W2t,
+                    const void* Ut, void* dxk, void* dxv, void* dgw, float* dWqkv, float* dbqkv, float* dWo, float* dbo, float* dW0,
                     float* db0, float* dW2, float* db2, float* dU, float* dbU, void* ws, int64_t ws_bytes, int32_t B, int32_t L,
                     float p_drop, uint64_t seed, evk_stream_t stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  EVK_REQUIRE(dout && xk && xv && Wqkv && Wo && W0 && W2 && U && dxk && dxv && dgw && dWqkv && dbqkv && dWo && dbo && dW0 && db0 && dW2 &&
+  EVK_REQUIRE(dout && xk && xv && Wqkvt && Wot && W0t && W2t && Ut && dxk && dxv && dgw && dWqkv && dbqkv && dWo && dbo && dW0 && db0 && dW2 &&
               db2 && dU && dbU && ws && B > 0 && L > 0, "rm_backward: null/empty argument");
   EVK_REQUIRE(ws_bytes >= evk_rm_ws_bytes(B, L), "rm_backward: workspace too small");
   Ws w = carve(ws, B, L);
@@ -337,7 +339,7 @@ int evk_rm_backward(const void* dout, const void* xk, const void* xv, const void
       hipLaunchKernelGGL(rm_gate_bwd2_kernel, dim3(ew_blocks((long)B * D_)), dim3(256), 0, s, gb);
     }
     // dtm = dgates . U
-    if (int e = gemm(dgs, U, w.t_dtm, (int)R, D_, 2 * D_, EVK_B_KSTR, D_, nullptr, nullptr, EVK_ACT_NONE, stream)) return e;
+    if (int e = gemm(dgs, Ut, w.t_dtm, (int)R, D_, 2 * D_, EVK_B_PLAIN, 2 * D_, nullptr, nullptr, EVK_ACT_NONE, stream)) return e;
     // dh2 = dnm2 * (h2 > 0);  t1 = dh2 . W2;  dh1 = t1 * (h1 > 0);  dnm1 = dh1 . W0 + dnm2
     bf16_t* dh2 = w.dh2s + t * RD;
     bf16_t* dh1 = w.dh1s + t * RD;
@@ -345,14 +347,14 @@ int evk_rm_backward(const void* dout, const void* xk, const void* xv, const void
       ProfScope ps(EVK_FAM_ELTWISE, s);
       hipLaunchKernelGGL(relu_mask_kernel, dim3(ew_blocks(RD)), dim3(256), 0, s, w.t_dnm1, w.h2 + t * RD, dh2, RD);
     }
-    if (int e = gemm(dh2, W2, w.t_t1, (int)R, D_, D_, EVK_B_KSTR, D_, nullptr, nullptr, EVK_ACT_NONE, stream)) return e;
+    if (int e = gemm(dh2, W2t, w.t_t1, (int)R, D_, D_, EVK_B_PLAIN, D_, nullptr, nullptr, EVK_ACT_NONE, stream)) return e;
     {
       ProfScope ps(EVK_FAM_ELTWISE, s);
       hipLaunchKernelGGL(relu_mask_kernel, dim3(ew_blocks(RD)), dim3(256), 0, s, w.t_t1, w.h1 + t * RD, dh1, RD);
     }
-    if (int e = gemm(dh1, W0, dnm2, (int)R, D_, D_, EVK_B_KSTR, D_, nullptr, w.t_dnm1, EVK_ACT_NONE, stream)) return e;   // dnm2 now holds dnm1
+    if (int e = gemm(dh1, W0t, dnm2, (int)R, D_, D_, EVK_B_PLAIN, D_, nullptr, w.t_dnm1, EVK_ACT_NONE, stream)) return e;   // dnm2 now holds dnm1
     // da = dnm1 . Wo ; attention backward
-    if (int e = gemm(dnm2, Wo, w.t_da, (int)R, D_, D_, EVK_B_KSTR, D_, nullptr, nullptr, EVK_ACT_NONE, stream)) return e;
+    if (int e = gemm(dnm2, Wot, w.t_da, (int)R, D_, D_, EVK_B_PLAIN, D_, nullptr, nullptr, EVK_ACT_NONE, stream)) return e;
     bf16_t* dqkv = w.dqkv + (long)t * R * 1536;
     AttP ap{w.qkv + (long)t * R * 1536, (const bf16_t*)xk + (long)t * D_, (const bf16_t*)xv + (long)t * D_, (long)L * D_,
             w.P + (long)t * B * HEADS * S_ * KEYS, nullptr, p_drop, (unsigned long long)(seed + 0x51ED27ULL * (uint64_t)(t + 1)), w.t_da, dqkv,
@@ -362,7 +364,7 @@ int evk_rm_backward(const void* dout, const void* xk, const void* xv, const void
       hipLaunchKernelGGL(rm_attn_bwd_kernel, dim3(B), dim3(256), 0, s, ap);
     }
     // dm(from projections) = dqkv . Wqkv + dnm1
-    if (int e = gemm(dqkv, Wqkv, w.t_dmp, (int)R, D_, 1536, EVK_B_KSTR, D_, nullptr, dnm2, EVK_ACT_NONE, stream)) return e;
+    if (int e = gemm(dqkv, Wqkvt, w.t_dmp, (int)R, D_, 1536, EVK_B_PLAIN, 1536, nullptr, dnm2, EVK_ACT_NONE, stream)) return e;
     bf16_t* nc = (t & 1) ? w.t_carry1 : w.t_carry0;
     {
       ProfScope ps(EVK_FAM_ELTWISE, s);

@@ -22,7 +22,9 @@ int evk_check_launch(const char* what) {
   return EVK_OK;
 }
 
-struct ProfRec { int fam; hipEvent_t a, b; double flops; };
+struct ProfRec { int fam; hipEvent_t a, b; double flops; int tag[6]; };
+static thread_local int g_tag[6] = {0, 0, 0, 0, 0, 0};
+void evk_prof_tag(int a, int b, int c, int d, int e, int f) { g_tag[0] = a; g_tag[1] = b; g_tag[2] = c; g_tag[3] = d; g_tag[4] = e; g_tag[5] = f; }
 static std::mutex g_mu;
 static bool g_prof = false;
 static std::vector<ProfRec> g_recs;
@@ -49,7 +51,8 @@ void evk_prof_end(int family, hipStream_t s, double flops) {
   hipEvent_t b = get_event();
   if (!b) return;
   (void)hipEventRecord(b, s);
-  g_recs.push_back({family, g_open, b, flops});
+  g_recs.push_back({family, g_open, b, flops, {g_tag[0], g_tag[1], g_tag[2], g_tag[3], g_tag[4], g_tag[5]}});
+  for (int i = 0; i < 6; ++i) g_tag[i] = 0;
   g_open = nullptr;
 }
 
@@ -64,8 +67,13 @@ int evk_prof_enable(int on) {
   return EVK_OK;
 }
 
+static const char* g_dump_path = nullptr;
+int evk_prof_dump_to(const char* path) { g_dump_path = path; return EVK_OK; }
+
 int evk_prof_collect(double* ms, int64_t* launches, double* flops_gemm) {
   std::lock_guard<std::mutex> lk(g_mu);
+  FILE* df = g_dump_path ? fopen(g_dump_path, "w") : nullptr;
+  if (df) fprintf(df, "family,ms,flops,M,N,K,batch,a_mode,b_mode\n");
   for (int i = 0; i < EVK_FAM_COUNT; ++i) { ms[i] = 0.0; launches[i] = 0; }
   double fl = 0.0;
   for (auto& r : g_recs) {
@@ -74,11 +82,13 @@ int evk_prof_collect(double* ms, int64_t* launches, double* flops_gemm) {
       ms[r.fam] += t;
       launches[r.fam] += 1;
       if (r.fam == EVK_FAM_GEMM) fl += r.flops;
+      if (df) fprintf(df, "%d,%.6f,%.0f,%d,%d,%d,%d,%d,%d\n", r.fam, t, r.flops, r.tag[0], r.tag[1], r.tag[2], r.tag[3], r.tag[4], r.tag[5]);
     }
     g_pool.push_back(r.a);
     g_pool.push_back(r.b);
   }
   g_recs.clear();
+  if (df) fclose(df);
   if (flops_gemm) *flops_gemm = fl;
   return EVK_OK;
 }

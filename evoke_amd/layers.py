@@ -511,8 +511,11 @@ class _RMRecurrence(torch.autograd.Function):
         dWqkv = torch.zeros(3 * d, d, dtype=F32, device=dev)
         dbqkv = torch.zeros(3 * d, dtype=F32, device=dev)
         gb = ops.grad_buffer
-        H.check(H.lib.evk_rm_backward(H.ptr(dout), H.ptr(xk), H.ptr(xv), H.ptr(wqkv), H.ptr(ops.shadow(lin[3].weight)),
-                                      H.ptr(ops.shadow(rm.mlp[0].weight)), H.ptr(ops.shadow(rm.mlp[2].weight)), H.ptr(ops.shadow(rm.U.weight)),
+        tr = lambda w_, o, i: w_.view(o, i).t().contiguous()          # transposed bf16 weights for the data-gradient GEMMs
+        wqkv_t, wo_t = tr(wqkv, 3 * d, d), tr(ops.shadow(lin[3].weight), d, d)
+        w0_t, w2_t = tr(ops.shadow(rm.mlp[0].weight), d, d), tr(ops.shadow(rm.mlp[2].weight), d, d)
+        u_t = tr(ops.shadow(rm.U.weight), 2 * d, d)
+        H.check(H.lib.evk_rm_backward(H.ptr(dout), H.ptr(xk), H.ptr(xv), H.ptr(wqkv_t), H.ptr(wo_t), H.ptr(w0_t), H.ptr(w2_t), H.ptr(u_t),
                                       H.ptr(dxk), H.ptr(dxv), H.ptr(dgw), H.ptr(dWqkv), H.ptr(dbqkv), H.ptr(gb(lin[3].weight)),
                                       H.ptr(gb(lin[3].bias)), H.ptr(gb(rm.mlp[0].weight)), H.ptr(gb(rm.mlp[0].bias)),
                                       H.ptr(gb(rm.mlp[2].weight)), H.ptr(gb(rm.mlp[2].bias)), H.ptr(gb(rm.U.weight)), H.ptr(gb(rm.U.bias)),

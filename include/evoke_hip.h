@@ -76,6 +76,7 @@ enum evk_family { EVK_FAM_GEMM = 0, EVK_FAM_NORM = 1, EVK_FAM_ELTWISE = 2, EVK_F
                   EVK_FAM_COUNT = 5 };
 int evk_prof_enable(int on);                     /* records a hipEvent pair around every launch when on  */
 int evk_prof_collect(double* ms_per_family, int64_t* launches_per_family, double* flops_gemm); /* syncs+resets */
+int evk_prof_dump_to(const char* path);          /* next evk_prof_collect also writes one CSV row per launch (shape-tagged GEMMs) */
 
 /* ---- GEMM / implicit-GEMM family (MFMA) -------------------------------------------------------------
  * replaces: nn.Linear / torch.matmul (encoder_decoder.py:20-28,192-214; bert_model.py:262-341;
@@ -193,9 +194,9 @@ int evk_rm_forward(const void* xk, const void* xv, const void* gw, const void* m
                    const float* bo, const void* W0, const float* b0, const void* W2, const float* b2, const void* U, const float* bU,
                    void* out, void* m_last, void* ws, int64_t ws_bytes, int32_t B, int32_t L, float p_drop, uint64_t seed,
                    evk_stream_t stream);
-/* dxk, dxv, dgw are written; the f32 parameter gradients are accumulated (+=) */
-int evk_rm_backward(const void* dout, const void* xk, const void* xv, const void* Wqkv, const void* Wo, const void* W0, const void* W2,
-                    const void* U, void* dxk, void* dxv, void* dgw, float* dWqkv, float* dbqkv, float* dWo, float* dbo, float* dW0,
+/* dxk, dxv, dgw are written; the f32 parameter gradients are accumulated (+=); W*t = transposed bf16 weights */
+int evk_rm_backward(const void* dout, const void* xk, const void* xv, const void* Wqkvt, const void* Wot, const void* W0t, const void* W2t,
+                    const void* Ut, void* dxk, void* dxv, void* dgw, float* dWqkv, float* dbqkv, float* dWo, float* dbo, float* dW0,
                     float* db0, float* dW2, float* db2, float* dU, float* dbU, void* ws, int64_t ws_bytes, int32_t B, int32_t L,
                     float p_drop, uint64_t seed, evk_stream_t stream);
 
