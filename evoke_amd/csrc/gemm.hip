@@ -13,6 +13,7 @@
 // other LDS buffer after them (one barrier per K-tile).
 // MFMA orientation is swapped (weights tile as the "A" operand) so each lane ends up with 4 consecutive
 // n of one row m -> 8/16-byte epilogue stores.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -224,7 +225,7 @@ template <int ROWS> struct LoaderSel<ROWS, EVK_B_PLAIN, false> { using T = RowLo
 template <int ROWS> struct LoaderSel<ROWS, EVK_B_KSTR, false> { using T = KstrLoader<ROWS, 0>; static constexpr bool KS = true; };
 template <int ROWS> struct LoaderSel<ROWS, EVK_B_WGATHER, false> { using T = KstrLoader<ROWS, 1>; static constexpr bool KS = true; };
 
-template <int WM, int WN, int AMODE, int BMODE>
+template <int WM, int WN, int AMODE, int BMODE, bool SB>
 __global__ __launch_bounds__(NTHR) void gemm_kernel(const GemmP p) {
   constexpr int TM = 64 * WM, TN = 64 * WN;
   constexpr int TILE_BYTES = (TM + TN) * BK * 2;
@@ -271,21 +272,7 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(const GemmP p) {
   const int wm = wave / WN, wn = wave - wm * WN;
   const int frow = lane & 15, fq = lane >> 4;
 
-  la.load(p, k_begin, k_end, tid, ra);
-  lb.load(p, k_begin, k_end, tid, rb);
-  la.store(smem, tid, ra);
-  lb.store(smem + TM * 128, tid, rb);
-  __syncthreads();
-
-  int buf = 0;
-  for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-    const bool more = (k0 + BK) < k_end;
-    if (more) {
-      la.load(p, k0 + BK, k_end, tid, ra);
-      lb.load(p, k0 + BK, k_end, tid, rb);
-    }
-    const char* As = smem + buf * TILE_BYTES;
-    const char* Bs = As + TM * 128;
+  auto compute = [&](const char* As, const char* Bs) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 af[4], bfr[4];
@@ -311,13 +298,45 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(const GemmP p) {
         for (int im = 0; im < 4; ++im)
           acc[in][im] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[in], af[im], acc[in][im], 0, 0, 0);
     }
-    if (more) {
-      char* nxt = smem + (buf ^ 1) * TILE_BYTES;
-      la.store(nxt, tid, ra);
-      lb.store(nxt + TM * 128, tid, rb);
+  };
+
+  la.load(p, k_begin, k_end, tid, ra);
+  lb.load(p, k_begin, k_end, tid, rb);
+  if constexpr (SB) {
+    // single LDS buffer (32-40 KB/block -> 4 blocks per CU): the next tile's global loads are in flight in registers
+    // while this tile is multiplied; two barriers per K-step
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+      __syncthreads();
+      la.store(smem, tid, ra);
+      lb.store(smem + TM * 128, tid, rb);
+      __syncthreads();
+      if (k0 + BK < k_end) {
+        la.load(p, k0 + BK, k_end, tid, ra);
+        lb.load(p, k0 + BK, k_end, tid, rb);
+      }
+      compute(smem, smem + TM * 128);
     }
+  } else {
+    la.store(smem, tid, ra);
+    lb.store(smem + TM * 128, tid, rb);
     __syncthreads();
-    buf ^= 1;
+    int buf = 0;
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+      const bool more = (k0 + BK) < k_end;
+      if (more) {
+        la.load(p, k0 + BK, k_end, tid, ra);
+        lb.load(p, k0 + BK, k_end, tid, rb);
+      }
+      const char* As = smem + buf * TILE_BYTES;
+      compute(As, As + TM * 128);
+      if (more) {
+        char* nxt = smem + (buf ^ 1) * TILE_BYTES;
+        la.store(nxt, tid, ra);
+        lb.store(nxt + TM * 128, tid, rb);
+      }
+      __syncthreads();
+      buf ^= 1;
+    }
   }
 
   // ---- epilogue: lane holds C[m][n0..n0+3], m = ..+(lane&15), n0 = ..+(lane>>4)*4 -------------------
@@ -538,17 +557,34 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const SkrP p) {
 
 constexpr long SLAB_MAX_BYTES = 192L << 20;
 
-template <int WM, int WN, int AMODE, int BMODE>
-int launch_cfg(const GemmP& p, dim3 grid, hipStream_t s) {
-  constexpr int LDS = 2 * (64 * WM + 64 * WN) * BK * 2;
+// LDS staging per operand mode (measured on MI355X, FineTune 384^2 bs 32, profiles/r01_*): a single 32-40 KB buffer
+// (4 blocks/CU, two barriers per K-step) wins for the K-contiguous A loaders (fwd GEMMs +10 %, conv fwd +23 %, dX +15 %);
+// the double buffer (2 blocks/CU, one barrier) wins for the gather-from-dY and K-strided A loaders (dgrad, wgrad: 5-10 %).
+// EVK_GEMM_SB=0/1 forces one of them for experiments.
+inline int single_buf_override() {
+  static int v = -2;
+  if (v == -2) { const char* e = getenv("EVK_GEMM_SB"); v = !e ? -1 : (e[0] == '0' ? 0 : 1); }
+  return v;
+}
+
+template <int WM, int WN, int AMODE, int BMODE, bool SB>
+int launch_cfg_sb(const GemmP& p, dim3 grid, hipStream_t s) {
+  constexpr int LDS = (SB ? 1 : 2) * (64 * WM + 64 * WN) * BK * 2;
   static bool attr_done = false;
-  auto kern = gemm_kernel<WM, WN, AMODE, BMODE>;
+  auto kern = gemm_kernel<WM, WN, AMODE, BMODE, SB>;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_done = true;
   }
   hipLaunchKernelGGL(kern, grid, dim3(NTHR), LDS, s, p);
   return evk_check_launch("gemm_kernel");
+}
+
+template <int WM, int WN, int AMODE, int BMODE>
+int launch_cfg(const GemmP& p, dim3 grid, hipStream_t s) {
+  const int ov = single_buf_override();
+  const bool sb = ov >= 0 ? ov == 1 : (AMODE == EVK_A_PLAIN || AMODE == EVK_A_CONV);
+  return sb ? launch_cfg_sb<WM, WN, AMODE, BMODE, true>(p, grid, s) : launch_cfg_sb<WM, WN, AMODE, BMODE, false>(p, grid, s);
 }
 
 // split-K choice shared by the launcher and evk_gemm_workspace_bytes
