@@ -160,6 +160,8 @@ class GradReducer:
 
     def finish(self):
         """Call after backward(): reduces what was not launched from the backward, waits for everything."""
+        if self.flat and self.flat[0].is_cuda:
+            ops.join_side_streams()
         for b in range(len(self.buckets)):
             self._launch(b)
         for h in self.handles:

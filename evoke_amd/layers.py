@@ -614,8 +614,30 @@ class EncoderDecoder(nn.Module):
         src_mask = None if all_on else key_mask(am)
         return self.model.encoder(feats, src_mask), src_mask
 
-    def forward_logits(self, input_ids, enc_states, attention_mask, enc_mask):
+    def start_memory(self, input_ids):
+        """Token embedding + relational-memory recurrence on a side stream (they depend on the report tokens only, not on
+        the images): ~1.7k tiny kernels that would otherwise serialise behind / in front of the ResNet."""
+        if not (ops.SIDE_STREAMS_ENABLED[0] and input_ids.is_cuda):
+            emb = self.model.embed(input_ids)
+            return emb, self.model.rm(emb), None
+        main = torch.cuda.current_stream()
+        side = ops.side_stream('rm')
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            emb = self.model.embed(input_ids)
+            memory = self.model.rm(emb)
+        return emb, memory, side
+
+    def forward_logits(self, input_ids, enc_states, attention_mask, enc_mask, pending=None):
         """-> f32 logits (B, L, pad8(V+1)); the log_softmax is fused into the loss / the decode step."""
+        if pending is None:
+            pending = self.start_memory(input_ids)
+        emb, memory, side = pending
         enc, src_mask = self.encode(enc_states, enc_mask)
-        out = self.model.decode(enc, src_mask, input_ids, key_mask(attention_mask))
+        if side is not None:
+            main = torch.cuda.current_stream()
+            main.wait_stream(side)
+            emb.record_stream(main)
+            memory.record_stream(main)
+        out = self.model.decoder(emb, enc, src_mask, key_mask(attention_mask), memory)
         return self.logit(out, out_f32=True)

@@ -30,6 +30,18 @@ class _Base(nn.Module):
         att_feats, fc_feats = self.visual_extractor(images)
         return fc_feats, att_feats
 
+    @staticmethod
+    def _side_branch(name, fn):
+        """Run fn() on a side HIP stream (after everything queued so far); returns (result, stream or None)."""
+        if not ops.SIDE_STREAMS_ENABLED[0]:
+            return fn(), None
+        main = torch.cuda.current_stream()
+        side = ops.side_stream(name)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            out = fn()
+        return out, side
+
     def _image_tokens(self, images, patient_ids, batch_size):
         """visual_forward + (multiview_fusion | plain LN1) + visual_head -> (fc (N,D) bf16, tokens (B,T,D) bf16)."""
         fc, att = self.visual_forward(images)
@@ -81,11 +93,17 @@ class FineTune(_Base):
     def encoder_states(self, images, patient_ids, batch_size, inc_ids=None, inc_masks=None):
         """lines 152-203: image tokens -> (indication cross-fusion | visual self-attention) -> (B,T,D) bf16."""
         device = images.device
+        y = side = None
+        if inc_ids is not None:
+            # the indication branch depends on the text only: run it on a side stream under the ResNet
+            inc_ids, inc_masks = inc_ids.to(device, non_blocking=True), inc_masks.to(device, non_blocking=True)
+            y, side = self._side_branch('text', lambda: self.text_head(self.text_encoder(input_ids=inc_ids, attention_mask=inc_masks)))
         _, x = self._image_tokens(images, patient_ids, batch_size)
         enc_mask = torch.ones(x.shape[:2], dtype=torch.long, device=device)
         if inc_ids is not None:
-            inc_ids, inc_masks = inc_ids.to(device, non_blocking=True), inc_masks.to(device, non_blocking=True)
-            y = self.text_head(self.text_encoder(input_ids=inc_ids, attention_mask=inc_masks))
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
+                y.record_stream(torch.cuda.current_stream())
             ym = key_mask(inc_masks)
             for layer in self.multimodal_fusion_layers:
                 x = layer(x, y, None, ym)
@@ -94,9 +112,10 @@ class FineTune(_Base):
                 x = layer(x, None, None, None)
         return x, enc_mask
 
-    def text_decoder_forward_r2gen(self, input_ids, attention_mask, encoder_hidden_states, encoder_attention_mask, mode='train'):
+    def text_decoder_forward_r2gen(self, input_ids, attention_mask, encoder_hidden_states, encoder_attention_mask, mode='train',
+                                   pending=None):
         if mode == 'train':
-            logits = self.text_decoder.forward_logits(input_ids, encoder_hidden_states, attention_mask, encoder_attention_mask)
+            logits = self.text_decoder.forward_logits(input_ids, encoder_hidden_states, attention_mask, encoder_attention_mask, pending)
             return losses.lm_loss(logits, input_ids, attention_mask, self.text_decoder.vocab_size + 1)
         from .decode import beam_search
         output = beam_search(self.text_decoder, encoder_hidden_states, encoder_attention_mask, self.args)
@@ -111,8 +130,12 @@ class FineTune(_Base):
     def forward(self, images, report_ids, report_masks, patient_ids, inc_ids=None, inc_masks=None, mode='train'):
         if mode not in ('train', 'sample', 'inference'):
             raise ValueError
+        report_ids, report_masks = report_ids.to(images.device), report_masks.to(images.device)
+        kw = {}
+        if mode == 'train' and self.text_decoder_forward == self.text_decoder_forward_r2gen:
+            kw['pending'] = self.text_decoder.start_memory(report_ids)       # overlaps with the image path
         x, enc_mask = self.encoder_states(images, patient_ids, report_ids.shape[0], inc_ids, inc_masks)
-        ret = self.text_decoder_forward(report_ids.to(images.device), report_masks.to(images.device), x, enc_mask, mode=mode)
+        ret = self.text_decoder_forward(report_ids, report_masks, x, enc_mask, mode=mode, **kw)
         if mode == 'train':
             return {'lm': ret, 'all_loss': ret}
         return [ret[0], ret[1]]
@@ -151,12 +174,17 @@ class Pretrain(_Base):
     def forward(self, images, radgraph_ids, radgraph_masks, patient_ids):
         device = images.device
         b = radgraph_ids.shape[0]
+        rid, rmask = radgraph_ids.to(device), radgraph_masks.to(device)
+        (t_fc, t_att), side = self._side_branch('text', lambda: self.obtain_text_embeds(rid, rmask))
         fc, tok = self._image_tokens(images, patient_ids, b)
         mul_pos_loss = torch.tensor([0.0])
         if self.args['is_multiview_learning']:
             mul_pos_loss = self.multi_pos_contra_images_v0401(fc, patient_ids)
         v_fc, v_att = tok[:, 0, :], tok[:, 1:, :]
-        t_fc, t_att = self.obtain_text_embeds(radgraph_ids.to(device), radgraph_masks.to(device))
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+            t_fc.record_stream(torch.cuda.current_stream())
+            t_att.record_stream(torch.cuda.current_stream())
         instance_loss = self.global_alignment_loss(v_fc, t_fc, patient_ids)
         sen_text_loss = self.local_text_token_alignment_loss(v_att, t_att)
         all_loss = instance_loss + sen_text_loss

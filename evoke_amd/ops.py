@@ -70,6 +70,32 @@ def grad_done(p):
         fn(p)
 
 
+# ----------------------------------------------------------------------------------------------------
+# side streams: latency-bound branches (the relational-memory recurrence, the indication text encoder) run on their
+# own HIP stream concurrently with the fat ResNet kernels; autograd replays each op's backward on its forward stream.
+# ----------------------------------------------------------------------------------------------------
+_side_streams = {}
+SIDE_STREAMS_ENABLED = [True]
+
+
+def side_stream(name, device=None):
+    dev = torch.cuda.current_device() if device is None else device
+    key = (name, dev)
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
+def join_side_streams():
+    """Make the current stream wait for everything queued on the side streams (called before the optimizer /
+    gradient all-reduce, because parameter gradients are accumulated in place from those streams)."""
+    cur = torch.cuda.current_stream()
+    for (name, dev), st in _side_streams.items():
+        if dev == cur.device.index:
+            cur.wait_stream(st)
+
+
 def _z(*shape, dtype=BF16, device='cuda'):
     return torch.zeros(*shape, dtype=dtype, device=device)
 

@@ -99,6 +99,8 @@ class FusedOptimizer(torch.optim.Optimizer):
         step-count increment) -- e.g. the BERT pooler always, visual_self_atten_layers on indication batches.  Runs of
         consecutive updated parameters with the same step count share one fused launch."""
         self.steps += 1
+        if self.flat and self.flat[0]['p'].is_cuda:
+            ops.join_side_streams()
         for g, st in zip(self.param_groups, self.flat):
             b1, b2 = g['betas']
             ps, offs = g['params'], st['offsets']
