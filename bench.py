@@ -98,12 +98,61 @@ def cpu_baseline(model, kind, res, L, Li, seconds_budget=25.0):
                        'median of %d steps after 1 warm-up' % (kind, B, res, res, max(1, len(times) - 1)))
 
 
+def bench_decode(a, rank, world, dev):
+    """BASELINE.json configs[4]: EVOKE-384 inference, beam search (default beam 4), bs 64, max_seq_len 100, replicas only.
+    One step = the whole FineTune.forward(mode='inference') of one batch (visual extractor + fusion + beam search); every
+    hypothesis is extended for all max_seq_len steps as in the reference (finished beams keep running with -1000), so
+    tokens = batch x max_seq_len per step."""
+    from evoke_amd import hip as H, ops
+    from evoke_amd.model_pretrain_finetune import FineTune
+    from tests.helpers import load_tokenizer
+    torch.manual_seed(9233)
+    args = make_args('test')
+    args['beam_size'] = a.beam
+    B = a.batch if a.batch != 32 else 64
+    model = FineTune(args, load_tokenizer(), 'mimic_cxr').to(dev).eval()
+    b = synth_batch('finetune', B, a.views, a.res, 100, 30, dev, 1000 + rank)
+
+    def step():
+        with torch.no_grad():
+            return model(b['images'], b['ids'], b['masks'], b['pids'], b['inc'], b['inc_masks'], mode='inference')[1]
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        seq = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+    if rank != 0:
+        return
+    L = args['max_seq_len']
+    toks = B * L * a.steps * world
+    print(json.dumps({
+        'metric': 'decode tokens/sec (beam search, %d^2)' % a.res, 'value': toks / float(tt.item()), 'unit': 'tokens/s', 'n_gpus': world,
+        'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * float(tt.item()) / a.steps, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'config': {'workload': 'EVOKE-%d inference: beam=%d, batch %d studies x %d views, max_seq_len %d (all steps run, as the reference), '
+                               'incremental decoder state, visual extractor + fusion included, V=%d, random-init weights'
+                               % (a.res, a.beam, B, a.views, L, V), 'parallelism': 'replicas x%d' % world,
+                   'mean_generated_len': float((seq != 0).sum(1).float().mean().item())}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', default='finetune', choices=['finetune', 'pretrain'])
+    ap.add_argument('--workload', default='finetune', choices=['finetune', 'pretrain', 'decode'])
+    ap.add_argument('--beam', type=int, default=4)
     ap.add_argument('--res', type=int, default=384)
     ap.add_argument('--batch', type=int, default=32, help='studies per GPU')
     ap.add_argument('--views', type=int, default=2)
@@ -124,6 +173,8 @@ def main():
     from tests.helpers import load_tokenizer
     torch.manual_seed(9233)
     ops.manual_seed(9233 + rank)
+    if a.workload == 'decode':
+        return bench_decode(a, rank, world, dev)
     args = make_args(a.workload)
     kind = a.workload
     L, Li = (100, 30) if kind == 'finetune' else (40, 0)
@@ -179,7 +230,7 @@ def main():
         return
     studies = a.batch * world * a.steps
     out = {
-        'metric': 'studies/sec (train step, 2-view 384^2)', 'value': studies / dt, 'unit': 'studies/s', 'n_gpus': world,
+        'metric': 'studies/sec (train step, 2-view %d^2)' % a.res, 'value': studies / dt, 'unit': 'studies/s', 'n_gpus': world,
         'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
         'config': {'workload': 'EVOKE-%d two-view %s train step (fwd+bwd+allreduce+clip+RAdam), %d studies (%d images) per GPU, '

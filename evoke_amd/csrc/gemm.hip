@@ -587,13 +587,19 @@ int launch_cfg(const GemmP& p, dim3 grid, hipStream_t s) {
   return sb ? launch_cfg_sb<WM, WN, AMODE, BMODE, true>(p, grid, s) : launch_cfg_sb<WM, WN, AMODE, BMODE, false>(p, grid, s);
 }
 
+inline long split_target() {
+  static long v = 0;
+  if (!v) { const char* e = getenv("EVK_SPLIT_TARGET"); v = e ? atol(e) : 256; if (v < 1) v = 256; }
+  return v;
+}
+
 // split-K choice shared by the launcher and evk_gemm_workspace_bytes
 inline int choose_splitk(int M, int N, int K, int batch, int splitk_req) {
   const bool narrow = N <= 64;
   const int TM = narrow ? 256 : 128, TN = narrow ? 64 : 128;
   const long tiles = cdiv(M, TM) * cdiv(N, TN) * batch;
   const int ksteps = (int)cdiv(K, BK);
-  long splitk = splitk_req > 0 ? splitk_req : cdiv(1024, tiles);
+  long splitk = splitk_req > 0 ? splitk_req : cdiv(split_target(), tiles);
   if (splitk > 512) splitk = 512;
   const long per_split = (long)M * N * batch * 4;
   if (splitk * per_split > SLAB_MAX_BYTES) splitk = SLAB_MAX_BYTES / per_split;
