@@ -49,9 +49,9 @@ def synth_batch(kind, B, views, res, L, Li, device, seed):
     else:
         ids[:, 0] = 1                                  # [CLS]
     masks = torch.ones(B, L, dtype=torch.long)
-    inc = torch.randint(5, V - 2, (B, Li), generator=g)
+    inc = torch.randint(5, V - 2, (B, max(Li, 1)), generator=g)
     inc[:, 0] = 1
-    inc_masks = torch.ones(B, Li, dtype=torch.long)
+    inc_masks = torch.ones(B, max(Li, 1), dtype=torch.long)
     studies = list(range(B)) * views                   # anchors first, then the other views of the same studies
     pids = np.array(['p%08d_s%08d' % (seed * 1000 + s, s) for s in studies])
     return dict(images=images.to(device), ids=ids.to(device), masks=masks.to(device), inc=inc.to(device),
