@@ -33,6 +33,7 @@ __device__ __forceinline__ float act_apply(float x, int act) {
     case EVK_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
     case EVK_ACT_TANH: return tanhf(x);
     case EVK_ACT_SIGMOID: return 1.f / (1.f + __expf(-x));
+    case EVK_ACT_GELU_NEW: return 0.5f * x * (1.f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
     default: return x;
   }
 }

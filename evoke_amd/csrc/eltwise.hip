@@ -49,6 +49,10 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const bf16_t* __restrict__
       case EVK_ACT_TANH: d = 1.f - r * r; break;
       case EVK_ACT_SIGMOID: d = r * (1.f - r); break;
       case EVK_ACT_GELU: d = 0.5f * (1.f + erff(r * 0.70710678118654752f)) + r * 0.3989422804014327f * __expf(-0.5f * r * r); break;
+      case EVK_ACT_GELU_NEW: {
+        const float u = 0.7978845608028654f * (r + 0.044715f * r * r * r), th = tanhf(u);
+        d = 0.5f * (1.f + th) + 0.5f * r * (1.f - th * th) * 0.7978845608028654f * (1.f + 3.f * 0.044715f * r * r);
+      } break;
       default: d = 1.f;
     }
     dx[i] = f2bf(g * d);

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libevoke_hip.so')
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH, ACT_SIGMOID, ACT_GELU_NEW = 0, 1, 2, 3, 4, 5
 A_PLAIN, A_CONV, A_DGRAD, A_KSTR = 0, 1, 2, 3
 B_PLAIN, B_KSTR, B_WGATHER = 0, 1, 2
 FAMILIES = ('gemm', 'norm', 'eltwise', 'reduce', 'optim')

@@ -64,7 +64,14 @@ class FineTune(_Base):
         self.text_encoder = TextEncoderModel(args, tokenizer)
         self.layer_norm_1 = LayerNormP(visual_dim)
         self.layer_norm_2 = LayerNormP(visual_dim)
-        self.text_decoder = EncoderDecoder(args, tokenizer)
+        self.decoder_kind = args.get('text_decoder', 'r2gen')          # modules/utils.py:78 (commented-out switch)
+        if self.decoder_kind == 'distilgpt2':
+            from .gpt2 import DistilGPT2TextDecoderModel
+            self.text_decoder = DistilGPT2TextDecoderModel(args, tokenizer)
+        elif self.decoder_kind == 'r2gen':
+            self.text_decoder = EncoderDecoder(args, tokenizer)
+        else:
+            raise ValueError('text_decoder must be r2gen or distilgpt2')
         text_dim = self.text_encoder.encoder.hidden_size
         self.visual_head = ProjectionHead(visual_dim, args['output_dim'], args['output_dim'], final_bn=True)
         self.text_head = ProjectionHead(text_dim, args['output_dim'], args['output_dim'], final_bn=True)
@@ -78,7 +85,19 @@ class FineTune(_Base):
                     nn.init.normal_(m.weight, std=0.02)
                     nn.init.zeros_(m.bias)
         self.visual_forward = self.visual_forward_mimic_cxr
-        self.text_decoder_forward = self.text_decoder_forward_r2gen
+        self.text_decoder_forward = self.text_decoder_forward_r2gen if self.decoder_kind == 'r2gen' else self.text_decoder_forward_gpt2
+
+    def text_decoder_forward_gpt2(self, input_ids, attention_mask, encoder_hidden_states, encoder_attention_mask, mode='train'):
+        if mode == 'train':
+            return self.text_decoder(encoder_hidden_states, encoder_attention_mask, input_ids, attention_mask, stage='train')
+        output = self.text_decoder(encoder_hidden_states, encoder_attention_mask, stage='test')
+        gen_texts = self.tokenizer.decode_batch(output.cpu().tolist())
+        gt_texts = self.tokenizer.decode_batch(input_ids.cpu().tolist())
+        if mode == 'sample':
+            return [[t if len(t) > 0 else NO_FINDING for t in gen_texts], gt_texts]
+        if mode == 'test':
+            return [gen_texts, gt_texts]
+        return [[t if len(t) > 0 else NO_FINDING for t in gen_texts], output]
 
     def freeze_encoder_models(self, freeze_image_encoder: bool, freeze_text_encoder: bool):
         if freeze_image_encoder:

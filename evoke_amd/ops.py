@@ -200,6 +200,45 @@ def linear(x, W, b=None, resid=None, act=H.ACT_NONE, out_f32=False):
     return _Linear.apply(x, W, b, resid, act, out_f32)
 
 
+class _LinearT(torch.autograd.Function):
+    """HF Conv1D: y = x W + b with W stored (in, out)  (GPT-2: transformers.pytorch_utils.Conv1D)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, resid):
+        K, N = W.shape
+        M = _rows(x)
+        y = _e(M, N, device=x.device)
+        gemm(x, shadow(W), y, M, N, K, b_mode=H.B_KSTR, lda=K, ldb=N, ldc=N, bias=b, resid=resid, ldr=N)
+        ctx.save_for_backward(x)
+        ctx.W, ctx.b, ctx.dims, ctx.has_resid = W, b, (M, N, K), resid is not None
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        W, b = ctx.W, ctx.b
+        M, N, K = ctx.dims
+        dy = dy.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _e(M, K, device=dy.device)
+            gemm(dy, shadow(W), dx, M, K, N, lda=N, ldb=N, ldc=K)            # dX = dY W^T : B[n'=k][k'=n] = W[k][n]
+            dx = dx.view(x.shape)
+        if W.requires_grad:
+            gemm(x, dy, grad_buffer(W), K, N, M, a_mode=H.A_KSTR, b_mode=H.B_KSTR, lda=K, ldb=N, ldc=N, accumulate=True)
+            grad_done(W)
+        if b is not None and b.requires_grad:
+            H.check(H.lib.evk_colsum(H.ptr(dy), H.ptr(grad_buffer(b)), M, N, N, H.stream()), 'colsum')
+            grad_done(b)
+        return dx, None, None, (dy if ctx.has_resid else None)
+
+
+def linear_t(x, W, b=None, resid=None):
+    """x (.., in) @ W (in, out) + b (+ resid): the Conv1D layout of HF GPT-2 (in and out multiples of 8)."""
+    assert x.dtype == BF16 and x.is_contiguous() and W.shape[0] % 8 == 0 and W.shape[1] % 8 == 0
+    return _LinearT.apply(x, W, b, resid)
+
+
 # ----------------------------------------------------------------------------------------------------
 # activations / dropout
 # ----------------------------------------------------------------------------------------------------
@@ -209,7 +248,7 @@ class _Act(torch.autograd.Function):
         y = torch.empty_like(x)
         H.check(H.lib.evk_act_fwd(H.ptr(x), H.ptr(y), x.numel(), act, H.stream()), 'act_fwd')
         ctx.act = act
-        ctx.save_for_backward(x if act == H.ACT_GELU else y)
+        ctx.save_for_backward(x if act in (H.ACT_GELU, H.ACT_GELU_NEW) else y)
         return y
 
     @staticmethod

@@ -26,7 +26,8 @@ typedef void* evk_stream_t;
 
 enum evk_status { EVK_OK = 0, EVK_EINVAL = -1, EVK_ELAUNCH = -2, EVK_EUNSUPPORTED = -3 };
 enum evk_dtype { EVK_F32 = 0, EVK_BF16 = 1 };
-enum evk_act { EVK_ACT_NONE = 0, EVK_ACT_RELU = 1, EVK_ACT_GELU = 2, EVK_ACT_TANH = 3, EVK_ACT_SIGMOID = 4 };
+enum evk_act { EVK_ACT_NONE = 0, EVK_ACT_RELU = 1, EVK_ACT_GELU = 2, EVK_ACT_TANH = 3, EVK_ACT_SIGMOID = 4,
+               EVK_ACT_GELU_NEW = 5 /* HF "gelu_new" (tanh approximation), GPT-2 */ };
 
 /* operand addressing modes of the GEMM family (C[m][n] = sum_k A(m,k) * B(n,k)) */
 enum evk_amode {

@@ -206,6 +206,9 @@ def _range(kind, shape):
         fan_in = int(np.prod(shape[1:]))
         b = float(np.sqrt(3.0 / fan_in))
         return -b, b
+    if kind == 'c1d_w':                      # HF Conv1D (in, out)
+        b = float(np.sqrt(3.0 / shape[0]))
+        return -b, b
     if kind == 'emb':
         return -0.08, 0.08
     if kind in ('bn_w', 'bn_var', 'ln_w'):

@@ -265,6 +265,44 @@ def run_kat(tmp, tokenizer):
     return k
 
 
+def run_gpt2():
+    """distilgpt2 backend (a20): in-container HF GPT2LMHeadModel with the EVOKE YAML sizes (3 x 2048 x 8 heads), procedural
+    weights by key, encoder states from det(); stores the un-shifted CE loss, a logits tap, eval grads and beam sequences."""
+    from transformers import GPT2Config, GPT2LMHeadModel
+    from oracle import gpt2 as G
+    import torch.nn.functional as F
+    V, d, layers, heads = 1444, 2048, 3, 8
+    cfg = GPT2Config(vocab_size=V, n_embd=d, n_layer=layers, n_head=heads, add_cross_attention=True, is_decoder=True,
+                     bos_token_id=V - 2, eos_token_id=V - 1, pad_token_id=0)
+    m = GPT2LMHeadModel(cfg).eval()
+    spec = G.gpt2_spec(V, d, layers)
+    sd = {k[len(G.PRE):]: v for k, v in S.procedural_state(spec).items()}
+    sd['lm_head.weight'] = sd['transformer.wte.weight']
+    missing = m.load_state_dict(sd, strict=False)
+    assert not [k for k in missing.missing_keys if 'bias' not in k.split('.')[-1] or 'attn.bias' not in k], missing
+    inp = make_inputs(dict(kind='finetune', res=224, pids=[0, 1, 2], B=3, L=12, Li=0), V)
+    enc = S.det((3, 50, d), a=.013, b=.007, c=.3) * 0.5
+    out = {}
+    ids, am = inp['ids'], inp['masks']
+    for p in m.parameters():
+        p.requires_grad_(True)
+    lg = m(input_ids=ids, attention_mask=am, encoder_hidden_states=enc).logits
+    loss = F.cross_entropy(lg.permute(0, 2, 1), ids, ignore_index=0)
+    loss.backward()
+    out['eval/loss'] = np.float64(loss.item())
+    out['eval/tap/logits'] = reduce_tensor(lg)
+    g = dict(m.named_parameters())
+    for k in ('transformer.wte.weight', 'transformer.h.0.attn.c_attn.weight', 'transformer.h.1.crossattention.c_attn.weight',
+              'transformer.h.2.mlp.c_proj.weight', 'transformer.h.0.crossattention.q_attn.weight', 'transformer.wpe.weight'):
+        out['eval/grad/' + k] = reduce_tensor(g[k].grad)
+    with torch.no_grad():
+        for nb, ml in ((3, 16), (1, 10)):
+            seq = m.generate(input_ids=torch.full((3, 1), V - 2), encoder_hidden_states=enc, num_beams=nb, max_length=ml, use_cache=True,
+                             bos_token_id=V - 2, eos_token_id=V - 1, pad_token_id=0, do_sample=False)
+            out['eval/seq_b%d' % nb] = seq.numpy().astype(np.int64)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default='')
@@ -280,6 +318,9 @@ def main():
     if only is None or 'kat' in only:
         json.dump(run_kat(tmp, tokenizer), open(os.path.join(HERE, 'kat.json'), 'w'), indent=1)
         print('kat.json written')
+    if only is None or 'gpt2' in only:
+        np.savez_compressed(os.path.join(HERE, 'gpt2.npz'), **run_gpt2())
+        print('gpt2.npz written')
     for name, case in CASES.items():
         if only is not None and name not in only:
             continue

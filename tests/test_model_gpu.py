@@ -226,3 +226,46 @@ def test_beam_search_matches_reference(name):
         print('   oracle score of hip seq', s_h, ' of ref seq', s_r)
         for a, b in zip(s_h, s_r):
             assert a >= b - 0.05 * max(1.0, abs(b)), (a, b)
+
+
+def test_distilgpt2_backend_matches_hf_fixture():
+    """a20: the distilgpt2 cross-attention decoder backend vs the fixture produced by in-container HF GPT2LMHeadModel."""
+    from evoke_amd import ops
+    from evoke_amd.gpt2 import DistilGPT2TextDecoderModel
+    from oracle import gpt2 as G, spec as S
+    gold = _gold('gpt2')
+    d, layers, heads = 2048, 3, 8
+    args = dict(ARGS, decoder_hidden_size=d, decoder_num_hidden_layers=layers, decoder_num_attention_heads=heads, beam_size=3, max_seq_len=16)
+    dec = DistilGPT2TextDecoderModel(args, load_tokenizer())
+    sd = {k[len('text_decoder.'):]: v for k, v in S.procedural_state(G.gpt2_spec(V, d, layers)).items()}
+    sd['decoder.encoder_decoder.decoder.lm_head.weight'] = sd['decoder.encoder_decoder.decoder.transformer.wte.weight']
+    dec.load_state_dict(sd)
+    dec = dec.cuda().eval()
+    ops.set_dropout_enabled(False)
+    inp = make_inputs(dict(kind='finetune', res=224, pids=[0, 1, 2], B=3, L=12, Li=0), V)
+    enc = (S.det((3, 50, d), a=.013, b=.007, c=.3) * 0.5).to(torch.bfloat16).cuda()
+    bad = []
+    lg = dec.logits(inp['ids'].cuda(), inp['masks'].cuda(), enc)
+    loss = dec(enc, None, inp['ids'].cuda(), inp['masks'].cuda(), stage='train')
+    print('\n[gpt2] loss hip %.6f ref %.6f diff %.2e' % (loss.item(), float(gold['eval/loss']), abs(loss.item() - float(gold['eval/loss']))))
+    if abs(loss.item() - float(gold['eval/loss'])) > LOSS_TOL:
+        bad.append('loss')
+    if not _report('logits', lg[..., :V], gold['eval/tap/logits'], ACT_TOL):
+        bad.append('logits')
+    loss.backward()
+    prm = dict(dec.named_parameters())
+    for k in gold.files:
+        if k.startswith('eval/grad/'):
+            g = prm['decoder.encoder_decoder.decoder.' + k[len('eval/grad/'):]].grad
+            if g is None or not _report_grad(k[10:], g, gold[k]):
+                bad.append(k)
+    with torch.no_grad():
+        seq = dec(enc, None, stage='test').cpu()
+    want = torch.from_numpy(gold['eval/seq_b3'])
+    print('   seq hip', seq.tolist())
+    print('   seq ref', want.tolist())
+    agree = sum(int(a.tolist() == b.tolist()) for a, b in zip(seq, want)) if seq.shape == want.shape else 0
+    print('   identical sequences %d / %d' % (agree, len(want)))
+    assert seq.dtype == torch.long and seq.shape[0] == 3 and bool((seq[:, 0] == V - 2).all())
+    ops.set_dropout_enabled(True)
+    assert not bad, bad

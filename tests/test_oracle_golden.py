@@ -140,3 +140,28 @@ def test_beam_search_vs_reference(name, tokenizer):
         seq = OB.beam_search(P, x, m, cfg, bos=V - 2, eos=V - 1, pad=0)
     assert seq.tolist() == gold['eval/seq'].tolist()          # bit-exact token ids
     assert OB.decode_texts(tokenizer, seq) == gold['eval/texts'].tolist()
+
+
+def test_gpt2_backend_vs_hf():
+    """distilgpt2 decoder restatement (oracle/gpt2.py) vs the fixture produced by in-container HF GPT2LMHeadModel."""
+    from oracle import gpt2 as G
+    gold = _load('gpt2')
+    d, layers, heads = 2048, 3, 8
+    spec = G.gpt2_spec(V, d, layers)
+    P = S.procedural_state(spec)
+    for k in P:
+        P[k].requires_grad_(True)
+    inp = make_inputs(dict(kind='finetune', res=224, pids=[0, 1, 2], B=3, L=12, Li=0), V)
+    enc = S.det((3, 50, d), a=.013, b=.007, c=.3) * 0.5
+    lg = G.gpt2_logits(P, inp['ids'], inp['masks'], enc, heads, layers)
+    loss = torch.nn.functional.cross_entropy(lg.permute(0, 2, 1), inp['ids'], ignore_index=0)
+    assert abs(loss.item() - float(gold['eval/loss'])) < 2e-5
+    _check(reduce_tensor(lg), gold['eval/tap/logits'], 2e-4, 'logits')
+    loss.backward()
+    for k in gold.files:
+        if k.startswith('eval/grad/'):
+            _check(reduce_tensor(P[G.PRE + k[len('eval/grad/'):]].grad), gold[k], 5e-3, k)
+    with torch.no_grad():
+        P = S.procedural_state(spec)
+        assert G.beam_search(P, enc, heads, layers, 3, 16, V - 2, V - 1, 0).tolist() == gold['eval/seq_b3'].tolist()
+        assert G.beam_search(P, enc, heads, layers, 1, 10, V - 2, V - 1, 0).tolist() == gold['eval/seq_b1'].tolist()
