@@ -78,14 +78,19 @@ struct RowLoader {
     }
   }
 
-  __device__ __forceinline__ void load(const GemmP& p, int k0, int kend, int tid, uint4 (&v)[NI]) const {
+  // Loads are UNCONDITIONAL (invalid chunks read the operand's first bytes) and the validity mask is applied when the
+  // registers are written to LDS: a per-chunk `valid ? load : 0` makes hipcc branch around every load and drain vmcnt
+  // in the middle of the sequence (cdna_hip_programming.md section 5, trap (c)).
+  __device__ __forceinline__ unsigned load(const GemmP& p, int k0, int kend, int tid, uint4 (&v)[NI]) const {
     const int k = k0 + (tid & 7) * 8;
     const bool kin = k < kend;
+    unsigned mask = 0;
     if constexpr (MODE == EVK_A_PLAIN) {
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
-        if (ok[i] && kin) v[i] = *reinterpret_cast<const uint4*>(base + off[i] + k);
-        else v[i] = make_uint4(0, 0, 0, 0);
+        const bool valid = ok[i] && kin;
+        v[i] = *reinterpret_cast<const uint4*>(base + (valid ? off[i] + k : 0));
+        mask |= (valid ? 1u : 0u) << i;
       }
     } else {
       const int tap = k >> p.lgC;
@@ -108,17 +113,18 @@ struct RowLoader {
           valid = valid && oh < p.Ho && ow < p.Wo;
           a = off[i] + ((long)oh * p.Wo + ow) * p.Cg + c;
         }
-        if (valid) v[i] = *reinterpret_cast<const uint4*>(base + a);
-        else v[i] = make_uint4(0, 0, 0, 0);
+        v[i] = *reinterpret_cast<const uint4*>(base + (valid ? a : 0));
+        mask |= (valid ? 1u : 0u) << i;
       }
     }
+    return mask;
   }
 
-  __device__ __forceinline__ void store(char* lds, int tid, const uint4 (&v)[NI]) const {
+  __device__ __forceinline__ void store(char* lds, int tid, const uint4 (&v)[NI], unsigned mask) const {
     const int rl = tid >> 3;
     char* d = lds + rl * 128 + (((tid & 7) ^ (rl & 7)) << 4);
 #pragma unroll
-    for (int i = 0; i < NI; ++i) *reinterpret_cast<uint4*>(d + i * 4096) = v[i];
+    for (int i = 0; i < NI; ++i) *reinterpret_cast<uint4*>(d + i * 4096) = ((mask >> i) & 1u) ? v[i] : make_uint4(0, 0, 0, 0);
   }
 };
 
@@ -147,6 +153,7 @@ struct KstrLoader {
   static constexpr int ROWB = ROWS * 2;
   static constexpr int NCH = ROWS / 16;         // 32-byte chunks per k-row
   const bf16_t* ptr;
+  const bf16_t* safe;     // always-readable address for masked-off chunks
   long ld, tapstride;
   bool rok;
   int kh, kw, klog, kmask;
@@ -157,6 +164,7 @@ struct KstrLoader {
     const int r0 = row0 + (tid % CPR) * 8;
     rok = r0 < nrows;
     ptr = b + (rok ? r0 : 0);
+    safe = b;
     ld = ld_;
     kh = tap / p.KW;
     kw = tap - kh * p.KW;
@@ -167,7 +175,8 @@ struct KstrLoader {
     inv_rw = 1.f / (float)p.row_w;
   }
 
-  __device__ __forceinline__ void load(const GemmP& p, int k0, int kend, int tid, uint4 (&v)[NI]) const {
+  __device__ __forceinline__ unsigned load(const GemmP& p, int k0, int kend, int tid, uint4 (&v)[NI]) const {
+    unsigned mask = 0;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int k = k0 + tid / CPR + i * KSTEP;
@@ -187,18 +196,19 @@ struct KstrLoader {
         valid = valid && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
         a = (long)n * p.sN + (long)ih * p.sH + (long)iw * p.sW;
       }
-      if (valid) v[i] = *reinterpret_cast<const uint4*>(ptr + a);
-      else v[i] = make_uint4(0, 0, 0, 0);
+      v[i] = *reinterpret_cast<const uint4*>(valid ? ptr + a : safe);
+      mask |= (valid ? 1u : 0u) << i;
     }
+    return mask;
   }
 
-  __device__ __forceinline__ void store(char* lds, int tid, const uint4 (&v)[NI]) const {
+  __device__ __forceinline__ void store(char* lds, int tid, const uint4 (&v)[NI], unsigned mask) const {
     const int m8 = tid % CPR;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int kr = tid / CPR + i * KSTEP;
       const int ch = (m8 >> 1) ^ (kswz(kr) & (NCH - 1));
-      *reinterpret_cast<uint4*>(lds + kr * ROWB + (ch << 5) + ((m8 & 1) << 4)) = v[i];
+      *reinterpret_cast<uint4*>(lds + kr * ROWB + (ch << 5) + ((m8 & 1) << 4)) = ((mask >> i) & 1u) ? v[i] : make_uint4(0, 0, 0, 0);
     }
   }
 
@@ -300,39 +310,39 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(const GemmP p) {
     }
   };
 
-  la.load(p, k_begin, k_end, tid, ra);
-  lb.load(p, k_begin, k_end, tid, rb);
+  unsigned ma = la.load(p, k_begin, k_end, tid, ra);
+  unsigned mb = lb.load(p, k_begin, k_end, tid, rb);
   if constexpr (SB) {
     // single LDS buffer (32-40 KB/block -> 4 blocks per CU): the next tile's global loads are in flight in registers
     // while this tile is multiplied; two barriers per K-step
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
       __syncthreads();
-      la.store(smem, tid, ra);
-      lb.store(smem + TM * 128, tid, rb);
+      la.store(smem, tid, ra, ma);
+      lb.store(smem + TM * 128, tid, rb, mb);
       __syncthreads();
       if (k0 + BK < k_end) {
-        la.load(p, k0 + BK, k_end, tid, ra);
-        lb.load(p, k0 + BK, k_end, tid, rb);
+        ma = la.load(p, k0 + BK, k_end, tid, ra);
+        mb = lb.load(p, k0 + BK, k_end, tid, rb);
       }
       compute(smem, smem + TM * 128);
     }
   } else {
-    la.store(smem, tid, ra);
-    lb.store(smem + TM * 128, tid, rb);
+    la.store(smem, tid, ra, ma);
+    lb.store(smem + TM * 128, tid, rb, mb);
     __syncthreads();
     int buf = 0;
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
       const bool more = (k0 + BK) < k_end;
       if (more) {
-        la.load(p, k0 + BK, k_end, tid, ra);
-        lb.load(p, k0 + BK, k_end, tid, rb);
+        ma = la.load(p, k0 + BK, k_end, tid, ra);
+        mb = lb.load(p, k0 + BK, k_end, tid, rb);
       }
       const char* As = smem + buf * TILE_BYTES;
       compute(As, As + TM * 128);
       if (more) {
         char* nxt = smem + (buf ^ 1) * TILE_BYTES;
-        la.store(nxt, tid, ra);
-        lb.store(nxt + TM * 128, tid, rb);
+        la.store(nxt, tid, ra, ma);
+        lb.store(nxt + TM * 128, tid, rb, mb);
       }
       __syncthreads();
       buf ^= 1;

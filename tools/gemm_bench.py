@@ -1,0 +1,79 @@
+"""Isolated timing of the GEMM / implicit-GEMM kernel on representative shapes of the FineTune 384^2 bs32 step."""
+import ctypes as C
+import sys
+import torch
+sys.path.insert(0, '.')
+from evoke_amd import hip as H, ops
+
+BF = torch.bfloat16
+
+
+def time_it(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def gemm_case(M, N, K, a_mode, b_mode):
+    A = torch.randn((M, K) if a_mode == H.A_PLAIN else (K, M), device='cuda').to(BF)
+    B = torch.randn((N, K) if b_mode == H.B_PLAIN else (K, N), device='cuda').to(BF)
+    acc = a_mode == H.A_KSTR
+    Cm = torch.zeros(M, N, device='cuda', dtype=torch.float32 if acc else BF)
+    lda = K if a_mode == H.A_PLAIN else M
+    ldb = K if b_mode == H.B_PLAIN else N
+    return lambda: ops.gemm(A, B, Cm, M, N, K, a_mode=a_mode, b_mode=b_mode, lda=lda, ldb=ldb, ldc=N, accumulate=acc)
+
+
+def conv_case(N, Hh, Ci, Co, k, stride, kind):
+    g = H.conv_geom(N, Hh, Hh, Ci, Co, k, k, stride, k // 2)
+    x = torch.randn(N, Hh, Hh, Ci, device='cuda').to(BF)
+    w = torch.randn(Co, k, k, Ci, device='cuda').to(BF)
+    y = torch.randn(N, g.Ho, g.Wo, Co, device='cuda').to(BF)
+    dx = torch.empty_like(x)
+    dw = torch.zeros(Co, k, k, Ci, device='cuda')
+    nb = H.lib.evk_conv2d_wgrad_ws_bytes(C.byref(g))
+    ws = torch.empty(max(nb // 4, 1), device='cuda')
+    st = H.stream
+    if kind == 'fwd':
+        return lambda: H.check(H.lib.evk_conv2d_fwd(H.ptr(x), H.ptr(w), H.ptr(y), C.byref(g), st()))
+    if kind == 'dgrad':
+        return lambda: H.check(H.lib.evk_conv2d_dgrad(H.ptr(y), H.ptr(w), H.ptr(dx), C.byref(g), st()))
+    return lambda: H.check(H.lib.evk_conv2d_wgrad(H.ptr(y), H.ptr(x), H.ptr(dw), C.byref(g), H.ptr(ws), nb, st()))
+
+
+CASES = [
+    ('gemm 4640x16384x2048 NT', lambda: gemm_case(4640, 16384, 2048, 0, 0), 2 * 4640 * 16384 * 2048),
+    ('gemm 4640x2048x16384 NT', lambda: gemm_case(4640, 2048, 16384, 0, 0), 2 * 4640 * 16384 * 2048),
+    ('gemm 8192x8192x8192 NT', lambda: gemm_case(8192, 8192, 8192, 0, 0), 2 * 8192 ** 3),
+    ('gemm 4640x16384x2048 NN(dX)', lambda: gemm_case(4640, 16384, 2048, 0, 1), 2 * 4640 * 16384 * 2048),
+    ('gemm 16384x2048x4640 TN(dW)', lambda: gemm_case(16384, 2048, 4640, 3, 1), 2 * 4640 * 16384 * 2048),
+    ('conv3x3 l3 fwd 64x24x24 256->256', lambda: conv_case(64, 24, 256, 256, 3, 1, 'fwd'), 2 * 36864 * 256 * 2304),
+    ('conv3x3 l3 dgrad', lambda: conv_case(64, 24, 256, 256, 3, 1, 'dgrad'), 2 * 36864 * 256 * 2304),
+    ('conv3x3 l3 wgrad', lambda: conv_case(64, 24, 256, 256, 3, 1, 'wgrad'), 2 * 36864 * 256 * 2304),
+    ('conv1x1 l3 fwd 256->1024', lambda: conv_case(64, 24, 256, 1024, 1, 1, 'fwd'), 2 * 36864 * 256 * 1024),
+    ('conv1x1 l3 fwd 1024->256', lambda: conv_case(64, 24, 1024, 256, 1, 1, 'fwd'), 2 * 36864 * 256 * 1024),
+    ('conv1x1 l3 dgrad 1024->256', lambda: conv_case(64, 24, 1024, 256, 1, 1, 'dgrad'), 2 * 36864 * 256 * 1024),
+    ('conv1x1 l3 wgrad 1024->256', lambda: conv_case(64, 24, 1024, 256, 1, 1, 'wgrad'), 2 * 36864 * 256 * 1024),
+    ('conv3x3 l2 fwd 64x48x48 128->128', lambda: conv_case(64, 48, 128, 128, 3, 1, 'fwd'), 2 * 147456 * 128 * 1152),
+    ('conv1x1 l1 fwd 64x96x96 64->256', lambda: conv_case(64, 96, 64, 256, 1, 1, 'fwd'), 2 * 589824 * 64 * 256),
+    ('conv1x1 l1 fwd 256->64', lambda: conv_case(64, 96, 256, 64, 1, 1, 'fwd'), 2 * 589824 * 64 * 256),
+    ('conv3x3 l4 fwd 64x12x12 512->512', lambda: conv_case(64, 12, 512, 512, 3, 1, 'fwd'), 2 * 9216 * 512 * 4608),
+    ('gemm 3200x512x512 NT', lambda: gemm_case(3200, 512, 512, 0, 0), 2 * 3200 * 512 * 512),
+    ('gemm 96x512x512 NT (skinny)', lambda: gemm_case(96, 512, 512, 0, 0), 2 * 96 * 512 * 512),
+]
+
+if __name__ == '__main__':
+    sel = sys.argv[1] if len(sys.argv) > 1 else ''
+    for name, mk, flops in CASES:
+        if sel and sel not in name:
+            continue
+        fn = mk()
+        ms = time_it(fn)
+        print('%-40s %8.3f ms  %8.1f TF/s' % (name, ms, flops / ms / 1e9), flush=True)
