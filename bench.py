@@ -207,12 +207,13 @@ def main():
     for _ in range(a.warmup):
         step()
     barrier()
-    if not a.no_prof:
-        H.prof_enable(True)
     t0 = time.perf_counter()
     losses = []
-    for _ in range(a.steps):
+    for i in range(a.steps):
+        if not a.no_prof and i == a.steps - 1:
+            H.prof_enable(True)           # HIP-event pairs around every launch of the LAST timed step only (they cost host time)
         losses.append(step())
+    host_dt = time.perf_counter() - t0
     barrier()
     dt = time.perf_counter() - t0
     fam, launched_flops = ({}, 0.0)
@@ -235,18 +236,20 @@ def main():
         'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
         'config': {'workload': 'EVOKE-%d two-view %s train step (fwd+bwd+allreduce+clip+RAdam), %d studies (%d images) per GPU, '
                                'L=%d, Li=%d, V=%d, random-init weights' % (a.res, kind, a.batch, a.batch * a.views, L, Li, V),
-                   'parallelism': 'dp%d' % world, 'loss_last': float(losses[-1].item())},
+                   'parallelism': 'dp%d' % world, 'loss_last': float(losses[-1].item()),
+                   'host_launch_ms_per_step': 1e3 * host_dt / a.steps},
     }
     if fam:
         ms, n = fam['gemm']
         alg = ALG_GFLOP_PER_STUDY.get((kind, a.res))
-        alg_flops = (alg * 1e9 * a.batch * a.steps) if alg else launched_flops
+        psteps = 1                                   # steps that carried HIP events
+        alg_flops = (alg * 1e9 * a.batch * psteps) if alg else launched_flops
         ach = alg_flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_kernel (MFMA GEMM / implicit-GEMM conv family)', 'achieved': ach,
                            'peak': MFMA_BF16_DENSE_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / MFMA_BF16_DENSE_PEAK_TFLOPS,
-                           'traffic': None, 'launches_per_step': n / a.steps, 'avg_launch_us': 1e3 * ms / max(n, 1),
-                           'gemm_ms_per_step': ms / a.steps, 'launched_tflops': launched_flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
-                           'family_ms_per_step': {k: v[0] / a.steps for k, v in fam.items()}}
+                           'traffic': None, 'launches_per_step': n / psteps, 'event_timed_steps': psteps, 'avg_launch_us': 1e3 * ms / max(n, 1),
+                           'gemm_ms_per_step': ms / psteps, 'launched_tflops': launched_flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+                           'family_ms_per_step': {k: v[0] / psteps for k, v in fam.items()}}
     if world == 1 and not a.no_cpu_baseline:
         try:
             out['cpu_baseline'] = cpu_baseline(model, kind, a.res, L, Li)

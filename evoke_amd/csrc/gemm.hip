@@ -28,7 +28,7 @@ struct GemmP {
   int bi;
   long sAo, sAi, sBo, sBi, sCo, sCi, sRo, sRi;
   float alpha; int act, c_f32, r_f32, accumulate, vec_ok;
-  int ksteps_per_split, tilesN;
+  int ksteps_per_split, tilesN, kslice_xcd;
   float* slab; long slab_mn;        // split-K partial slabs [z][split][M][N] f32 (accumulate mode with splitk > 1)
   int b_klog, b_kmask; long b_tapstride;
   // gather geometry
@@ -244,15 +244,25 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(const GemmP p) {
 
   // XCD-aware bijective remap (cdna_hip_programming.md T1): blocks b, b+8, ... share an XCD/L2, give
   // each XCD a contiguous run of tiles so neighbouring tiles re-use the same operand panels in L2.
-  int wg;
-  {
+  int wg, by = blockIdx.y, bz = blockIdx.z;
+  if (p.kslice_xcd && gridDim.y > 1 && (gridDim.y & 7) == 0) {
+    // split-K launch (weight gradients: small M x N, long K): every tile / tap of one K-slice reads the same operand
+    // slice, so give each XCD whole K-slices -- slice s lives on XCD s % 8 and is fetched into that L2 once.
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int per = gridDim.x * gridDim.z;               // blocks per K-slice
+    const int xcd = lin & 7, j = lin >> 3;
+    const int sl = j / per, w = j - sl * per;
+    by = xcd + 8 * sl;
+    bz = w / gridDim.x;
+    wg = w - bz * gridDim.x;
+  } else {
     const int bid = blockIdx.x, nwg = gridDim.x;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
   const int tm = wg / p.tilesN, tn = wg - tm * p.tilesN;
-  const int zo = blockIdx.z / p.bi, zi = blockIdx.z - zo * p.bi;
-  const int k_begin = blockIdx.y * p.ksteps_per_split * BK;
+  const int zo = bz / p.bi, zi = bz - zo * p.bi;
+  const int k_begin = by * p.ksteps_per_split * BK;
   const int k_end = min(p.K, k_begin + p.ksteps_per_split * BK);
   if (k_begin >= k_end) return;
 
@@ -364,7 +374,7 @@ __global__ __launch_bounds__(NTHR) void gemm_kernel(const GemmP p) {
       const bool full = p.vec_ok && (n0 + 3 < p.N);
       if (p.accumulate) {
         if (p.slab) {          // split-K partial: plain row-contiguous stores, summed into C by splitk_reduce_kernel
-          float* c = p.slab + ((long)blockIdx.z * gridDim.y + blockIdx.y) * p.slab_mn + (long)m * p.N + n0;
+          float* c = p.slab + ((long)bz * gridDim.y + by) * p.slab_mn + (long)m * p.N + n0;
           if ((p.N & 3) == 0 && n0 + 3 < p.N) *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
           else {
 #pragma unroll
@@ -615,6 +625,13 @@ inline int choose_splitk(int M, int N, int K, int batch, int splitk_req) {
   if (splitk * per_split > SLAB_MAX_BYTES) splitk = SLAB_MAX_BYTES / per_split;
   if (splitk > ksteps) splitk = ksteps;
   if (splitk < 1) splitk = 1;
+  if (splitk >= 8 && ksteps >= 8) {      // whole K-slices per XCD (see gemm_kernel): a multiple of 8 non-empty slices
+    for (long s8 = (splitk + 4) / 8 * 8; s8 >= 8; s8 -= 8) {
+      if (s8 * per_split > SLAB_MAX_BYTES) continue;
+      const int per = (int)cdiv(ksteps, s8);
+      if (cdiv(ksteps, per) == s8) return (int)s8;
+    }
+  }
   const int per = (int)cdiv(ksteps, splitk);
   return (int)cdiv(ksteps, per);
 }
@@ -635,6 +652,8 @@ int launch_modes(GemmP& p, int batch, int splitk_req, void* ws, long ws_bytes, c
   }
   p.ksteps_per_split = (int)cdiv(ksteps, splitk);
   splitk = (int)cdiv(ksteps, p.ksteps_per_split);
+  static const int kslice = [] { const char* e = getenv("EVK_KSLICE_XCD"); return e ? atoi(e) : 1; }();
+  p.kslice_xcd = kslice;
   dim3 grid(tilesM * p.tilesN, splitk, batch);
   int rc = narrow ? launch_cfg<4, 1, AMODE, BMODE>(p, grid, s) : launch_cfg<2, 2, AMODE, BMODE>(p, grid, s);
   if (rc == EVK_OK && p.slab) {

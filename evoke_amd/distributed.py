@@ -146,6 +146,8 @@ class GradReducer:
         if world_size() == 1:
             return
         fi, s, e = self.buckets[b]
+        if self.flat[fi].is_cuda:
+            ops.join_side_streams()       # gradients are accumulated in place from side streams (wgrad, rm, text)
         self.handles.append(dist.all_reduce(self.flat[fi][s:e], op=dist.ReduceOp.SUM, async_op=True))
 
     def on_grad(self, p):

@@ -79,21 +79,31 @@ SIDE_STREAMS_ENABLED = [True]
 
 
 def side_stream(name, device=None):
+    """The named side stream of `device`; the stream current at the call is remembered as that device's main stream."""
     dev = torch.cuda.current_device() if device is None else device
     key = (name, dev)
     st = _side_streams.get(key)
     if st is None:
         st = _side_streams[key] = torch.cuda.Stream(device=dev)
+    cur = torch.cuda.current_stream(dev)
+    if all(cur != s for (n, d), s in _side_streams.items() if d == dev):
+        _main_stream[dev] = cur
     return st
 
 
+_main_stream = {}
+
+
 def join_side_streams():
-    """Make the current stream wait for everything queued on the side streams (called before the optimizer /
-    gradient all-reduce, because parameter gradients are accumulated in place from those streams)."""
+    """Make the current stream wait for everything queued on the side streams and on the main stream (called before the
+    optimizer / gradient all-reduce, because parameter gradients are accumulated in place from those streams)."""
     cur = torch.cuda.current_stream()
     for (name, dev), st in _side_streams.items():
-        if dev == cur.device.index:
+        if dev == cur.device.index and st != cur:
             cur.wait_stream(st)
+    main = _main_stream.get(cur.device.index)
+    if main is not None and main != cur:
+        cur.wait_stream(main)
 
 
 def _z(*shape, dtype=BF16, device='cuda'):

@@ -42,11 +42,37 @@ class _Conv(torch.autograd.Function):
             dx = _e(*x.shape, device=x.device)
             H.check(H.lib.evk_conv2d_dgrad(H.ptr(dy), H.ptr(shadow(W)), H.ptr(dx), C.byref(g), H.stream()), 'conv_dgrad')
         if W.requires_grad:
-            nb = H.lib.evk_conv2d_wgrad_ws_bytes(C.byref(g))
-            ws = torch.empty(max(nb // 4, 1), dtype=F32, device=x.device)
-            H.check(H.lib.evk_conv2d_wgrad(H.ptr(dy), H.ptr(x), H.ptr(grad_buffer(W)), C.byref(g), H.ptr(ws), nb, H.stream()), 'conv_wgrad')
+            # the weight gradient feeds nothing before the optimizer: run it on a side stream so its long, latency-bound
+            # split-K blocks share the CUs with the (HBM-bound) data-gradient / batch-norm kernels of the main stream
+            with _wgrad_stream(dy, x):
+                nb = H.lib.evk_conv2d_wgrad_ws_bytes(C.byref(g))
+                ws = torch.empty(max(nb // 4, 1), dtype=F32, device=x.device)
+                H.check(H.lib.evk_conv2d_wgrad(H.ptr(dy), H.ptr(x), H.ptr(grad_buffer(W)), C.byref(g), H.ptr(ws), nb, H.stream()), 'conv_wgrad')
             grad_done(W)
         return dx, None, None, None
+
+
+class _wgrad_stream:
+    """context: side stream 'wgrad' ordered after the current stream; `tensors` are kept alive for it."""
+
+    def __init__(self, *tensors):
+        self.tensors = tensors
+        self.ctx = None
+
+    def __enter__(self):
+        if ops.SIDE_STREAMS_ENABLED[0]:
+            side = ops.side_stream('wgrad')
+            side.wait_stream(torch.cuda.current_stream())
+            for t in self.tensors:
+                t.record_stream(side)
+            self.ctx = torch.cuda.stream(side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
 
 
 def conv2d(x, W, stride=1, pad=0):
@@ -77,13 +103,14 @@ class _Stem(torch.autograd.Function):
         W = ctx.W
         N, Hh, Ww = ctx.dims
         if W.requires_grad:
-            st = H.stream()
             dy = dy.contiguous()
-            dwp = _z(64 * 224, dtype=F32, device=dy.device)
-            nb = H.lib.evk_stem_wgrad_ws_bytes(N, Hh, Ww)
-            ws = torch.empty(max(nb // 4, 1), dtype=F32, device=dy.device)
-            H.check(H.lib.evk_stem_wgrad(H.ptr(dy), H.ptr(xpad), H.ptr(dwp), N, Hh, Ww, H.ptr(ws), nb, st), 'stem_wgrad')
-            H.check(H.lib.evk_stem_unpack_wgrad(H.ptr(dwp), H.ptr(grad_buffer(W)), st), 'stem_unpack_wgrad')
+            with _wgrad_stream(dy, xpad):
+                st = H.stream()
+                dwp = _z(64 * 224, dtype=F32, device=dy.device)
+                nb = H.lib.evk_stem_wgrad_ws_bytes(N, Hh, Ww)
+                ws = torch.empty(max(nb // 4, 1), dtype=F32, device=dy.device)
+                H.check(H.lib.evk_stem_wgrad(H.ptr(dy), H.ptr(xpad), H.ptr(dwp), N, Hh, Ww, H.ptr(ws), nb, st), 'stem_wgrad')
+                H.check(H.lib.evk_stem_unpack_wgrad(H.ptr(dwp), H.ptr(grad_buffer(W)), st), 'stem_unpack_wgrad')
             grad_done(W)
         return None, None
 
