@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const RedP p) {
 // out0[c] = sum_blk part[blk][0][c], out1[c] = sum_blk part[blk][1][c].  Block = 16 columns x 16 row-lanes: every
 // thread sums nblk/16 partials with 8 independent loads in flight, then the 16 row-lanes are combined in LDS.
 __global__ __launch_bounds__(256) void colreduce_final_kernel(const float* __restrict__ part, float* __restrict__ out0,
-                                                              float* __restrict__ out1, int nblk, int C) {
+                                                              float* __restrict__ out1, float* acc0, float* acc1, int nblk, int C) {
   __shared__ float red[16][17];
   const int col = blockIdx.x * 16 + (threadIdx.x & 15);
   const int rl = threadIdx.x >> 4;
@@ -119,7 +119,8 @@ __global__ __launch_bounds__(256) void colreduce_final_kernel(const float* __res
     float s = 0.f;
 #pragma unroll
     for (int q = 0; q < 16; ++q) s += red[q][threadIdx.x];
-    if (col < C) out0[col] = s; else out1[col - C] = s;
+    if (col < C) { out0[col] = s; if (acc0) acc0[col] += s; }
+    else { out1[col - C] = s; if (acc1) acc1[col - C] += s; }
   }
 }
 
@@ -318,7 +319,8 @@ inline int ew_blocks(long work) { long b = cdiv(work, 256); return (int)(b < 1 ?
 
 constexpr int RED_MAX_BLOCKS = 1024;
 
-int launch_reduce(const RedP& p0, float* out0, float* out1, void* ws, long ws_bytes, hipStream_t s) {
+int launch_reduce(const RedP& p0, float* out0, float* out1, void* ws, long ws_bytes, hipStream_t s, float* acc0 = nullptr,
+                  float* acc1 = nullptr) {
   RedP p = p0;
   const int G = p.C >> 3;
   const int rpb = 256 / G;
@@ -332,7 +334,7 @@ int launch_reduce(const RedP& p0, float* out0, float* out1, void* ws, long ws_by
   p.part = reinterpret_cast<float*>(ws);
   ProfScope ps(EVK_FAM_REDUCE, s);
   hipLaunchKernelGGL(colreduce_kernel, dim3((int)blocks), dim3(256), 0, s, p);
-  hipLaunchKernelGGL(colreduce_final_kernel, dim3((int)cdiv(2 * p.C, 16)), dim3(256), 0, s, p.part, out0, out1, (int)blocks, p.C);
+  hipLaunchKernelGGL(colreduce_final_kernel, dim3((int)cdiv(2 * p.C, 16)), dim3(256), 0, s, p.part, out0, out1, acc0, acc1, (int)blocks, p.C);
   return evk_check_launch("colreduce");
 }
 
@@ -376,10 +378,17 @@ int evk_bn_apply(const void* x, const float* scale, const float* shift, const vo
 // sum_g[c] = sum_rows g, sum_gx[c] = sum_rows g*xhat  with g = dz * (z > 0 if relu)
 int evk_bn_bwd_reduce(const void* dz, const void* z, const void* x, const float* mean, const float* invstd, float* sum_g,
                       float* sum_gx, void* ws, int64_t ws_bytes, int64_t M, int32_t C, int32_t relu, evk_stream_t stream) {
+  return evk_bn_bwd_reduce_acc(dz, z, x, mean, invstd, sum_g, sum_gx, nullptr, nullptr, ws, ws_bytes, M, C, relu, stream);
+}
+
+// same, and dbeta_acc[c] += sum_g[c], dgamma_acc[c] += sum_gx[c] (the affine parameters' gradients) when given
+int evk_bn_bwd_reduce_acc(const void* dz, const void* z, const void* x, const float* mean, const float* invstd, float* sum_g,
+                          float* sum_gx, float* dbeta_acc, float* dgamma_acc, void* ws, int64_t ws_bytes, int64_t M, int32_t C,
+                          int32_t relu, evk_stream_t stream) {
   EVK_REQUIRE(dz && x && mean && invstd && sum_g && sum_gx && (!relu || z) && M > 0 && C % 8 == 0 && C >= 8 && C <= 2048 &&
               256 % (C / 8) == 0, "bn_bwd_reduce: bad args");
   RedP p{(const bf16_t*)x, (const bf16_t*)dz, (const bf16_t*)z, mean, invstd, nullptr, M, C, 1, relu, 0};
-  return launch_reduce(p, sum_g, sum_gx, ws, ws_bytes, reinterpret_cast<hipStream_t>(stream));
+  return launch_reduce(p, sum_g, sum_gx, ws, ws_bytes, reinterpret_cast<hipStream_t>(stream), dbeta_acc, dgamma_acc);
 }
 
 int evk_bn_bwd_apply(const void* dz, const void* z, const void* x, const float* scale, const float* mean, const float* invstd,

@@ -80,6 +80,10 @@ int evk_conv2d_fwd(const void* x, const void* w, void* y, const evk_conv_geom* g
 }
 
 int evk_conv2d_dgrad(const void* dy, const void* w, void* dx, const evk_conv_geom* g, evk_stream_t stream) {
+  return evk_conv2d_dgrad_add(dy, w, nullptr, dx, g, stream);
+}
+
+int evk_conv2d_dgrad_add(const void* dy, const void* w, const void* resid, void* dx, const evk_conv_geom* g, evk_stream_t stream) {
   if (int e = check_geom(g)) return e;
   const int T = g->KH * g->KW;
   EVK_REQUIRE(ilog2_exact(g->Co) >= 3, "conv dgrad: Co must be a power of two >= 8");
@@ -90,6 +94,7 @@ int evk_conv2d_dgrad(const void* dy, const void* w, void* dx, const evk_conv_geo
   d.lda = g->Co; d.ldb = (int64_t)T * g->Ci; d.ldc = g->Ci;
   d.b_klog = ilog2_exact(g->Co); d.b_tapstride = g->Ci;
   d.batch_outer = d.batch_inner = 1; d.alpha = 1.f; d.c_dtype = EVK_BF16;
+  if (resid) { d.resid = resid; d.ldr = g->Ci; d.r_dtype = EVK_BF16; }
   d.g = *g;
   return evk_gemm_launch(&d, stream);
 }

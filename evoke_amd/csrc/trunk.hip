@@ -1,0 +1,287 @@
+// trunk.hip -- native runner of the ResNet bottleneck trunk (visual_extractor.py:27-43 -> torchvision resnet101
+// children 0-7): one C call runs the whole forward (stem, max-pool, 33 bottlenecks) and one the whole backward, so the
+// ~1200 kernel launches of a training step are issued from C++ instead of one Python autograd node per op.
+//
+// Workspace (one caller-provided buffer, laid out by plan()): for every conv+BN pair the raw conv output y, the
+// post-BN activation z and its statistics (saved for the backward), and for the backward a gradient buffer dy per pair
+// plus six rotating gradient buffers for the block-level tensors.  Every dy buffer is unique, so the weight-gradient
+// GEMMs can run on a second stream (they feed nothing before the optimizer) without slot-reuse hazards.
+#include <vector>
+#include "common.h"
+
+namespace {
+
+struct Pair {               // one conv + batch-norm
+  evk_conv_geom g;          // conv geometry (unused for the stem)
+  int C;                    // output channels
+  long M;                   // output rows N*Ho*Wo
+  long y, z, stats, dy, sums;   // workspace offsets (bytes)
+};
+
+struct Plan {
+  std::vector<Pair> pairs;  // [0] stem, then per block conv1, conv2, conv3, (downsample)
+  std::vector<int> has_down;  // per block
+  int N, H, W;
+  long xpad, wp, dwp, pooled, red, slab, zeros, gbuf[6];
+  long gcap, slab_bytes, red_bytes;
+  long total;
+};
+
+inline long align256(long x) { return (x + 255) & ~255L; }
+
+evk_conv_geom geom(int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int pad) {
+  evk_conv_geom g{};
+  g.N = N; g.Hi = Hi; g.Wi = Wi; g.Ci = Ci; g.Co = Co; g.KH = g.KW = k; g.stride_h = g.stride_w = stride; g.pad_h = g.pad_w = pad;
+  g.Ho = (Hi + 2 * pad - k) / stride + 1; g.Wo = (Wi + 2 * pad - k) / stride + 1;
+  g.sN = (int64_t)Hi * Wi * Ci; g.sH = (int64_t)Wi * Ci; g.sW = Ci;
+  return g;
+}
+
+int make_plan(const evk_trunk_cfg* cfg, int N, int H, int W, Plan& P) {
+  EVK_REQUIRE(cfg && N > 0 && H >= 32 && W >= 32 && H % 32 == 0 && W % 32 == 0, "trunk: image size must be a multiple of 32 (got %dx%d)", H, W);
+  P.N = N; P.H = H; P.W = W;
+  long off = 0;
+  auto take = [&](long bytes) { long o = off; off = align256(off + bytes); return o; };
+  P.xpad = take((long)N * (H + 6) * (W + 8) * 4 * 2);
+  P.wp = take(64 * 224 * 2);
+  P.dwp = take(64 * 224 * 4);
+  long gcap = 0, slab = evk_stem_wgrad_ws_bytes(N, H, W);
+  auto add_pair = [&](const evk_conv_geom& g, int C, long M) {
+    Pair pr{};
+    pr.g = g; pr.C = C; pr.M = M;
+    pr.y = take(M * C * 2); pr.z = take(M * C * 2); pr.stats = take(6L * C * 4);
+    pr.dy = take(M * C * 2); pr.sums = take(2L * C * 4);
+    if (M * C * 2 > gcap) gcap = M * C * 2;
+    P.pairs.push_back(pr);
+  };
+  int h = H / 2, w = W / 2;
+  add_pair(evk_conv_geom{}, 64, (long)N * h * w);                 // stem
+  h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1;
+  P.pooled = take((long)N * h * w * 64 * 2);
+  int inpl = 64;
+  for (int L = 0; L < 4; ++L) {
+    const int planes = cfg->planes[L];
+    EVK_REQUIRE(cfg->blocks[L] >= 1 && planes >= 8 && (planes & (planes - 1)) == 0, "trunk: bad layer %d config", L);
+    for (int b = 0; b < cfg->blocks[L]; ++b) {
+      const int stride = b == 0 ? cfg->stride[L] : 1;
+      const bool down = b == 0;
+      const int ho = (h - 1) / stride + 1, wo = (w - 1) / stride + 1;
+      evk_conv_geom g1 = geom(N, h, w, inpl, planes, 1, 1, 0);
+      evk_conv_geom g2 = geom(N, h, w, planes, planes, 3, stride, 1);
+      evk_conv_geom g3 = geom(N, ho, wo, planes, planes * 4, 1, 1, 0);
+      add_pair(g1, planes, (long)N * h * w);
+      add_pair(g2, planes, (long)N * ho * wo);
+      add_pair(g3, planes * 4, (long)N * ho * wo);
+      if (down) {
+        evk_conv_geom gd = geom(N, h, w, inpl, planes * 4, 1, stride, 0);
+        add_pair(gd, planes * 4, (long)N * ho * wo);
+      }
+      P.has_down.push_back(down ? 1 : 0);
+      for (size_t i = P.pairs.size() - (down ? 4 : 3); i < P.pairs.size(); ++i) {
+        const long nb = evk_conv2d_wgrad_ws_bytes(&P.pairs[i].g);
+        if (nb > slab) slab = nb;
+      }
+      if ((long)N * h * w * inpl * 2 > gcap) gcap = (long)N * h * w * inpl * 2;
+      inpl = planes * 4; h = ho; w = wo;
+    }
+  }
+  P.gcap = gcap;
+  for (int i = 0; i < 6; ++i) P.gbuf[i] = take(gcap);
+  P.red_bytes = evk_colreduce_ws_bytes(2048);
+  P.red = take(P.red_bytes);
+  P.slab_bytes = slab;
+  P.slab = take(slab);
+  P.zeros = take(2 * 2048 * 4);
+  P.total = off;
+  return EVK_OK;
+}
+
+#define TRY(expr) do { int rc_ = (expr); if (rc_ != EVK_OK) return rc_; } while (0)
+
+struct Ctx {
+  const evk_trunk_cfg* cfg; const evk_trunk_layer* L; char* ws; Plan* P; evk_stream_t s; int training;
+  template <typename T = void> T* at(long off) const { return reinterpret_cast<T*>(ws + off); }
+};
+
+// y = conv(x), batch statistics / running statistics -> scale, shift; z = relu?(y * scale + shift + resid)
+int bn_forward(const Ctx& c, int i, const void* resid, int relu) {
+  const Pair& pr = c.P->pairs[i];
+  const evk_trunk_layer& l = c.L[i];
+  float* st = c.at<float>(pr.stats);
+  const int C = pr.C;
+  if (c.training) TRY(evk_bn_stats(c.at(pr.y), st, st + C, c.at(c.P->red), c.P->red_bytes, pr.M, C, c.s));
+  TRY(evk_bn_finalize(st, st + C, l.gamma, l.beta, l.running_mean, l.running_var, st + 2 * C, st + 3 * C, st + 4 * C, st + 5 * C, C,
+                      (float)pr.M, c.cfg->momentum, c.cfg->eps, c.training, c.s));
+  return evk_bn_apply(c.at(pr.y), st + 2 * C, st + 3 * C, resid, c.at(pr.z), pr.M, C, relu, c.s);
+}
+
+// dz (gradient w.r.t. z) -> dy (gradient w.r.t. the conv output), optional dres (= masked dz, the skip-branch gradient)
+int bn_backward(const Ctx& c, int i, const void* dz, void* dres, int relu) {
+  const Pair& pr = c.P->pairs[i];
+  const evk_trunk_layer& l = c.L[i];
+  float* st = c.at<float>(pr.stats);
+  float* sums = c.at<float>(pr.sums);
+  const int C = pr.C;
+  TRY(evk_bn_bwd_reduce_acc(dz, c.at(pr.z), c.at(pr.y), st + 4 * C, st + 5 * C, sums, sums + C, l.dbeta, l.dgamma, c.at(c.P->red),
+                            c.P->red_bytes, pr.M, C, relu, c.s));
+  const float* sg = c.training ? sums : c.at<float>(c.P->zeros);       // eval-mode BN is a fixed affine map
+  const float* sgx = c.training ? sums + C : c.at<float>(c.P->zeros);
+  return evk_bn_bwd_apply(dz, c.at(pr.z), c.at(pr.y), st + 2 * C, st + 4 * C, st + 5 * C, sg, sgx, c.at(pr.dy), dres, pr.M, C, relu, c.s);
+}
+
+struct WgradQueue {      // weight gradients on a second stream, ordered after the main-stream kernel that produced dy
+  hipStream_t main, side;
+  hipEvent_t ev[8];
+  int n = 0;
+  bool ok = false;
+  int init(evk_stream_t m, evk_stream_t sd) {
+    main = reinterpret_cast<hipStream_t>(m);
+    side = reinterpret_cast<hipStream_t>(sd);
+    ok = sd != nullptr && sd != m;
+    if (ok) {
+      static thread_local hipEvent_t pool[8];
+      static thread_local bool made = false;
+      if (!made) {
+        for (int i = 0; i < 8; ++i)
+          if (hipEventCreateWithFlags(&pool[i], hipEventDisableTiming) != hipSuccess) { evk_set_error("trunk: hipEventCreate failed"); return EVK_ELAUNCH; }
+        made = true;
+      }
+      for (int i = 0; i < 8; ++i) ev[i] = pool[i];
+    }
+    return EVK_OK;
+  }
+  evk_stream_t fork() {        // returns the stream to launch the weight gradient on
+    if (!ok) return reinterpret_cast<evk_stream_t>(main);
+    hipEvent_t e = ev[n++ & 7];
+    (void)hipEventRecord(e, main);
+    (void)hipStreamWaitEvent(side, e, 0);
+    return reinterpret_cast<evk_stream_t>(side);
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+int64_t evk_trunk_ws_bytes(const evk_trunk_cfg* cfg, int32_t N, int32_t H, int32_t W) {
+  Plan P;
+  if (make_plan(cfg, N, H, W, P) != EVK_OK) return -1;
+  return P.total;
+}
+
+int evk_trunk_num_pairs(const evk_trunk_cfg* cfg) {
+  if (!cfg) return -1;
+  int n = 1;
+  for (int L = 0; L < 4; ++L) n += 3 * cfg->blocks[L] + 1;
+  return n;
+}
+
+int evk_trunk_forward(const evk_trunk_cfg* cfg, const evk_trunk_layer* layers, int32_t n_layers, const float* images, int32_t N,
+                      int32_t H, int32_t W, void* ws, int64_t ws_bytes, void* out, int32_t training, evk_stream_t stream) {
+  Plan P;
+  TRY(make_plan(cfg, N, H, W, P));
+  EVK_REQUIRE(layers && images && ws && out, "trunk_forward: null argument");
+  EVK_REQUIRE(n_layers == (int)P.pairs.size(), "trunk_forward: expected %d conv+bn pairs, got %d", (int)P.pairs.size(), n_layers);
+  EVK_REQUIRE(ws_bytes >= P.total, "trunk_forward: workspace too small (%ld bytes needed)", P.total);
+  Ctx c{cfg, layers, static_cast<char*>(ws), &P, stream, training};
+  hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(c.at(P.zeros), 0, 2 * 2048 * 4, hs) != hipSuccess) { evk_set_error("trunk: memset failed"); return EVK_ELAUNCH; }
+
+  // stem: pack, conv 7x7 s2, BN + ReLU, max-pool 3x3 s2
+  TRY(evk_stem_pack_image(images, c.at(P.xpad), N, H, W, stream));
+  TRY(evk_stem_pack_weight(reinterpret_cast<const float*>(layers[0].w), c.at(P.wp), stream));
+  TRY(evk_stem_fwd(c.at(P.xpad), c.at(P.wp), c.at(P.pairs[0].y), N, H, W, stream));
+  TRY(bn_forward(c, 0, nullptr, 1));
+  TRY(evk_maxpool3x3s2_fwd(c.at(P.pairs[0].z), c.at(P.pooled), N, H / 2, W / 2, 64, stream));
+
+  const void* x = c.at(P.pooled);
+  int i = 1;
+  for (size_t b = 0; b < P.has_down.size(); ++b) {
+    const bool down = P.has_down[b];
+    const void* idt = x;
+    if (down) {
+      TRY(evk_conv2d_fwd(x, layers[i + 3].w, c.at(P.pairs[i + 3].y), &P.pairs[i + 3].g, stream));
+      TRY(bn_forward(c, i + 3, nullptr, 0));
+      idt = c.at(P.pairs[i + 3].z);
+    }
+    TRY(evk_conv2d_fwd(x, layers[i].w, c.at(P.pairs[i].y), &P.pairs[i].g, stream));
+    TRY(bn_forward(c, i, nullptr, 1));
+    TRY(evk_conv2d_fwd(c.at(P.pairs[i].z), layers[i + 1].w, c.at(P.pairs[i + 1].y), &P.pairs[i + 1].g, stream));
+    TRY(bn_forward(c, i + 1, nullptr, 1));
+    TRY(evk_conv2d_fwd(c.at(P.pairs[i + 1].z), layers[i + 2].w, c.at(P.pairs[i + 2].y), &P.pairs[i + 2].g, stream));
+    TRY(bn_forward(c, i + 2, idt, 1));
+    x = c.at(P.pairs[i + 2].z);
+    i += down ? 4 : 3;
+  }
+  const Pair& last = P.pairs[i - (P.has_down.back() ? 4 : 3) + 2];
+  if (hipMemcpyAsync(out, x, last.M * last.C * 2, hipMemcpyDeviceToDevice, hs) != hipSuccess) { evk_set_error("trunk: copy-out failed"); return EVK_ELAUNCH; }
+  return EVK_OK;
+}
+
+int evk_trunk_backward(const evk_trunk_cfg* cfg, const evk_trunk_layer* layers, int32_t n_layers, int32_t N, int32_t H, int32_t W,
+                       void* ws, int64_t ws_bytes, const void* dout, int32_t training, evk_stream_t stream, evk_stream_t wgrad_stream) {
+  Plan P;
+  TRY(make_plan(cfg, N, H, W, P));
+  EVK_REQUIRE(layers && ws && dout, "trunk_backward: null argument");
+  EVK_REQUIRE(n_layers == (int)P.pairs.size() && ws_bytes >= P.total, "trunk_backward: layer count / workspace mismatch");
+  Ctx c{cfg, layers, static_cast<char*>(ws), &P, stream, training};
+  WgradQueue q;
+  TRY(q.init(stream, wgrad_stream));
+
+  auto wgrad = [&](int i, const void* xin) -> int {
+    if (!layers[i].dw) return EVK_OK;
+    evk_stream_t s2 = q.fork();
+    return evk_conv2d_wgrad(c.at(P.pairs[i].dy), xin, layers[i].dw, &P.pairs[i].g, c.at(P.slab), P.slab_bytes, s2);
+  };
+
+  // first pair index of every block
+  std::vector<int> first(P.has_down.size());
+  {
+    int i = 1;
+    for (size_t b = 0; b < P.has_down.size(); ++b) { first[b] = i; i += P.has_down[b] ? 4 : 3; }
+  }
+  const void* gZ = dout;                 // gradient w.r.t. the current block's output
+  int flip = 0;
+  for (int b = (int)P.has_down.size() - 1; b >= 0; --b) {
+    const int i = first[b];
+    const bool down = P.has_down[b];
+    const void* X = b == 0 ? c.at(P.pooled) : c.at(P.pairs[first[b - 1] + 2].z);     // block input
+    void* R = c.at(P.gbuf[2]);           // skip-branch gradient (masked gZ)
+    void* S1 = c.at(P.gbuf[3]);
+    void* S2 = c.at(P.gbuf[4]);
+    void* T = c.at(P.gbuf[5]);
+    void* gX = c.at(P.gbuf[flip]);
+    flip ^= 1;
+    TRY(bn_backward(c, i + 2, gZ, R, 1));
+    TRY(evk_conv2d_dgrad(c.at(P.pairs[i + 2].dy), layers[i + 2].w, S1, &P.pairs[i + 2].g, stream));
+    TRY(wgrad(i + 2, c.at(P.pairs[i + 1].z)));
+    TRY(bn_backward(c, i + 1, S1, nullptr, 1));
+    TRY(evk_conv2d_dgrad(c.at(P.pairs[i + 1].dy), layers[i + 1].w, S2, &P.pairs[i + 1].g, stream));
+    TRY(wgrad(i + 1, c.at(P.pairs[i].z)));
+    TRY(bn_backward(c, i, S2, nullptr, 1));
+    const void* skip = R;
+    if (down) {
+      TRY(bn_backward(c, i + 3, R, nullptr, 0));
+      TRY(evk_conv2d_dgrad(c.at(P.pairs[i + 3].dy), layers[i + 3].w, T, &P.pairs[i + 3].g, stream));
+      TRY(wgrad(i + 3, X));
+      skip = T;
+    }
+    TRY(evk_conv2d_dgrad_add(c.at(P.pairs[i].dy), layers[i].w, skip, gX, &P.pairs[i].g, stream));
+    TRY(wgrad(i, X));
+    gZ = gX;
+  }
+  // max-pool, stem BN, stem weight gradient (images get no gradient)
+  void* gS = c.at(P.gbuf[2]);
+  TRY(evk_maxpool3x3s2_bwd(c.at(P.pairs[0].z), gZ, gS, N, H / 2, W / 2, 64, stream));
+  TRY(bn_backward(c, 0, gS, nullptr, 1));
+  if (layers[0].dw) {
+    evk_stream_t s2 = q.fork();
+    hipStream_t h2 = reinterpret_cast<hipStream_t>(s2);
+    if (hipMemsetAsync(c.at(P.dwp), 0, 64 * 224 * 4, h2) != hipSuccess) { evk_set_error("trunk: memset failed"); return EVK_ELAUNCH; }
+    TRY(evk_stem_wgrad(c.at(P.pairs[0].dy), c.at(P.xpad), c.at<float>(P.dwp), N, H, W, c.at(P.slab), P.slab_bytes, s2));
+    TRY(evk_stem_unpack_wgrad(c.at<float>(P.dwp), layers[0].dw, s2));
+  }
+  return EVK_OK;
+}
+
+}  // extern "C"

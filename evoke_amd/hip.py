@@ -34,6 +34,15 @@ class Gemm(C.Structure):
                 ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64), ('g', ConvGeom)]
 
 
+class TrunkCfg(C.Structure):
+    _fields_ = [('blocks', C.c_int32 * 4), ('planes', C.c_int32 * 4), ('stride', C.c_int32 * 4), ('eps', C.c_float),
+                ('momentum', C.c_float)]
+
+
+class TrunkLayer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('w', 'dw', 'gamma', 'beta', 'running_mean', 'running_var', 'dgamma', 'dbeta')]
+
+
 _CTYPES = {'int': C.c_int32, 'int32_t': C.c_int32, 'int64_t': C.c_int64, 'uint64_t': C.c_uint64, 'float': C.c_float,
            'evk_stream_t': C.c_void_p}
 

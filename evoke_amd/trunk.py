@@ -115,6 +115,66 @@ class _Stem(torch.autograd.Function):
         return None, None
 
 
+class _TrunkFn(torch.autograd.Function):
+    """ResNet trunk forward / backward through evk_trunk_forward / evk_trunk_backward.  `anchor` (the stem weight) only ties
+    the node into the autograd graph; parameter gradients are accumulated in place by the runner."""
+
+    @staticmethod
+    def _layers(pairs, with_grads):
+        arr = (H.TrunkLayer * len(pairs))()
+        keep = []
+        for i, (cv, bn) in enumerate(pairs):
+            W = cv.weight
+            wt = W if i == 0 else shadow(W)
+            keep.append(wt)
+            l = arr[i]
+            l.w = wt.data_ptr()
+            l.gamma, l.beta = bn.weight.data_ptr(), bn.bias.data_ptr()
+            l.running_mean, l.running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+            if with_grads:
+                l.dw = grad_buffer(W).data_ptr() if W.requires_grad else None
+                l.dgamma = grad_buffer(bn.weight).data_ptr() if bn.weight.requires_grad else None
+                l.dbeta = grad_buffer(bn.bias).data_ptr() if bn.bias.requires_grad else None
+        return arr, keep
+
+    @staticmethod
+    def forward(ctx, images, anchor, trunk):
+        N, _, Hh, Ww = images.shape
+        pairs = trunk.pairs()
+        cfg = trunk.native_cfg()
+        arr, keep = _TrunkFn._layers(pairs, False)
+        nb = H.lib.evk_trunk_ws_bytes(C.byref(cfg), N, Hh, Ww)
+        if nb < 0:
+            raise RuntimeError('evk_trunk_ws_bytes: ' + H.lib.evk_last_error().decode())
+        ws = torch.empty(nb, dtype=torch.uint8, device=images.device)
+        out = _e(N, Hh // 32, Ww // 32, 4 * RESNET_LAYERS[-1][0], device=images.device)
+        H.check(H.lib.evk_trunk_forward(C.byref(cfg), arr, len(pairs), H.ptr(images), N, Hh, Ww, H.ptr(ws), nb, H.ptr(out),
+                                        int(trunk.training), H.stream()), 'trunk_forward')
+        ctx.ws, ctx.trunk, ctx.dims, ctx.training, ctx.keep = ws, trunk, (N, Hh, Ww), trunk.training, keep
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        trunk, ws = ctx.trunk, ctx.ws
+        N, Hh, Ww = ctx.dims
+        pairs = trunk.pairs()
+        cfg = trunk.native_cfg()
+        arr, keep = _TrunkFn._layers(pairs, True)
+        dout = dout.contiguous()
+        side = None
+        if ops.SIDE_STREAMS_ENABLED[0]:
+            side = ops.side_stream('wgrad')
+            ws.record_stream(side)
+        H.check(H.lib.evk_trunk_backward(C.byref(cfg), arr, len(pairs), N, Hh, Ww, H.ptr(ws), ws.numel(), H.ptr(dout), int(ctx.training),
+                                         H.stream(), side.cuda_stream if side is not None else None), 'trunk_backward')
+        ctx.ws = None
+        for cv, bn in pairs:
+            for p in (cv.weight, bn.weight, bn.bias):
+                if p.requires_grad:
+                    grad_done(p)
+        return None, None, None
+
+
 def _reduce_ws(C_, dev):
     """workspace for the two-stage column reductions (per-block partials)"""
     return torch.empty(H.lib.evk_colreduce_ws_bytes(C_) // 4, dtype=F32, device=dev)
@@ -129,7 +189,7 @@ class _BatchNorm(torch.autograd.Function):
         M = x.numel() // Cc
         dev = x.device
         st = H.stream()
-        stats = _z(6, Cc, dtype=F32, device=dev)          # sum, sumsq, scale, shift, mean, invstd
+        stats = _e(6, Cc, dtype=F32, device=dev)          # sum, sumsq, scale, shift, mean, invstd (all written by the kernels)
         if training:
             ws = _reduce_ws(Cc, dev)
             H.check(H.lib.evk_bn_stats(H.ptr(x), H.ptr(stats[0]), H.ptr(stats[1]), H.ptr(ws), ws.numel() * 4, M, Cc, st), 'bn_stats')
@@ -152,11 +212,12 @@ class _BatchNorm(torch.autograd.Function):
         dz = dz.contiguous()
         sums = _e(2, Cc, dtype=F32, device=dev)
         ws = _reduce_ws(Cc, dev)
-        H.check(H.lib.evk_bn_bwd_reduce(H.ptr(dz), H.ptr(z), H.ptr(x), H.ptr(stats[4]), H.ptr(stats[5]), H.ptr(sums[0]),
-                                        H.ptr(sums[1]), H.ptr(ws), ws.numel() * 4, M, Cc, int(relu), st), 'bn_bwd_reduce')
-        if gamma is not None and gamma.requires_grad:
-            grad_buffer(gamma).add_(sums[1])
-            grad_buffer(beta).add_(sums[0])
+        affine = gamma is not None and gamma.requires_grad
+        H.check(H.lib.evk_bn_bwd_reduce_acc(H.ptr(dz), H.ptr(z), H.ptr(x), H.ptr(stats[4]), H.ptr(stats[5]), H.ptr(sums[0]),
+                                            H.ptr(sums[1]), H.ptr(grad_buffer(beta)) if affine else None,
+                                            H.ptr(grad_buffer(gamma)) if affine else None, H.ptr(ws), ws.numel() * 4, M, Cc,
+                                            int(relu), st), 'bn_bwd_reduce')
+        if affine:
             grad_done(gamma)
             grad_done(beta)
         dx = _e(*x.shape, device=dev)
@@ -296,16 +357,30 @@ class ResNetTrunk(nn.Sequential):
             mods.append(nn.Sequential(*layer))
         super().__init__(*mods)
 
-    def forward(self, images):
-        """images f32 NCHW on the GPU -> NHWC bf16 feature map (N, h, w, 2048)."""
-        assert images.dtype == F32 and images.is_cuda and images.dim() == 4 and images.shape[1] == 3
-        x = _Stem.apply(images.contiguous(), self[0].weight)
-        x = self[1](x, relu=True)
-        x = _MaxPool.apply(x)
+    def pairs(self):
+        """(conv, bn) holders in the order of the native runner's `layers` array (torchvision state_dict order)."""
+        out = [(self[0], self[1])]
         for li in range(4, 8):
             for blk in self[li]:
-                x = blk(x)
-        return x
+                out += [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2), (blk.conv3, blk.bn3)]
+                if blk.downsample is not None:
+                    out.append((blk.downsample[0], blk.downsample[1]))
+        return out
+
+    def native_cfg(self):
+        cfg = H.TrunkCfg()
+        for i, (planes, blocks, stride) in enumerate(RESNET_LAYERS):
+            cfg.blocks[i], cfg.planes[i], cfg.stride[i] = blocks, planes, stride
+        cfg.eps, cfg.momentum = self[1].eps, self[1].momentum
+        return cfg
+
+    def forward(self, images):
+        """images f32 NCHW on the GPU -> NHWC bf16 feature map (N, h, w, 2048); the whole trunk is ONE autograd node whose
+        forward / backward are single calls into the native runner (csrc/trunk.hip)."""
+        assert images.dtype == F32 and images.is_cuda and images.dim() == 4 and images.shape[1] == 3
+        if self.training:
+            torch._foreach_add_([bn.num_batches_tracked for _, bn in self.pairs()], 1)
+        return _TrunkFn.apply(images.contiguous(), self[0].weight, self)
 
 
 class ResNet(nn.Module):

@@ -90,6 +90,8 @@ int64_t evk_gemm_workspace_bytes(const evk_gemm* desc);   /* 0 when no workspace
  * fwd:   y[N,Ho,Wo,Co]      dgrad: dx[N,Hi,Wi,Ci]      wgrad: dw[Co,KH,KW,Ci] (f32, accumulated)       */
 int evk_conv2d_fwd(const void* x, const void* w, void* y, const evk_conv_geom* g, evk_stream_t stream);
 int evk_conv2d_dgrad(const void* dy, const void* w, void* dx, const evk_conv_geom* g, evk_stream_t stream);
+/* dx = dgrad(dy, w) + resid (bf16, shape of dx): the skip-connection gradient of a residual block joins in the epilogue */
+int evk_conv2d_dgrad_add(const void* dy, const void* w, const void* resid, void* dx, const evk_conv_geom* g, evk_stream_t stream);
 int evk_conv2d_wgrad(const void* dy, const void* x, float* dw, const evk_conv_geom* g, void* ws, int64_t ws_bytes, evk_stream_t stream);
 int64_t evk_conv2d_wgrad_ws_bytes(const evk_conv_geom* g);
 
@@ -101,6 +103,34 @@ int evk_stem_unpack_wgrad(const float* dw_packed, float* dw_oihw, evk_stream_t s
 int evk_stem_fwd(const void* xpad, const void* w_packed, void* y, int32_t N, int32_t H, int32_t W, evk_stream_t stream);
 int evk_stem_wgrad(const void* dy, const void* xpad, float* dw_packed, int32_t N, int32_t H, int32_t W, void* ws, int64_t ws_bytes, evk_stream_t stream);
 int64_t evk_stem_wgrad_ws_bytes(int32_t N, int32_t H, int32_t W);
+
+/* ---- native runner of the ResNet bottleneck trunk (trunk.hip) -------------------------------------------------
+ * replaces: the Python module walk over torchvision resnet101 children 0-7 (modules/visual_extractor.py:27-43,
+ * patch_feats = self.model(images)) and autograd's backward over it: one call per direction issues every conv /
+ * batch-norm / pooling kernel of the trunk from C++.  `layers` lists the conv+BN pairs in torchvision state_dict order:
+ * [0] conv1+bn1 (the 7x7 stem), then per bottleneck conv1+bn1, conv2+bn2, conv3+bn3 and, for the first block of each
+ * layer, downsample.0+downsample.1.                                                                               */
+typedef struct evk_trunk_cfg {
+  int32_t blocks[4];             /* bottlenecks per layer (resnet101: 3, 4, 23, 3)                                */
+  int32_t planes[4];             /* bottleneck width per layer (64, 128, 256, 512); outputs are 4 x planes        */
+  int32_t stride[4];             /* stride of the first block of each layer (1, 2, 2, 2)                          */
+  float eps, momentum;           /* batch-norm epsilon and running-statistics momentum                           */
+} evk_trunk_cfg;
+typedef struct evk_trunk_layer {
+  const void* w;                 /* bf16 KRSC conv weight; [0]: the f32 OIHW master weight of the 7x7 stem        */
+  float* dw;                     /* f32 gradient to accumulate into (layout of the master weight), NULL = frozen  */
+  const float* gamma; const float* beta; float* running_mean; float* running_var;
+  float* dgamma; float* dbeta;   /* f32 gradients to accumulate into, or NULL                                     */
+} evk_trunk_layer;
+int evk_trunk_num_pairs(const evk_trunk_cfg* cfg);
+int64_t evk_trunk_ws_bytes(const evk_trunk_cfg* cfg, int32_t N, int32_t H, int32_t W);   /* -1 on bad arguments */
+/* images f32 NCHW [N][3][H][W] -> out bf16 NHWC [N][H/32][W/32][4*planes[3]]; ws keeps what the backward needs */
+int evk_trunk_forward(const evk_trunk_cfg* cfg, const evk_trunk_layer* layers, int32_t n_layers, const float* images, int32_t N,
+                      int32_t H, int32_t W, void* ws, int64_t ws_bytes, void* out, int32_t training, evk_stream_t stream);
+/* dout bf16 (shape of out); parameter gradients are accumulated in place; weight-gradient GEMMs run on wgrad_stream
+ * (ordered after their inputs by events; pass NULL or `stream` to keep everything on one stream)                 */
+int evk_trunk_backward(const evk_trunk_cfg* cfg, const evk_trunk_layer* layers, int32_t n_layers, int32_t N, int32_t H, int32_t W,
+                       void* ws, int64_t ws_bytes, const void* dout, int32_t training, evk_stream_t stream, evk_stream_t wgrad_stream);
 
 /* ---- row-wise kernels (norm.hip): one wavefront per row, shuffle reductions ----------------------------
  * LayerNorm family.  mode 0 = torch.nn.LayerNorm (biased variance, eps inside the sqrt; bert_model.py:355,433,
@@ -153,6 +183,9 @@ int evk_bn_apply(const void* x, const float* scale, const float* shift, const vo
                  int32_t relu, evk_stream_t stream);
 int evk_bn_bwd_reduce(const void* dz, const void* z, const void* x, const float* mean, const float* invstd, float* sum_g,
                       float* sum_gx, void* ws, int64_t ws_bytes, int64_t M, int32_t C, int32_t relu, evk_stream_t stream);
+int evk_bn_bwd_reduce_acc(const void* dz, const void* z, const void* x, const float* mean, const float* invstd, float* sum_g,
+                          float* sum_gx, float* dbeta_acc, float* dgamma_acc, void* ws, int64_t ws_bytes, int64_t M, int32_t C,
+                          int32_t relu, evk_stream_t stream);   /* + accumulates the affine gradients in place */
 int evk_bn_bwd_apply(const void* dz, const void* z, const void* x, const float* scale, const float* mean, const float* invstd,
                      const float* sum_g, const float* sum_gx, void* dx, void* dres, int64_t M, int32_t C, int32_t relu,
                      evk_stream_t stream);
