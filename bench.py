@@ -210,14 +210,30 @@ def main():
     t0 = time.perf_counter()
     losses = []
     for i in range(a.steps):
-        if not a.no_prof and i == a.steps - 1:
-            H.prof_enable(True)           # HIP-event pairs around every launch of the LAST timed step only (they cost host time)
         losses.append(step())
     host_dt = time.perf_counter() - t0
     barrier()
     dt = time.perf_counter() - t0
     fam, launched_flops = ({}, 0.0)
     if not a.no_prof:
+        # Per-kernel durations for the roofline: ONE more step of the same workload right after the timed region, with a
+        # HIP-event pair around every launch (on the launch's own stream) and the side streams folded into the main one --
+        # concurrent kernels share the CUs, which would inflate every event-timed duration, and the ~6k event records
+        # cost ~15 ms of host time that must not sit inside the timed steps.
+        # The step is enqueued behind a bounded GPU-side spin (torch.cuda._sleep, ~1.5 steps long) so that every launch and
+        # event is already queued when the GPU reaches it: the event pairs then time kernels, not host launch latency.
+        ops.SIDE_STREAMS_ENABLED[0] = False
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        torch.cuda._sleep(20_000_000)
+        e1.record()
+        torch.cuda.synchronize()
+        cyc_per_ms = 20_000_000 / max(e0.elapsed_time(e1), 1e-3)
+        torch.cuda._sleep(int(cyc_per_ms * min(400.0, 1.5e3 * dt / a.steps + 30.0)))
+        H.prof_enable(True)
+        step()
+        barrier()
+        ops.SIDE_STREAMS_ENABLED[0] = True
         if a.dump_launches:
             H._dump_path = a.dump_launches.encode()
             H.check(H.lib.evk_prof_dump_to(H._dump_path))
@@ -242,12 +258,12 @@ def main():
     if fam:
         ms, n = fam['gemm']
         alg = ALG_GFLOP_PER_STUDY.get((kind, a.res))
-        psteps = 1                                   # steps that carried HIP events
+        psteps = 1                                   # the extra, event-timed step
         alg_flops = (alg * 1e9 * a.batch * psteps) if alg else launched_flops
         ach = alg_flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_kernel (MFMA GEMM / implicit-GEMM conv family)', 'achieved': ach,
                            'peak': MFMA_BF16_DENSE_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / MFMA_BF16_DENSE_PEAK_TFLOPS,
-                           'traffic': None, 'launches_per_step': n / psteps, 'event_timed_steps': psteps, 'avg_launch_us': 1e3 * ms / max(n, 1),
+                           'traffic': None, 'launches_per_step': n / psteps, 'event_timed': '1 extra step after the timed region, single stream', 'avg_launch_us': 1e3 * ms / max(n, 1),
                            'gemm_ms_per_step': ms / psteps, 'launched_tflops': launched_flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
                            'family_ms_per_step': {k: v[0] / psteps for k, v in fam.items()}}
     if world == 1 and not a.no_cpu_baseline:

@@ -41,6 +41,10 @@ def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
 def fnv1a64(s):
     h = 0xcbf29ce484222325
     for ch in str(s).encode('utf-8'):

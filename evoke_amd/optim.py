@@ -85,6 +85,53 @@ class FusedOptimizer(torch.optim.Optimizer):
     def _on_grad(self, p):
         self._touched.add(id(p))
 
+    # ---- torch.optim-format state (what the reference checkpoints with `optimizer.state_dict()`, trainer_v0401.py:160-189)
+    def state_dict(self):
+        state, groups, idx = {}, [], 0
+        for g, st in zip(self.param_groups, self.flat):
+            ids = []
+            for p, o in zip(g['params'], st['offsets']):
+                k = self._pstep.get(id(p), 0)
+                if k > 0:
+                    n = p.numel()
+                    ent = {'step': torch.tensor(float(k)),
+                           'exp_avg': _view_like(st['m'][o:o + n], p).detach().clone(memory_format=torch.contiguous_format),
+                           'exp_avg_sq': _view_like(st['v'][o:o + n], p).detach().clone(memory_format=torch.contiguous_format)}
+                    if st['vmax'] is not None:
+                        ent['max_exp_avg_sq'] = _view_like(st['vmax'][o:o + n], p).detach().clone(memory_format=torch.contiguous_format)
+                    state[idx] = ent
+                ids.append(idx)
+                idx += 1
+            hp = {k: v for k, v in g.items() if k != 'params'}
+            hp['params'] = ids
+            groups.append(hp)
+        return {'state': state, 'param_groups': groups}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd):
+        if len(sd['param_groups']) != len(self.param_groups):
+            raise ValueError('loaded state dict has a different number of parameter groups')
+        self._pstep = {}
+        for g, st, lg in zip(self.param_groups, self.flat, sd['param_groups']):
+            if len(lg['params']) != len(g['params']):
+                raise ValueError("loaded state dict contains a parameter group that doesn't match the size of optimizer's group")
+            for k, v in lg.items():
+                if k != 'params':
+                    g[k] = v
+            for p, o, idx in zip(g['params'], st['offsets'], lg['params']):
+                n = p.numel()
+                ent = sd['state'].get(idx)
+                for name, buf in (('exp_avg', st['m']), ('exp_avg_sq', st['v']), ('max_exp_avg_sq', st['vmax'])):
+                    if buf is None:
+                        continue
+                    view = _view_like(buf[o:o + n], p)
+                    if ent is not None and name in ent:
+                        view.copy_(ent[name].to(view.device))
+                    else:
+                        view.zero_()
+                if ent is not None:
+                    self._pstep[id(p)] = int(float(ent['step']))
+
     def flat_grads(self):
         return [st['g'] for st in self.flat]
 
