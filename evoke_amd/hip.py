@@ -34,6 +34,12 @@ class Gemm(C.Structure):
                 ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64), ('g', ConvGeom)]
 
 
+class PreprocDesc(C.Structure):
+    _fields_ = [('src', C.c_void_p), ('src_h', C.c_int32), ('src_w', C.c_int32), ('channels', C.c_int32), ('resize_h', C.c_int32),
+                ('resize_w', C.c_int32), ('crop_top', C.c_int32), ('crop_left', C.c_int32), ('out_size', C.c_int32),
+                ('flip', C.c_int32), ('rotate', C.c_int32), ('affine', C.c_int32 * 6), ('mean', C.c_float * 3), ('std', C.c_float * 3)]
+
+
 class TrunkCfg(C.Structure):
     _fields_ = [('blocks', C.c_int32 * 4), ('planes', C.c_int32 * 4), ('stride', C.c_int32 * 4), ('eps', C.c_float),
                 ('momentum', C.c_float)]

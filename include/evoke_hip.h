@@ -104,6 +104,24 @@ int evk_stem_fwd(const void* xpad, const void* w_packed, void* y, int32_t N, int
 int evk_stem_wgrad(const void* dy, const void* xpad, float* dw_packed, int32_t N, int32_t H, int32_t W, void* ws, int64_t ws_bytes, evk_stream_t stream);
 int64_t evk_stem_wgrad_ws_bytes(int32_t N, int32_t H, int32_t W);
 
+/* ---- input pipeline: image pre-processing on the GPU (preproc.hip) --------------------------------------------
+ * replaces, per image: the torchvision transform stack applied inside collate_fn (modules/dataloaders_v0623.py:22-37,
+ * 89-92; modules/dataloaders_v0401.py:25-37): Resize (Pillow antialiased bilinear, two 8-bit passes) -> RandomCrop /
+ * CenterCrop -> [RandomHorizontalFlip] -> [RandomRotation, nearest, fill 0] -> ToTensor -> Normalize.  The random
+ * parameters are drawn by the caller; `affine` holds Pillow's 16.16 fixed-point inverse map (evoke_amd/pipeline.py).  */
+typedef struct evk_preproc_desc {
+  const void* src;               /* uint8 pixels [src_h][src_w][channels] in device memory                        */
+  int32_t src_h, src_w, channels;/* channels: 3 (RGB) or 1 (grey, replicated like PIL .convert('RGB'))            */
+  int32_t resize_h, resize_w;    /* size after transforms.Resize                                                  */
+  int32_t crop_top, crop_left, out_size;   /* square crop window inside the resized image                         */
+  int32_t flip;                  /* horizontal flip of the crop                                                   */
+  int32_t rotate;                /* 0: no rotation; 1: apply `affine` (a0..a5 of Pillow's affine_fixed)           */
+  int32_t affine[6];
+  float mean[3], std[3];
+} evk_preproc_desc;
+int64_t evk_preprocess_ws_bytes(const evk_preproc_desc* d);          /* -1 on a bad descriptor */
+int evk_preprocess_image(const evk_preproc_desc* d, void* ws, int64_t ws_bytes, float* out, evk_stream_t stream); /* out f32 [3][S][S] */
+
 /* ---- native runner of the ResNet bottleneck trunk (trunk.hip) -------------------------------------------------
  * replaces: the Python module walk over torchvision resnet101 children 0-7 (modules/visual_extractor.py:27-43,
  * patch_feats = self.model(images)) and autograd's backward over it: one call per direction issues every conv /
