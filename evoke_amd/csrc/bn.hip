@@ -352,6 +352,16 @@ int evk_bn_stats(const void* x, float* sum, float* sumsq, void* ws, int64_t ws_b
   return launch_reduce(p, sum, sumsq, ws, ws_bytes, reinterpret_cast<hipStream_t>(stream));
 }
 
+// second stage alone: sum / sumsq from the partial rows a convolution epilogue wrote (evk_conv2d_fwd_stats)
+int evk_bn_stats_from_partials(const float* part, int32_t nblk, float* sum, float* sumsq, int32_t C, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(part && sum && sumsq && nblk > 0 && C > 0, "bn_stats_from_partials: bad args");
+  ProfScope ps(EVK_FAM_REDUCE, s);
+  hipLaunchKernelGGL(colreduce_final_kernel, dim3((int)cdiv(2 * C, 16)), dim3(256), 0, s, part, sum, sumsq, (float*)nullptr,
+                     (float*)nullptr, (int)nblk, (int)C);
+  return evk_check_launch("bn_stats_from_partials");
+}
+
 int evk_bn_finalize(const float* sum, const float* sumsq, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float* scale, float* shift, float* mean, float* invstd, int32_t C, float count,
                     float momentum, float eps, int32_t training, evk_stream_t stream) {

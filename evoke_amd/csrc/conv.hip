@@ -67,8 +67,24 @@ void stem_geom(evk_conv_geom* g, int N, int H, int W) {
 extern "C" {
 
 int evk_conv2d_fwd(const void* x, const void* w, void* y, const evk_conv_geom* g, evk_stream_t stream) {
+  return evk_conv2d_fwd_stats(x, w, y, g, nullptr, 0, nullptr, stream);
+}
+
+// rows of per-64-row-block partial statistics the GEMM epilogue writes for an M-row output
+static int stats_rows(int M, int N) { return N <= 64 ? (int)((M + 255) / 256) * 4 : (int)((M + 127) / 128) * 2; }
+
+int64_t evk_conv_stats_bytes(int64_t M, int32_t C) { return (int64_t)stats_rows((int)M, C) * 2 * C * (int64_t)sizeof(float); }
+
+int evk_conv2d_fwd_stats(const void* x, const void* w, void* y, const evk_conv_geom* g, float* part, int64_t part_bytes,
+                         int32_t* nblk, evk_stream_t stream) {
   if (int e = check_geom(g)) return e;
   evk_gemm d{};
+  if (part) {
+    const int M = g->N * g->Ho * g->Wo;
+    EVK_REQUIRE(nblk && part_bytes >= evk_conv_stats_bytes(M, g->Co), "conv fwd: statistics buffer too small");
+    *nblk = stats_rows(M, g->Co);
+    d.colstats = part;
+  }
   d.A = x; d.B = w; d.C = y;
   d.M = g->N * g->Ho * g->Wo; d.N = g->Co; d.K = g->KH * g->KW * g->Ci;
   d.a_mode = is_pointwise(g) ? EVK_A_PLAIN : EVK_A_CONV; d.b_mode = EVK_B_PLAIN;
@@ -155,8 +171,19 @@ int evk_stem_unpack_wgrad(const float* dwp, float* dw, evk_stream_t stream) {
 }
 
 int evk_stem_fwd(const void* xpad, const void* wp, void* y, int32_t N, int32_t H, int32_t W, evk_stream_t stream) {
+  return evk_stem_fwd_stats(xpad, wp, y, N, H, W, nullptr, 0, nullptr, stream);
+}
+
+int evk_stem_fwd_stats(const void* xpad, const void* wp, void* y, int32_t N, int32_t H, int32_t W, float* part, int64_t part_bytes,
+                       int32_t* nblk, evk_stream_t stream) {
   EVK_REQUIRE(H % 2 == 0 && W % 2 == 0, "stem: H and W must be even");
   evk_gemm d{};
+  if (part) {
+    const int64_t M = (int64_t)N * (H / 2) * (W / 2);
+    EVK_REQUIRE(nblk && part_bytes >= evk_conv_stats_bytes(M, 64), "stem fwd: statistics buffer too small");
+    *nblk = stats_rows((int)M, 64);
+    d.colstats = part;
+  }
   stem_geom(&d.g, N, H, W);
   d.A = xpad; d.B = wp; d.C = y;
   d.M = N * d.g.Ho * d.g.Wo; d.N = 64; d.K = 224;

@@ -29,6 +29,7 @@ struct GemmP {
   long sAo, sAi, sBo, sBi, sCo, sCi, sRo, sRi;
   float alpha; int act, c_f32, r_f32, accumulate, vec_ok;
   int ksteps_per_split, tilesN, kslice_xcd;
+  float* colstats;                  // per 64-row block partial column sums / sums of squares [row block][2][N] (or null)
   float* slab; long slab_mn;        // split-K partial slabs [z][split][M][N] f32 (accumulate mode with splitk > 1)
   int b_klog, b_kmask; long b_tapstride;
   // gather geometry
@@ -320,10 +321,51 @@ template <int ROWS> struct LoaderSel<ROWS, EVK_B_PLAIN, false> { using T = RowLo
 template <int ROWS> struct LoaderSel<ROWS, EVK_B_KSTR, false> { using T = KstrLoader<ROWS, 0>; static constexpr bool KS = true; };
 template <int ROWS> struct LoaderSel<ROWS, EVK_B_WGATHER, false> { using T = KstrLoader<ROWS, 1>; static constexpr bool KS = true; };
 
+// sum over the 16 lanes of a DPP row (lanes sharing lane >> 4); every lane of the row ends up with the total
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true);
+  return v + __builtin_bit_cast(float, t);
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v = dpp_add<0xB1>(v);     // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);     // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);    // row_half_mirror
+  return dpp_add<0x140>(v); // row_mirror
+}
+
 // ---- epilogue shared by the GEMM kernels: lane holds C[m][n0..n0+3], m = ..+(lane&15), n0 = ..+(lane>>4)*4 ----
 template <int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[4][4], int tm, int tn, int wm, int wn, int frow, int fq,
                                               int zo, int zi, int by, int bz) {
+  if (p.colstats) {
+    // Batch-norm statistics of a convolution output, taken from the f32 accumulators: every wave reduces its 64 rows
+    // (4 in-lane sub-tiles, then the 16 lanes of a DPP row) and writes one partial row [2][N]; rows beyond M are zero
+    // because their A rows were zero-filled.  bn.hip's final stage sums the partials.
+    float* prow = p.colstats + ((long)(tm * (TM / 64) + wm)) * 2 * p.N;
+#pragma unroll
+    for (int in = 0; in < 4; ++in) {
+      float sm[4], sq[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int im = 0; im < 4; ++im) { const float v = acc[in][im][j] * p.alpha; a += v; b += v * v; }
+        sm[j] = row16_sum(a);
+        sq[j] = row16_sum(b);
+      }
+      const int n0 = tn * TN + wn * 64 + in * 16 + fq * 4;
+      if (frow == 0 && n0 < p.N) {
+        if ((p.N & 3) == 0) {
+          *reinterpret_cast<float4*>(prow + n0) = make_float4(sm[0], sm[1], sm[2], sm[3]);
+          *reinterpret_cast<float4*>(prow + p.N + n0) = make_float4(sq[0], sq[1], sq[2], sq[3]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (n0 + j < p.N) { prow[n0 + j] = sm[j]; prow[p.N + n0 + j] = sq[j]; }
+        }
+      }
+    }
+  }
   char* Cb = reinterpret_cast<char*>(p.C) + (zo * p.sCo + zi * p.sCi) * (p.c_f32 ? 4 : 2);
   const char* Rb = p.resid ? reinterpret_cast<const char*>(p.resid) + (zo * p.sRo + zi * p.sRi) * (p.r_f32 ? 4 : 2) : nullptr;
 #pragma unroll
@@ -903,6 +945,8 @@ extern "C" int evk_gemm_launch(const evk_gemm* d, evk_stream_t stream) {
   p.sAo = d->sAo; p.sAi = d->sAi; p.sBo = d->sBo; p.sBi = d->sBi; p.sCo = d->sCo; p.sCi = d->sCi; p.sRo = d->sRo; p.sRi = d->sRi;
   p.alpha = d->alpha; p.act = d->act; p.c_f32 = d->c_dtype == EVK_F32; p.r_f32 = d->r_dtype == EVK_F32;
   p.accumulate = d->accumulate;
+  p.colstats = reinterpret_cast<float*>(d->colstats);
+  EVK_REQUIRE(!p.colstats || (!p.accumulate && d->batch_outer * d->batch_inner == 1), "evk_gemm: colstats needs batch 1 and no accumulate");
   EVK_REQUIRE(!p.accumulate || (p.c_f32 && !d->bias && !d->resid && d->act == EVK_ACT_NONE),
               "evk_gemm: accumulate needs f32 C and no bias/resid/act");
   const int esz = p.c_f32 ? 4 : 2;
@@ -950,7 +994,7 @@ extern "C" int evk_gemm_launch(const evk_gemm* d, evk_stream_t stream) {
   ProfScope ps(EVK_FAM_GEMM, s, flops);
   const int am = d->a_mode, bm = d->b_mode;
   if (am == EVK_A_PLAIN && bm == EVK_B_PLAIN && batch == 1 && !p.accumulate && d->K % SK_KC == 0 &&
-      cdiv(d->M, 128) * cdiv(d->N, 128) < 48 && d->M <= 1024)
+      cdiv(d->M, 128) * cdiv(d->N, 128) < 48 && d->M <= 1024 && !d->colstats)
     return launch_skinny(p, s);
   if (am == EVK_A_PLAIN && bm == EVK_B_PLAIN) return launch_modes<EVK_A_PLAIN, EVK_B_PLAIN>(p, batch, d->splitk, d->workspace, d->workspace_bytes, d, s);
   if (am == EVK_A_CONV && bm == EVK_B_PLAIN) return launch_modes<EVK_A_CONV, EVK_B_PLAIN>(p, batch, d->splitk, d->workspace, d->workspace_bytes, d, s);

@@ -22,8 +22,8 @@ struct Plan {
   std::vector<Pair> pairs;  // [0] stem, then per block conv1, conv2, conv3, (downsample)
   std::vector<int> has_down;  // per block
   int N, H, W;
-  long xpad, wp, dwp, pooled, red, slab, zeros, gbuf[6];
-  long gcap, slab_bytes, red_bytes;
+  long xpad, wp, dwp, pooled, red, slab, zeros, part, gbuf[6];
+  long gcap, slab_bytes, red_bytes, part_bytes;
   long total;
 };
 
@@ -45,13 +45,14 @@ int make_plan(const evk_trunk_cfg* cfg, int N, int H, int W, Plan& P) {
   P.xpad = take((long)N * (H + 6) * (W + 8) * 4 * 2);
   P.wp = take(64 * 224 * 2);
   P.dwp = take(64 * 224 * 4);
-  long gcap = 0, slab = evk_stem_wgrad_ws_bytes(N, H, W);
+  long gcap = 0, slab = evk_stem_wgrad_ws_bytes(N, H, W), part = 0;
   auto add_pair = [&](const evk_conv_geom& g, int C, long M) {
     Pair pr{};
     pr.g = g; pr.C = C; pr.M = M;
     pr.y = take(M * C * 2); pr.z = take(M * C * 2); pr.stats = take(6L * C * 4);
     pr.dy = take(M * C * 2); pr.sums = take(2L * C * 4);
     if (M * C * 2 > gcap) gcap = M * C * 2;
+    if (evk_conv_stats_bytes(M, C) > part) part = evk_conv_stats_bytes(M, C);
     P.pairs.push_back(pr);
   };
   int h = H / 2, w = W / 2;
@@ -92,6 +93,8 @@ int make_plan(const evk_trunk_cfg* cfg, int N, int H, int W, Plan& P) {
   P.slab_bytes = slab;
   P.slab = take(slab);
   P.zeros = take(2 * 2048 * 4);
+  P.part_bytes = part;
+  P.part = take(part);
   P.total = off;
   return EVK_OK;
 }
@@ -104,12 +107,12 @@ struct Ctx {
 };
 
 // y = conv(x), batch statistics / running statistics -> scale, shift; z = relu?(y * scale + shift + resid)
-int bn_forward(const Ctx& c, int i, const void* resid, int relu) {
+int bn_forward(const Ctx& c, int i, const void* resid, int relu, int nblk) {
   const Pair& pr = c.P->pairs[i];
   const evk_trunk_layer& l = c.L[i];
   float* st = c.at<float>(pr.stats);
   const int C = pr.C;
-  if (c.training) TRY(evk_bn_stats(c.at(pr.y), st, st + C, c.at(c.P->red), c.P->red_bytes, pr.M, C, c.s));
+  if (c.training) TRY(evk_bn_stats_from_partials(c.at<float>(c.P->part), nblk, st, st + C, C, c.s));   // the conv epilogue left the partial sums
   TRY(evk_bn_finalize(st, st + C, l.gamma, l.beta, l.running_mean, l.running_var, st + 2 * C, st + 3 * C, st + 4 * C, st + 5 * C, C,
                       (float)pr.M, c.cfg->momentum, c.cfg->eps, c.training, c.s));
   return evk_bn_apply(c.at(pr.y), st + 2 * C, st + 3 * C, resid, c.at(pr.z), pr.M, C, relu, c.s);
@@ -187,11 +190,19 @@ int evk_trunk_forward(const evk_trunk_cfg* cfg, const evk_trunk_layer* layers, i
   hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
   if (hipMemsetAsync(c.at(P.zeros), 0, 2 * 2048 * 4, hs) != hipSuccess) { evk_set_error("trunk: memset failed"); return EVK_ELAUNCH; }
 
+  // conv + (training) batch statistics in its epilogue, then BN finalize + apply
+  float* part = training ? c.at<float>(P.part) : nullptr;
+  int nblk = 0;
+  auto conv_bn = [&](int i, const void* xin, const void* resid, int relu) -> int {
+    TRY(evk_conv2d_fwd_stats(xin, layers[i].w, c.at(P.pairs[i].y), &P.pairs[i].g, part, P.part_bytes, &nblk, stream));
+    return bn_forward(c, i, resid, relu, nblk);
+  };
+
   // stem: pack, conv 7x7 s2, BN + ReLU, max-pool 3x3 s2
   TRY(evk_stem_pack_image(images, c.at(P.xpad), N, H, W, stream));
   TRY(evk_stem_pack_weight(reinterpret_cast<const float*>(layers[0].w), c.at(P.wp), stream));
-  TRY(evk_stem_fwd(c.at(P.xpad), c.at(P.wp), c.at(P.pairs[0].y), N, H, W, stream));
-  TRY(bn_forward(c, 0, nullptr, 1));
+  TRY(evk_stem_fwd_stats(c.at(P.xpad), c.at(P.wp), c.at(P.pairs[0].y), N, H, W, part, P.part_bytes, &nblk, stream));
+  TRY(bn_forward(c, 0, nullptr, 1, nblk));
   TRY(evk_maxpool3x3s2_fwd(c.at(P.pairs[0].z), c.at(P.pooled), N, H / 2, W / 2, 64, stream));
 
   const void* x = c.at(P.pooled);
@@ -200,16 +211,12 @@ int evk_trunk_forward(const evk_trunk_cfg* cfg, const evk_trunk_layer* layers, i
     const bool down = P.has_down[b];
     const void* idt = x;
     if (down) {
-      TRY(evk_conv2d_fwd(x, layers[i + 3].w, c.at(P.pairs[i + 3].y), &P.pairs[i + 3].g, stream));
-      TRY(bn_forward(c, i + 3, nullptr, 0));
+      TRY(conv_bn(i + 3, x, nullptr, 0));
       idt = c.at(P.pairs[i + 3].z);
     }
-    TRY(evk_conv2d_fwd(x, layers[i].w, c.at(P.pairs[i].y), &P.pairs[i].g, stream));
-    TRY(bn_forward(c, i, nullptr, 1));
-    TRY(evk_conv2d_fwd(c.at(P.pairs[i].z), layers[i + 1].w, c.at(P.pairs[i + 1].y), &P.pairs[i + 1].g, stream));
-    TRY(bn_forward(c, i + 1, nullptr, 1));
-    TRY(evk_conv2d_fwd(c.at(P.pairs[i + 1].z), layers[i + 2].w, c.at(P.pairs[i + 2].y), &P.pairs[i + 2].g, stream));
-    TRY(bn_forward(c, i + 2, idt, 1));
+    TRY(conv_bn(i, x, nullptr, 1));
+    TRY(conv_bn(i + 1, c.at(P.pairs[i].z), nullptr, 1));
+    TRY(conv_bn(i + 2, c.at(P.pairs[i + 1].z), idt, 1));
     x = c.at(P.pairs[i + 2].z);
     i += down ? 4 : 3;
   }

@@ -66,6 +66,8 @@ typedef struct evk_gemm {
   int32_t b_klog; int64_t b_tapstride;   /* EVK_B_KSTR two-level K (see enum)                           */
   void* workspace; int64_t workspace_bytes; /* accumulate + split-K: partial slabs (evk_gemm_workspace_bytes);
                                             without it split-K falls back to f32 atomics                  */
+  void* colstats;                /* optional f32 [ceil(M/64) (rounded to the tile)][2][N]: per 64-row block column sums and
+                                    sums of squares of alpha*A.B, from the f32 accumulators (batch 1, no accumulate)  */
   evk_conv_geom g;               /* used by the gather modes                                            */
 } evk_gemm;
 
@@ -89,6 +91,11 @@ int64_t evk_gemm_workspace_bytes(const evk_gemm* desc);   /* 0 when no workspace
 /* NHWC bf16 convolution, weights KRSC bf16 ([Co][KH][KW][Ci]); y = conv(x, w) [+ nothing]: BN is separate.
  * fwd:   y[N,Ho,Wo,Co]      dgrad: dx[N,Hi,Wi,Ci]      wgrad: dw[Co,KH,KW,Ci] (f32, accumulated)       */
 int evk_conv2d_fwd(const void* x, const void* w, void* y, const evk_conv_geom* g, evk_stream_t stream);
+/* fwd + batch-norm statistics in the epilogue: part receives *nblk rows of [2][Co] partial sums (sum, sum of squares) of
+ * the f32 conv result, to be finished by evk_bn_stats_from_partials (replaces a separate read of y for BN's batch stats) */
+int64_t evk_conv_stats_bytes(int64_t M, int32_t C);
+int evk_conv2d_fwd_stats(const void* x, const void* w, void* y, const evk_conv_geom* g, float* part, int64_t part_bytes,
+                         int32_t* nblk, evk_stream_t stream);
 int evk_conv2d_dgrad(const void* dy, const void* w, void* dx, const evk_conv_geom* g, evk_stream_t stream);
 /* dx = dgrad(dy, w) + resid (bf16, shape of dx): the skip-connection gradient of a residual block joins in the epilogue */
 int evk_conv2d_dgrad_add(const void* dy, const void* w, const void* resid, void* dx, const evk_conv_geom* g, evk_stream_t stream);
@@ -101,6 +108,8 @@ int evk_stem_pack_image(const float* img_nchw, void* xpad, int32_t N, int32_t H,
 int evk_stem_pack_weight(const float* w_oihw, void* w_packed, evk_stream_t stream);        /* [64][7][8][4] bf16 */
 int evk_stem_unpack_wgrad(const float* dw_packed, float* dw_oihw, evk_stream_t stream);    /* += into OIHW grad  */
 int evk_stem_fwd(const void* xpad, const void* w_packed, void* y, int32_t N, int32_t H, int32_t W, evk_stream_t stream);
+int evk_stem_fwd_stats(const void* xpad, const void* w_packed, void* y, int32_t N, int32_t H, int32_t W, float* part, int64_t part_bytes,
+                       int32_t* nblk, evk_stream_t stream);
 int evk_stem_wgrad(const void* dy, const void* xpad, float* dw_packed, int32_t N, int32_t H, int32_t W, void* ws, int64_t ws_bytes, evk_stream_t stream);
 int64_t evk_stem_wgrad_ws_bytes(int32_t N, int32_t H, int32_t W);
 
@@ -194,6 +203,7 @@ int evk_softce(const float* z, const float* t, float* loss_acc, float* dz, const
 /* column reductions are two-stage (per-block partials in `ws`, then a final sum): deterministic, no atomics */
 int64_t evk_colreduce_ws_bytes(int32_t C);
 int evk_bn_stats(const void* x, float* sum, float* sumsq, void* ws, int64_t ws_bytes, int64_t M, int32_t C, evk_stream_t stream);
+int evk_bn_stats_from_partials(const float* part, int32_t nblk, float* sum, float* sumsq, int32_t C, evk_stream_t stream);
 int evk_bn_finalize(const float* sum, const float* sumsq, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float* scale, float* shift, float* mean, float* invstd, int32_t C, float count,
                     float momentum, float eps, int32_t training, evk_stream_t stream);

@@ -303,3 +303,87 @@ def test_optim_step_matches_torch():
                                          kind, 5e-3, 0.9, 0.999, 1e-8, 1e-4, 0.1, step, H.stream()))
         close(pd, pr, 1e-5, 1e-6, 'optim kind %d' % kind)
         close(sh, pr, 1e-2, 1e-3, 'shadow')
+
+
+def test_conv_fwd_stats_and_dgrad_add():
+    """conv epilogue batch-norm statistics (evk_conv2d_fwd_stats + evk_bn_stats_from_partials) and the fused skip-gradient
+    add of the data gradient (evk_conv2d_dgrad_add) against f32 torch convolutions of the same bf16 operands."""
+    import ctypes as C
+    from evoke_amd import hip as H
+    torch.manual_seed(3)
+    for (N, Hh, Ci, Co, k, stride) in [(3, 20, 64, 128, 3, 1), (2, 24, 128, 64, 1, 1), (2, 18, 64, 256, 3, 2), (5, 12, 256, 1024, 1, 1)]:
+        g = H.conv_geom(N, Hh, Hh, Ci, Co, k, k, stride, k // 2)
+        x = (torch.randn(N, Hh, Hh, Ci, device='cuda') * 0.7).to(BF)
+        w = (torch.randn(Co, k, k, Ci, device='cuda') * 0.05).to(BF)
+        y = torch.empty(N, g.Ho, g.Wo, Co, device='cuda', dtype=BF)
+        M = N * g.Ho * g.Wo
+        nb = H.lib.evk_conv_stats_bytes(M, Co)
+        part = torch.empty(nb // 4, device='cuda')
+        nblk = C.c_int32(0)
+        H.check(H.lib.evk_conv2d_fwd_stats(H.ptr(x), H.ptr(w), H.ptr(y), C.byref(g), H.ptr(part), nb, C.byref(nblk), H.stream()))
+        st = torch.empty(2, Co, device='cuda')
+        H.check(H.lib.evk_bn_stats_from_partials(H.ptr(part), nblk.value, H.ptr(st[0]), H.ptr(st[1]), Co, H.stream()))
+        ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), stride=stride, padding=k // 2).permute(0, 2, 3, 1)
+        ref = ref.cpu()
+        close(y.float(), ref, 1e-2, 2e-2, 'conv y')
+        close(st[0], ref.reshape(-1, Co).sum(0), 2e-3, 2e-3 * float(ref.abs().sum(dim=(0, 1, 2)).max()), 'stats sum')
+        close(st[1], (ref.reshape(-1, Co) ** 2).sum(0), 2e-3, 1e-3, 'stats sumsq')
+        dy = (torch.randn(N, g.Ho, g.Wo, Co, device='cuda') * 0.3).to(BF)
+        skip = (torch.randn(N, Hh, Hh, Ci, device='cuda') * 0.3).to(BF)
+        dx = torch.empty(N, Hh, Hh, Ci, device='cuda', dtype=BF)
+        H.check(H.lib.evk_conv2d_dgrad_add(H.ptr(dy), H.ptr(w), H.ptr(skip), H.ptr(dx), C.byref(g), H.stream()))
+        xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+        torch.nn.functional.conv2d(xr, w.float().permute(0, 3, 1, 2), stride=stride, padding=k // 2).backward(dy.float().permute(0, 3, 1, 2))
+        close(dx.float(), (xr.grad.permute(0, 2, 3, 1) + skip.float()).cpu(), 2e-2, 2e-2, 'dgrad + skip')
+
+
+def test_native_trunk_matches_module_walk():
+    """evk_trunk_forward / evk_trunk_backward (one C call per direction) against the op-by-op walk over the same parameter
+    holders (conv2d / batchnorm / max-pool autograd wrappers).  Eval mode (running statistics) must agree tightly; in
+    train mode the runner takes the batch statistics from the f32 conv accumulators while the walk reduces the bf16-rounded
+    output, and the random-weight trunk amplifies that 2^-9 difference (DESIGN.md "Parity"), so only a loose bound holds."""
+    import copy
+    from evoke_amd import ops, trunk as T
+
+    def rel(x, y):
+        return float((x - y).norm() / (y.norm() + 1e-30))
+
+    def walk(b, img):
+        x = T._Stem.apply(img, b[0].weight)
+        x = b[1](x, relu=True)
+        x = T._MaxPool.apply(x)
+        for li in range(4, 8):
+            for blk in b[li]:
+                x = blk(x)
+        return x
+
+    torch.manual_seed(11)
+    ops.clear_grad_callbacks()
+    a = T.ResNetTrunk().cuda()
+    with torch.no_grad():
+        for m in a.modules():
+            if isinstance(m, T.Bottleneck):
+                m.bn3.weight.mul_(0.2)
+    img = torch.randn(4, 3, 96, 96, device='cuda')
+    dout = (torch.randn(4, 3, 3, 2048, device='cuda') * 0.1).to(BF)
+    for train, out_tol, grad_tol in ((False, 5e-3, 5e-2), (True, 0.15, None)):
+        a.train(train)
+        b = copy.deepcopy(a)
+        for p in list(a.parameters()) + list(b.parameters()):
+            p.grad = None
+        ya = a(img)
+        ya.backward(dout)
+        yb = walk(b, img)
+        yb.backward(dout)
+        ops.join_side_streams()
+        torch.cuda.synchronize()
+        e_out = rel(ya.float(), yb.float())
+        assert e_out < out_tol, (train, e_out)
+        worst = 0.0
+        for (na, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+            e = rel(pa.grad.float(), pb.grad.float())
+            worst = max(worst, e)
+            assert grad_tol is None or e < grad_tol, (train, na, e)
+        for (na, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
+            assert rel(ba.float(), bb.float()) < (0.15 if train else 1e-6), (train, na)
+        print('   native trunk vs module walk (train=%s): out %.3g, worst grad %.3g' % (train, e_out, worst))
