@@ -123,41 +123,6 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
   }
 }
 
-// relational-memory gate: gates = gw[b][1][2d] (broadcast over slots) + gu[b][s][2d];
-//   next = sigmoid(ig) * tanh(nm) + sigmoid(fg) * m          (encoder_decoder.py:282-288)
-__global__ __launch_bounds__(256) void rm_gate_fwd_kernel(const bf16_t* __restrict__ gw, const bf16_t* __restrict__ gu,
-                                                          const bf16_t* __restrict__ nm, const bf16_t* __restrict__ m,
-                                                          bf16_t* __restrict__ out, bf16_t* __restrict__ sig_i, bf16_t* __restrict__ sig_f,
-                                                          bf16_t* __restrict__ tnm, long B, int S, int D) {
-  const long total = B * S * D;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % D);
-    const long bs = i / D;
-    const long b = bs / S;
-    const float ig = bf2f(gw[b * 2 * D + c]) + bf2f(gu[bs * 2 * D + c]);
-    const float fg = bf2f(gw[b * 2 * D + D + c]) + bf2f(gu[bs * 2 * D + D + c]);
-    const float si = 1.f / (1.f + __expf(-ig)), sf = 1.f / (1.f + __expf(-fg)), t = tanhf(bf2f(nm[i]));
-    out[i] = f2bf(si * t + sf * bf2f(m[i]));
-    if (sig_i) { sig_i[i] = f2bf(si); sig_f[i] = f2bf(sf); tnm[i] = f2bf(t); }
-  }
-}
-// given dnext: dnm = dnext*si*(1-t^2); dm_direct = dnext*sf; dgates[b][s][2d] = {dnext*t*si*(1-si), dnext*m*sf*(1-sf)}
-__global__ __launch_bounds__(256) void rm_gate_bwd_kernel(const bf16_t* __restrict__ dnext, const bf16_t* __restrict__ sig_i,
-                                                          const bf16_t* __restrict__ sig_f, const bf16_t* __restrict__ tnm,
-                                                          const bf16_t* __restrict__ m, bf16_t* __restrict__ dnm, bf16_t* __restrict__ dm,
-                                                          bf16_t* __restrict__ dgates, long B, int S, int D) {
-  const long total = B * S * D;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % D);
-    const long bs = i / D;
-    const float g = bf2f(dnext[i]), si = bf2f(sig_i[i]), sf = bf2f(sig_f[i]), t = bf2f(tnm[i]);
-    dnm[i] = f2bf(g * si * (1.f - t * t));
-    dm[i] = f2bf(g * sf);
-    dgates[bs * 2 * D + c] = f2bf(g * t * si * (1.f - si));
-    dgates[bs * 2 * D + D + c] = f2bf(g * bf2f(m[i]) * sf * (1.f - sf));
-  }
-}
-
 // fused step over a flat parameter buffer: g = clamp(g, -clip, clip) ; RAdam (torch.optim.RAdam, decoupled=False)
 // or Adam with amsgrad + L2 weight decay (optimizers.py:19-21 "AdamW" == optim.Adam(amsgrad=True)); also refreshes
 // the bf16 shadow used as GEMM operand.  Hyper-parameters that depend on the step count are precomputed on the host.
@@ -257,26 +222,6 @@ int evk_colsum(const void* x, float* out, int64_t M, int32_t N, int64_t ld, evk_
   ProfScope ps(EVK_FAM_REDUCE, s);
   hipLaunchKernelGGL(colsum_kernel, dim3(bx, (int)by), dim3(256), 0, s, (const bf16_t*)x, out, (long)M, N, (long)ld, rpb);
   return evk_check_launch("colsum");
-}
-
-int evk_rm_gate_fwd(const void* gw, const void* gu, const void* nm, const void* m, void* out, void* sig_i, void* sig_f, void* tnm,
-                    int64_t B, int32_t S, int32_t D, evk_stream_t stream) {
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  EVK_REQUIRE(gw && gu && nm && m && out && B > 0 && S > 0 && D > 0, "rm_gate_fwd: bad args");
-  ProfScope ps(EVK_FAM_ELTWISE, s);
-  hipLaunchKernelGGL(rm_gate_fwd_kernel, dim3(ew_blocks(B * S * D)), dim3(256), 0, s, (const bf16_t*)gw, (const bf16_t*)gu,
-                     (const bf16_t*)nm, (const bf16_t*)m, (bf16_t*)out, (bf16_t*)sig_i, (bf16_t*)sig_f, (bf16_t*)tnm, (long)B, S, D);
-  return evk_check_launch("rm_gate_fwd");
-}
-
-int evk_rm_gate_bwd(const void* dnext, const void* sig_i, const void* sig_f, const void* tnm, const void* m, void* dnm, void* dm,
-                    void* dgates, int64_t B, int32_t S, int32_t D, evk_stream_t stream) {
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  EVK_REQUIRE(dnext && sig_i && sig_f && tnm && m && dnm && dm && dgates && B > 0, "rm_gate_bwd: bad args");
-  ProfScope ps(EVK_FAM_ELTWISE, s);
-  hipLaunchKernelGGL(rm_gate_bwd_kernel, dim3(ew_blocks(B * S * D)), dim3(256), 0, s, (const bf16_t*)dnext, (const bf16_t*)sig_i,
-                     (const bf16_t*)sig_f, (const bf16_t*)tnm, (const bf16_t*)m, (bf16_t*)dnm, (bf16_t*)dm, (bf16_t*)dgates, (long)B, S, D);
-  return evk_check_launch("rm_gate_bwd");
 }
 
 int evk_optim_step(float* p, const float* g, float* m, float* v, float* vmax, void* shadow, int64_t n, int32_t kind, float lr,

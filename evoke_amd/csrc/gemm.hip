@@ -447,7 +447,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[4][4]
 }
 
 template <int WM, int WN, int AMODE, int BMODE, bool SB>
-__global__ __launch_bounds__(NTHR) void gemm_kernel(const GemmP p) {
+__global__ __launch_bounds__(NTHR, (SB && WM == 2) ? 3 : 2) void gemm_kernel(const GemmP p) {
   constexpr int TM = 64 * WM, TN = 64 * WN;
   constexpr int TILE_BYTES = (TM + TN) * BK * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];

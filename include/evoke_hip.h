@@ -236,11 +236,6 @@ int evk_embedding_fwd(const float* table, const int64_t* ids, const float* pos, 
 int evk_embedding_bwd(const void* dout, int d_dtype, const int64_t* ids, float* dtable, int64_t rows, int32_t D, float scale,
                       int64_t padding_idx, evk_stream_t stream);
 int evk_colsum(const void* x, float* out, int64_t M, int32_t N, int64_t ld, evk_stream_t stream);
-/* RelationalMemory gate, encoder_decoder.py:282-289 */
-int evk_rm_gate_fwd(const void* gw, const void* gu, const void* nm, const void* m, void* out, void* sig_i, void* sig_f, void* tnm,
-                    int64_t B, int32_t S, int32_t D, evk_stream_t stream);
-int evk_rm_gate_bwd(const void* dnext, const void* sig_i, const void* sig_f, const void* tnm, const void* m, void* dnm, void* dm,
-                    void* dgates, int64_t B, int32_t S, int32_t D, evk_stream_t stream);
 /* fused clip_grad_value_ + optimizer step + bf16 shadow refresh over a flat buffer (trainer_v0401.py:262,434;
  * optimizers.py:17-53).  kind 0 = torch.optim.RAdam, kind 1 = torch.optim.Adam (vmax != NULL -> amsgrad)      */
 int evk_optim_step(float* p, const float* g, float* m, float* v, float* vmax, void* shadow, int64_t n, int32_t kind, float lr,
