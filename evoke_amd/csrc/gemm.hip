@@ -861,6 +861,9 @@ int launch_cfg(const GemmP& p, dim3 grid, hipStream_t s) {
   return sb ? launch_cfg_sb<WM, WN, AMODE, BMODE, true>(p, grid, s) : launch_cfg_sb<WM, WN, AMODE, BMODE, false>(p, grid, s);
 }
 
+inline long skinny_tiles() { static long v = [] { const char* e = getenv("EVK_SKINNY_TILES"); return e ? atol(e) : 113L; }(); return v; }
+inline long skinny_rows() { static long v = [] { const char* e = getenv("EVK_SKINNY_ROWS"); return e ? atol(e) : 4096L; }(); return v; }
+
 inline long split_target() {
   static long v = 0;
   if (!v) { const char* e = getenv("EVK_SPLIT_TARGET"); v = e ? atol(e) : 256; if (v < 1) v = 256; }
@@ -994,7 +997,7 @@ extern "C" int evk_gemm_launch(const evk_gemm* d, evk_stream_t stream) {
   ProfScope ps(EVK_FAM_GEMM, s, flops);
   const int am = d->a_mode, bm = d->b_mode;
   if (am == EVK_A_PLAIN && bm == EVK_B_PLAIN && batch == 1 && !p.accumulate && d->K % SK_KC == 0 &&
-      cdiv(d->M, 128) * cdiv(d->N, 128) < 48 && d->M <= 1024 && !d->colstats)
+      cdiv(d->M, 128) * cdiv(d->N, 128) < skinny_tiles() && d->M <= skinny_rows() && !d->colstats)
     return launch_skinny(p, s);
   if (am == EVK_A_PLAIN && bm == EVK_B_PLAIN) return launch_modes<EVK_A_PLAIN, EVK_B_PLAIN>(p, batch, d->splitk, d->workspace, d->workspace_bytes, d, s);
   if (am == EVK_A_CONV && bm == EVK_B_PLAIN) return launch_modes<EVK_A_CONV, EVK_B_PLAIN>(p, batch, d->splitk, d->workspace, d->workspace_bytes, d, s);

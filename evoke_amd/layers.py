@@ -302,8 +302,8 @@ def multiview_fusion(x, patient_ids, batch_size, sdpa, ln2):
     out_rows = [None] * batch_size
     pieces, order = [], []
     for s, items in sorted(groups.items()):
-        a_idx = torch.tensor([i for i, _ in items], device=dev)
-        s_idx = torch.tensor(np.concatenate([sib for _, sib in items]), device=dev)
+        a_idx = ops.index_tensor([i for i, _ in items], dev)
+        s_idx = ops.index_tensor(np.concatenate([sib for _, sib in items]), dev)
         q_in = x.index_select(0, a_idx)                                   # (G, T, D) keeps grad
         kv_in = xd.index_select(0, s_idx).view(len(items), s * T, D)      # (G, s*T, D) detached
         y = ln2(sdpa(q_in, kv_in))
@@ -311,12 +311,12 @@ def multiview_fusion(x, patient_ids, batch_size, sdpa, ln2):
         order += [i for i, _ in items]
     lone = [i for i in range(batch_size) if i not in set(order)]
     if lone:
-        pieces.append(x.index_select(0, torch.tensor(lone, device=dev)))
+        pieces.append(x.index_select(0, ops.index_tensor(lone, dev)))
         order += lone
     allrows = torch.cat(pieces, 0)
-    inv = torch.empty(batch_size, dtype=torch.long)
-    inv[torch.tensor(order)] = torch.arange(batch_size)
-    return allrows.index_select(0, inv.to(dev))
+    inv = np.empty(batch_size, dtype=np.int64)
+    inv[np.asarray(order)] = np.arange(batch_size)
+    return allrows.index_select(0, ops.index_tensor(inv, dev))
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -607,7 +607,9 @@ class EncoderDecoder(nn.Module):
         """_prepare_feature_forward + Transformer.encode: drops the global token, att_embed, 3-layer encoder."""
         att = enc_states[:, 1:, :].contiguous()
         am = enc_mask[:, 1:]
-        all_on = bool(am.all()) if am.numel() else True
+        all_on = getattr(enc_mask, 'evk_all_ones', None)          # set by encoder_states: saves a device->host sync per step
+        if all_on is None:
+            all_on = bool(am.all()) if am.numel() else True
         if not all_on:
             att = att * am.unsqueeze(-1).to(att.dtype)
         feats = ops.dropout(self.att_embed[0](att, act=H.ACT_RELU), self.drop_prob_lm, self.training)

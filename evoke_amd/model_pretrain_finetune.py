@@ -119,6 +119,7 @@ class FineTune(_Base):
             y, side = self._side_branch('text', lambda: self.text_head(self.text_encoder(input_ids=inc_ids, attention_mask=inc_masks)))
         _, x = self._image_tokens(images, patient_ids, batch_size)
         enc_mask = torch.ones(x.shape[:2], dtype=torch.long, device=device)
+        enc_mask.evk_all_ones = True          # host-side knowledge of the mask content (no .all() readback downstream)
         if inc_ids is not None:
             if side is not None:
                 torch.cuda.current_stream().wait_stream(side)

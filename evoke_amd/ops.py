@@ -106,6 +106,57 @@ def join_side_streams():
         cur.wait_stream(main)
 
 
+class _IndexUploader:
+    """Host -> device upload of small int64 index arrays without stalling the host behind queued compute: a blocking
+    `torch.tensor(list, device=...)` is a synchronous copy ON THE CURRENT STREAM and therefore waits for every kernel queued
+    before it (the whole ResNet forward at the multi-view grouping point).  Here the data goes through a ring of pinned
+    staging buffers on a dedicated copy stream; the compute stream only waits for the copy's event on the GPU side."""
+
+    def __init__(self, device, slots=16, cap=1 << 15):
+        self.device = device
+        self.bufs = [torch.empty(cap, dtype=torch.int64).pin_memory() for _ in range(slots)]
+        self.events = [None] * slots
+        self.i = 0
+        self.stream = torch.cuda.Stream(device=device)
+
+    def put(self, values):
+        import numpy as np
+        arr = np.ascontiguousarray(np.asarray(values, dtype=np.int64).reshape(-1))
+        n = arr.shape[0]
+        if n > self.bufs[0].numel():
+            return torch.from_numpy(arr).to(self.device)          # oversize: plain (blocking) path
+        k = self.i % len(self.bufs)
+        self.i += 1
+        if self.events[k] is not None:
+            self.events[k].synchronize()                          # the copy issued `slots` uploads ago; long done
+        stage = self.bufs[k][:n]
+        stage.numpy()[:] = arr
+        main = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(self.stream):
+            t = stage.to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.events[k] = ev
+        main.wait_event(ev)
+        t.record_stream(main)
+        return t
+
+
+_uploaders = {}
+
+
+def index_tensor(values, device):
+    """int64 device tensor from a host list / array, uploaded asynchronously (see _IndexUploader)."""
+    device = torch.device(device)
+    if device.type != 'cuda':
+        return torch.as_tensor(values, dtype=torch.long, device=device)
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    up = _uploaders.get(key)
+    if up is None:
+        up = _uploaders[key] = _IndexUploader(torch.device('cuda', key))
+    return up.put(values)
+
+
 def _z(*shape, dtype=BF16, device='cuda'):
     return torch.zeros(*shape, dtype=dtype, device=device)
 

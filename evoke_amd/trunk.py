@@ -115,6 +115,25 @@ class _Stem(torch.autograd.Function):
         return None, None
 
 
+class _WsLease:
+    """The trunk workspace (20 GB at 64 x 384^2) is leased from a per-device pool and returned when the autograd node is
+    done with it, instead of a malloc/free per step: a freed block that a second stream has touched cannot be re-used by
+    the caching allocator until that stream's event completes, so a host that runs ahead would keep hipMalloc-ing new
+    20 GB blocks.  Re-use is safe in stream order: the next forward is enqueued on the main stream after the optimizer /
+    gradient reducer has joined the weight-gradient stream."""
+    _pool = {}
+
+    def __init__(self, nbytes, device):
+        self.key = (device.index if device.index is not None else torch.cuda.current_device(), int(nbytes))
+        free = _WsLease._pool.setdefault(self.key, [])
+        self.ws = free.pop() if free else torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+    def __del__(self):
+        pool = _WsLease._pool.get(self.key)
+        if pool is not None and len(pool) < 2:
+            pool.append(self.ws)
+
+
 class _TrunkFn(torch.autograd.Function):
     """ResNet trunk forward / backward through evk_trunk_forward / evk_trunk_backward.  `anchor` (the stem weight) only ties
     the node into the autograd graph; parameter gradients are accumulated in place by the runner."""
@@ -146,16 +165,17 @@ class _TrunkFn(torch.autograd.Function):
         nb = H.lib.evk_trunk_ws_bytes(C.byref(cfg), N, Hh, Ww)
         if nb < 0:
             raise RuntimeError('evk_trunk_ws_bytes: ' + H.lib.evk_last_error().decode())
-        ws = torch.empty(nb, dtype=torch.uint8, device=images.device)
+        lease = _WsLease(nb, images.device)
+        ws = lease.ws
         out = _e(N, Hh // 32, Ww // 32, 4 * RESNET_LAYERS[-1][0], device=images.device)
         H.check(H.lib.evk_trunk_forward(C.byref(cfg), arr, len(pairs), H.ptr(images), N, Hh, Ww, H.ptr(ws), nb, H.ptr(out),
                                         int(trunk.training), H.stream()), 'trunk_forward')
-        ctx.ws, ctx.trunk, ctx.dims, ctx.training, ctx.keep = ws, trunk, (N, Hh, Ww), trunk.training, keep
+        ctx.lease, ctx.trunk, ctx.dims, ctx.training, ctx.keep = lease, trunk, (N, Hh, Ww), trunk.training, keep
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        trunk, ws = ctx.trunk, ctx.ws
+        trunk, ws = ctx.trunk, ctx.lease.ws
         N, Hh, Ww = ctx.dims
         pairs = trunk.pairs()
         cfg = trunk.native_cfg()
@@ -163,11 +183,10 @@ class _TrunkFn(torch.autograd.Function):
         dout = dout.contiguous()
         side = None
         if ops.SIDE_STREAMS_ENABLED[0]:
-            side = ops.side_stream('wgrad')
-            ws.record_stream(side)
+            side = ops.side_stream('wgrad')       # joined by the optimizer / gradient reducer before the workspace's next use
         H.check(H.lib.evk_trunk_backward(C.byref(cfg), arr, len(pairs), N, Hh, Ww, H.ptr(ws), ws.numel(), H.ptr(dout), int(ctx.training),
                                          H.stream(), side.cuda_stream if side is not None else None), 'trunk_backward')
-        ctx.ws = None
+        ctx.lease = None
         for cv, bn in pairs:
             for p in (cv.weight, bn.weight, bn.bias):
                 if p.requires_grad:

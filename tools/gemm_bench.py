@@ -66,6 +66,10 @@ CASES = [
     ('conv1x1 l1 fwd 256->64', lambda: conv_case(64, 96, 256, 64, 1, 1, 'fwd'), 2 * 589824 * 64 * 256),
     ('conv3x3 l4 fwd 64x12x12 512->512', lambda: conv_case(64, 12, 512, 512, 3, 1, 'fwd'), 2 * 9216 * 512 * 4608),
     ('gemm 3200x512x512 NT', lambda: gemm_case(3200, 512, 512, 0, 0), 2 * 3200 * 512 * 512),
+    ('gemm 3200x512x1536 NT', lambda: gemm_case(3200, 512, 1536, 0, 0), 2 * 3200 * 512 * 1536),
+    ('gemm 4608x512x512 NT', lambda: gemm_case(4608, 512, 512, 0, 0), 2 * 4608 * 512 * 512),
+    ('gemm 960x768x768 NT', lambda: gemm_case(960, 768, 768, 0, 0), 2 * 960 * 768 * 768),
+    ('gemm 3200x1536x512 NT', lambda: gemm_case(3200, 1536, 512, 0, 0), 2 * 3200 * 512 * 1536),
     ('gemm 96x512x512 NT (skinny)', lambda: gemm_case(96, 512, 512, 0, 0), 2 * 96 * 512 * 512),
 ]
 
