@@ -26,7 +26,8 @@ def init_distributed(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get('EVK_FORCE_DIST', '0') == '1'      # rehearsal: a 1-rank RCCL group that still runs every collective
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -147,7 +148,7 @@ class GradReducer:
         if self.launched[b]:
             return
         self.launched[b] = True
-        if world_size() == 1:
+        if world_size() == 1 and not (dist.is_initialized() and os.environ.get('EVK_FORCE_DIST', '0') == '1'):
             return
         fi, s, e = self.buckets[b]
         if self.flat[fi].is_cuda:
