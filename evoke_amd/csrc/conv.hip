@@ -100,6 +100,11 @@ int evk_conv2d_dgrad(const void* dy, const void* w, void* dx, const evk_conv_geo
 }
 
 int evk_conv2d_dgrad_add(const void* dy, const void* w, const void* resid, void* dx, const evk_conv_geom* g, evk_stream_t stream) {
+  return evk_conv2d_dgrad_gated(dy, w, resid, nullptr, dx, g, stream);
+}
+
+int evk_conv2d_dgrad_gated(const void* dy, const void* w, const void* resid, const void* gate, void* dx, const evk_conv_geom* g,
+                           evk_stream_t stream) {
   if (int e = check_geom(g)) return e;
   const int T = g->KH * g->KW;
   EVK_REQUIRE(ilog2_exact(g->Co) >= 3, "conv dgrad: Co must be a power of two >= 8");
@@ -111,6 +116,7 @@ int evk_conv2d_dgrad_add(const void* dy, const void* w, const void* resid, void*
   d.b_klog = ilog2_exact(g->Co); d.b_tapstride = g->Ci;
   d.batch_outer = d.batch_inner = 1; d.alpha = 1.f; d.c_dtype = EVK_BF16;
   if (resid) { d.resid = resid; d.ldr = g->Ci; d.r_dtype = EVK_BF16; }
+  if (gate) { d.relu_gate = gate; d.ldg = g->Ci; }
   d.g = *g;
   return evk_gemm_launch(&d, stream);
 }

@@ -29,6 +29,7 @@ struct GemmP {
   long sAo, sAi, sBo, sBi, sCo, sCi, sRo, sRi;
   float alpha; int act, c_f32, r_f32, accumulate, vec_ok;
   int ksteps_per_split, tilesN, kslice_xcd;
+  const bf16_t* gate; long ldg;     // optional ReLU gate: C = (gate > 0) ? C : 0, applied last (bf16 [M][ldg], batch 1)
   float* colstats;                  // per 64-row block partial column sums / sums of squares [row block][2][N] (or null)
   float* slab; long slab_mn;        // split-K partial slabs [z][split][M][N] f32 (accumulate mode with splitk > 1)
   int b_klog, b_kmask; long b_tapstride;
@@ -425,6 +426,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[4][4]
 #pragma unroll
             for (int j = 0; j < 4; ++j) if (n0 + j < p.N) v[j] += bf2f(r[j]);
           }
+        }
+      }
+      if (p.gate) {        // gradient of a ReLU whose output is `gate`: zero where the forward activation was clipped
+        const bf16_t* gt = p.gate + (long)m * p.ldg + n0;
+        if (full && (p.ldg & 3) == 0) {
+          const uint2 t = *reinterpret_cast<const uint2*>(gt);
+          if (!(lo_bf(t.x) > 0.f)) v[0] = 0.f;
+          if (!(hi_bf(t.x) > 0.f)) v[1] = 0.f;
+          if (!(lo_bf(t.y) > 0.f)) v[2] = 0.f;
+          if (!(hi_bf(t.y) > 0.f)) v[3] = 0.f;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (n0 + j < p.N && !(bf2f(gt[j]) > 0.f)) v[j] = 0.f;
         }
       }
       if (p.c_f32) {
@@ -949,6 +963,8 @@ extern "C" int evk_gemm_launch(const evk_gemm* d, evk_stream_t stream) {
   p.alpha = d->alpha; p.act = d->act; p.c_f32 = d->c_dtype == EVK_F32; p.r_f32 = d->r_dtype == EVK_F32;
   p.accumulate = d->accumulate;
   p.colstats = reinterpret_cast<float*>(d->colstats);
+  p.gate = reinterpret_cast<const bf16_t*>(d->relu_gate); p.ldg = d->ldg;
+  EVK_REQUIRE(!p.gate || (!p.accumulate && d->batch_outer * d->batch_inner == 1 && d->ldg >= d->N), "evk_gemm: relu_gate needs batch 1, no accumulate, ldg >= N");
   EVK_REQUIRE(!p.colstats || (!p.accumulate && d->batch_outer * d->batch_inner == 1), "evk_gemm: colstats needs batch 1 and no accumulate");
   EVK_REQUIRE(!p.accumulate || (p.c_f32 && !d->bias && !d->resid && d->act == EVK_ACT_NONE),
               "evk_gemm: accumulate needs f32 C and no bias/resid/act");
@@ -997,7 +1013,7 @@ extern "C" int evk_gemm_launch(const evk_gemm* d, evk_stream_t stream) {
   ProfScope ps(EVK_FAM_GEMM, s, flops);
   const int am = d->a_mode, bm = d->b_mode;
   if (am == EVK_A_PLAIN && bm == EVK_B_PLAIN && batch == 1 && !p.accumulate && d->K % SK_KC == 0 &&
-      cdiv(d->M, 128) * cdiv(d->N, 128) < skinny_tiles() && d->M <= skinny_rows() && !d->colstats)
+      cdiv(d->M, 128) * cdiv(d->N, 128) < skinny_tiles() && d->M <= skinny_rows() && !d->colstats && !d->relu_gate)
     return launch_skinny(p, s);
   if (am == EVK_A_PLAIN && bm == EVK_B_PLAIN) return launch_modes<EVK_A_PLAIN, EVK_B_PLAIN>(p, batch, d->splitk, d->workspace, d->workspace_bytes, d, s);
   if (am == EVK_A_CONV && bm == EVK_B_PLAIN) return launch_modes<EVK_A_CONV, EVK_B_PLAIN>(p, batch, d->splitk, d->workspace, d->workspace_bytes, d, s);

@@ -247,33 +247,39 @@ int evk_trunk_backward(const evk_trunk_cfg* cfg, const evk_trunk_layer* layers, 
     int i = 1;
     for (size_t b = 0; b < P.has_down.size(); ++b) { first[b] = i; i += P.has_down[b] ? 4 : 3; }
   }
-  const void* gZ = dout;                 // gradient w.r.t. the current block's output
+  // ReLU gates travel with the producer: every gradient tensor is zeroed where its forward activation was clipped by the
+  // epilogue of the data-gradient GEMM that writes it (evk_conv2d_dgrad_gated), so the batch-norm backward passes read
+  // neither a mask tensor nor write a separate masked copy for the skip branch.
+  const Pair& lastp = P.pairs[first.back() + 2];
+  void* g0 = c.at(P.gbuf[1]);
+  TRY(evk_act_bwd(dout, c.at(lastp.z), g0, lastp.M * lastp.C, EVK_ACT_RELU, stream));
+  const void* gZ = g0;                   // gated gradient w.r.t. the current block's output
   int flip = 0;
   for (int b = (int)P.has_down.size() - 1; b >= 0; --b) {
     const int i = first[b];
     const bool down = P.has_down[b];
     const void* X = b == 0 ? c.at(P.pooled) : c.at(P.pairs[first[b - 1] + 2].z);     // block input
-    void* R = c.at(P.gbuf[2]);           // skip-branch gradient (masked gZ)
+    const void* xgate = b == 0 ? nullptr : X;      // X is the previous block's post-ReLU output (the pooled stem output has no ReLU)
     void* S1 = c.at(P.gbuf[3]);
     void* S2 = c.at(P.gbuf[4]);
     void* T = c.at(P.gbuf[5]);
     void* gX = c.at(P.gbuf[flip]);
     flip ^= 1;
-    TRY(bn_backward(c, i + 2, gZ, R, 1));
-    TRY(evk_conv2d_dgrad(c.at(P.pairs[i + 2].dy), layers[i + 2].w, S1, &P.pairs[i + 2].g, stream));
+    TRY(bn_backward(c, i + 2, gZ, nullptr, 0));
+    TRY(evk_conv2d_dgrad_gated(c.at(P.pairs[i + 2].dy), layers[i + 2].w, nullptr, c.at(P.pairs[i + 1].z), S1, &P.pairs[i + 2].g, stream));
     TRY(wgrad(i + 2, c.at(P.pairs[i + 1].z)));
-    TRY(bn_backward(c, i + 1, S1, nullptr, 1));
-    TRY(evk_conv2d_dgrad(c.at(P.pairs[i + 1].dy), layers[i + 1].w, S2, &P.pairs[i + 1].g, stream));
+    TRY(bn_backward(c, i + 1, S1, nullptr, 0));
+    TRY(evk_conv2d_dgrad_gated(c.at(P.pairs[i + 1].dy), layers[i + 1].w, nullptr, c.at(P.pairs[i].z), S2, &P.pairs[i + 1].g, stream));
     TRY(wgrad(i + 1, c.at(P.pairs[i].z)));
-    TRY(bn_backward(c, i, S2, nullptr, 1));
-    const void* skip = R;
+    TRY(bn_backward(c, i, S2, nullptr, 0));
+    const void* skip = gZ;
     if (down) {
-      TRY(bn_backward(c, i + 3, R, nullptr, 0));
+      TRY(bn_backward(c, i + 3, gZ, nullptr, 0));
       TRY(evk_conv2d_dgrad(c.at(P.pairs[i + 3].dy), layers[i + 3].w, T, &P.pairs[i + 3].g, stream));
       TRY(wgrad(i + 3, X));
       skip = T;
     }
-    TRY(evk_conv2d_dgrad_add(c.at(P.pairs[i].dy), layers[i].w, skip, gX, &P.pairs[i].g, stream));
+    TRY(evk_conv2d_dgrad_gated(c.at(P.pairs[i].dy), layers[i].w, skip, xgate, gX, &P.pairs[i].g, stream));
     TRY(wgrad(i, X));
     gZ = gX;
   }

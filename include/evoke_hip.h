@@ -66,6 +66,8 @@ typedef struct evk_gemm {
   int32_t b_klog; int64_t b_tapstride;   /* EVK_B_KSTR two-level K (see enum)                           */
   void* workspace; int64_t workspace_bytes; /* accumulate + split-K: partial slabs (evk_gemm_workspace_bytes);
                                             without it split-K falls back to f32 atomics                  */
+  const void* relu_gate; int64_t ldg; /* optional bf16 [M][ldg]: C = relu_gate > 0 ? C : 0, applied after resid (the gradient of
+                                    a ReLU whose forward output is relu_gate); batch 1, no accumulate                   */
   void* colstats;                /* optional f32 [ceil(M/64) (rounded to the tile)][2][N]: per 64-row block column sums and
                                     sums of squares of alpha*A.B, from the f32 accumulators (batch 1, no accumulate)  */
   evk_conv_geom g;               /* used by the gather modes                                            */
@@ -99,6 +101,10 @@ int evk_conv2d_fwd_stats(const void* x, const void* w, void* y, const evk_conv_g
 int evk_conv2d_dgrad(const void* dy, const void* w, void* dx, const evk_conv_geom* g, evk_stream_t stream);
 /* dx = dgrad(dy, w) + resid (bf16, shape of dx): the skip-connection gradient of a residual block joins in the epilogue */
 int evk_conv2d_dgrad_add(const void* dy, const void* w, const void* resid, void* dx, const evk_conv_geom* g, evk_stream_t stream);
+/* dx = relu'(gate) * (dgrad(dy, w) + resid): also applies the ReLU gate of the tensor dx belongs to (gate = that tensor's
+ * post-ReLU forward value), so the batch-norm backward that consumes dx needs no mask pass                          */
+int evk_conv2d_dgrad_gated(const void* dy, const void* w, const void* resid, const void* gate, void* dx, const evk_conv_geom* g,
+                           evk_stream_t stream);
 int evk_conv2d_wgrad(const void* dy, const void* x, float* dw, const evk_conv_geom* g, void* ws, int64_t ws_bytes, evk_stream_t stream);
 int64_t evk_conv2d_wgrad_ws_bytes(const evk_conv_geom* g);
 
