@@ -16,6 +16,8 @@ from . import hip as H
 from . import ops
 from .ops import BF16, F32
 
+_GRAPH_ENABLED = [True]          # capture the per-token launch sequence in a HIP graph (set False to debug eagerly)
+
 
 def _topk(x, k):
     rows, n = x.shape
@@ -23,6 +25,55 @@ def _topk(x, k):
     idx = torch.empty(rows, k, dtype=torch.long, device=x.device)
     H.check(H.lib.evk_topk_rows(H.ptr(x), H.ptr(vals), H.ptr(idx), rows, n, k, H.stream()), 'topk_rows')
     return vals, idx
+
+
+class _FusedDecodeWeights:
+    """Inference-time weight packing for the per-token step (built once per generate call from the frozen parameters):
+      * the 18 first-layer matrices of the nine ConditionalLayerNorm MLPs (mlp_gamma / mlp_beta, encoder_decoder.py:144-179)
+        all read the same relational-memory row, so they become ONE GEMM with N = 18 x 512; their second layers run as ONE
+        batched GEMM (batch 18), with the second-layer biases folded into per-norm effective gamma / beta vectors;
+      * the self-attention q / k / v projections of each layer become one GEMM with N = 3 x 512.
+    36 + 9 skinny launches per token turn into 2 + 3."""
+
+    def __init__(self, model):
+        dec = model.decoder
+        self.clns = [layer.sublayer[j].norm for layer in dec.layers for j in range(3)]
+        d = model.d_model
+        w1, b1, w2, geff, beff = [], [], [], [], []
+        for c in self.clns:
+            for mlp, base in ((c.mlp_gamma, c.gamma), (c.mlp_beta, c.beta)):
+                w1.append(mlp[0].weight.detach())
+                b1.append(mlp[0].bias.detach())
+                w2.append(mlp[2].weight.detach())
+                (geff if mlp is c.mlp_gamma else beff).append((base.detach() + mlp[2].bias.detach()).float().contiguous())
+        self.n = len(w1)
+        self.d = d
+        self.w1 = torch.cat(w1, 0).to(BF16).contiguous()                 # (18 d, slots*d)
+        self.b1 = torch.cat(b1, 0).float().contiguous()
+        self.w2 = torch.stack(w2, 0).to(BF16).contiguous()               # (18, d, d)
+        self.geff, self.beff = geff, beff
+        self.qkv_w = [torch.cat([l.self_attn.linears[i].weight.detach() for i in range(3)], 0).to(BF16).contiguous() for l in dec.layers]
+        self.qkv_b = [torch.cat([l.self_attn.linears[i].bias.detach() for i in range(3)], 0).float().contiguous() for l in dec.layers]
+
+    def cln_deltas(self, memory):
+        """memory (R, 1, slots*d) -> (18, R, d) bf16: [2i] = delta gamma, [2i+1] = delta beta of conditional norm i (bias folded out)."""
+        R, K = memory.shape[0], memory.shape[-1]
+        n, d = self.n, self.d
+        hid = torch.empty(R, n * d, dtype=BF16, device=memory.device)
+        ops.gemm(memory, self.w1, hid, R, n * d, K, lda=K, ldb=K, ldc=n * d, bias=self.b1, act=H.ACT_RELU)
+        out = torch.empty(n, R, d, dtype=BF16, device=memory.device)
+        ops.gemm(hid, self.w2, out, R, d, d, lda=n * d, ldb=d, ldc=d, batch=(1, n), sA=(0, d), sB=(0, d * d), sC=(0, R * d))
+        return out
+
+    def norm(self, i, x, deltas):
+        c = self.clns[i]
+        return ops.layernorm(x, self.geff[i], self.beff[i], eps=c.eps, mode=1, dgam=deltas[2 * i].unsqueeze(1), dbet=deltas[2 * i + 1].unsqueeze(1))
+
+    def qkv(self, li, n):
+        R, d = n.shape[0], self.d
+        out = torch.empty(R, 3 * d, dtype=BF16, device=n.device)
+        ops.gemm(n, self.qkv_w[li], out, R, 3 * d, d, lda=d, ldb=d, ldc=3 * d, bias=self.qkv_b[li])
+        return out
 
 
 class _DecoderState:
@@ -35,6 +86,7 @@ class _DecoderState:
         self.enc, self.src_mask = enc, src_mask
         self.mem = model.rm.init_memory(R, enc.device)
         self.t = 0
+        self.fused = _FusedDecodeWeights(model)
         self.kc, self.vc, self.ks, self.vs = [], [], [], []
         for layer in model.decoder.layers:
             self.kc.append(layer.src_attn.linears[1](enc))
@@ -60,6 +112,47 @@ class _DecoderState:
             else:
                 self.ks[i][:, :t] = self.ks[i][:, :t].index_select(0, ix)
                 self.vs[i][:, :t] = self.vs[i][:, :t].index_select(0, ix)
+
+    def reorder_static(self, ix):
+        """reorder() for a hypothesis count that no longer changes: every buffer is updated in place (graph-capturable)."""
+        # ix only permutes hypotheses WITHIN a sample (state_ix = beam_ix + sample * beam): the encoder states, their mask and
+        # the cross-attention K/V are identical for all beams of a sample and need no reordering once expanded
+        self.mem.copy_(self.mem.index_select(0, ix))
+        for i in range(len(self.ks)):
+            self.ks[i].copy_(self.ks[i].index_select(0, ix))
+            self.vs[i].copy_(self.vs[i].index_select(0, ix))
+
+    def step_static(self, it, pos, kmask):
+        """step() with the position held in a device tensor `pos` (1,) and self-attention over the whole cache under the key
+        mask `kmask` (R, max_len; 1 for positions <= pos): no host-side shape depends on the step index, so the launch
+        sequence can be captured once in a HIP graph and replayed."""
+        model = self.model
+        h = model.decoder.layers[0].self_attn.h
+        pe = model.tgt_embed[1].pe[0].index_select(0, pos)
+        emb = ops.embedding(it.view(-1, 1).contiguous(), model.tgt_embed[0].lut.weight, pos=pe, scale=math.sqrt(model.d_model))
+        memory, new_mem = model.rm.run(emb, self.mem)
+        self.mem.copy_(new_mem)
+        fw, d = self.fused, model.d_model
+        deltas = fw.cln_deltas(memory)
+        x = emb
+        for i, layer in enumerate(model.decoder.layers):
+            n = fw.norm(3 * i, x, deltas)
+            sa = layer.self_attn
+            qkv = fw.qkv(i, n.view(-1, d))
+            q = qkv[:, :d].contiguous().view(-1, 1, d)
+            self.ks[i].index_copy_(1, pos, qkv[:, d:2 * d].unsqueeze(1))
+            self.vs[i].index_copy_(1, pos, qkv[:, 2 * d:].unsqueeze(1))
+            c = ops.attention(q, self.ks[i], self.vs[i], h, mask=kmask)
+            x = sa.linears[3](c, resid=x)
+            n = fw.norm(3 * i + 1, x, deltas)
+            ca = layer.src_attn
+            c = ops.attention(ca.linears[0](n), self.kc[i], self.vc[i], h, mask=self.src_mask)
+            x = ca.linears[3](c, resid=x)
+            n = fw.norm(3 * i + 2, x, deltas)
+            x = layer.feed_forward(n, resid=x)
+        out = model.decoder.norm(x)
+        logits = self.dec.logit(out, out_f32=True)
+        return ops.log_softmax(logits.view(logits.shape[0], -1), self.dec.vocab_size + 1)
 
     def step(self, it):
         """it (R,) token ids at position self.t -> f32 log-probs (R, V+1) of the next token."""
@@ -110,32 +203,81 @@ def beam_search(dec, enc_states, enc_mask, args, return_scores=False):
         beam_sum = torch.zeros(B, beam, dtype=F32, device=dev)
         best_p = torch.full((B,), -float('inf'), dtype=F32, device=dev)
         best_seq = torch.full((B, max_len), dec.pad_idx, dtype=torch.long, device=dev)
-        nb = 1
-        for t in range(max_len):
-            cand = (beam_sum[:, :nb].unsqueeze(-1) + logp.view(B, nb, V1)).reshape(B, nb * V1).contiguous()
+        def book(t_host, last):
+            """beam bookkeeping of one step (caption_model.py beam_step + the finished-beam tracking) on persistent buffers;
+            t_host None -> the position comes from the device tensor `pos` (graph mode)."""
+            nonlocal beam_seq, beam_sum, best_p, best_seq, nb
+            cand = (beam_sum[:, :nb].unsqueeze(-1) + logp[0].view(B, nb, V1)).reshape(B, nb * V1).contiguous()
             ys, ix = _topk(cand, beam)
             beam_ix, word_ix = ix // V1, ix % V1
             state_ix = (beam_ix + base * nb).reshape(-1)
-            if t > 0:
-                beam_seq = beam_seq.gather(1, beam_ix.unsqueeze(-1).expand(-1, -1, max_len))
-            beam_seq[:, :, t] = word_ix
-            beam_sum = ys.clone()
-            st.reorder(state_ix)
-            is_end = word_ix == dec.eos_idx
-            if t == max_len - 1:
-                is_end = torch.ones_like(is_end)
+            if t_host is None:
+                beam_seq.copy_(beam_seq.gather(1, beam_ix.unsqueeze(-1).expand(-1, -1, max_len)))
+                beam_seq.index_copy_(2, pos, word_ix.unsqueeze(-1))
+                st.reorder_static(state_ix)
+            else:
+                if t_host > 0:
+                    beam_seq = beam_seq.gather(1, beam_ix.unsqueeze(-1).expand(-1, -1, max_len))
+                beam_seq[:, :, t_host] = word_ix
+                st.reorder(state_ix)
+            beam_sum.copy_(ys)
+            is_end = torch.ones_like(word_ix, dtype=torch.bool) if last else (word_ix == dec.eos_idx)
             # finished beams: keep, per sample, the best p seen so far (earlier / lower beam index wins ties)
             p_end = torch.where(is_end, beam_sum, torch.full_like(beam_sum, -float('inf')))
             pv, pi = p_end.max(dim=1)
             better = pv > best_p
             cand_seq = beam_seq.gather(1, pi.view(B, 1, 1).expand(-1, 1, max_len))[:, 0]
-            best_seq = torch.where(better.unsqueeze(1), cand_seq, best_seq)
-            best_p = torch.where(better, pv, best_p)
-            beam_sum = beam_sum - 1000.0 * is_end.to(F32)
-            if t == max_len - 1:
-                break
-            logp = st.step(word_ix.reshape(-1))
+            best_seq.copy_(torch.where(better.unsqueeze(1), cand_seq, best_seq))
+            best_p.copy_(torch.where(better, pv, best_p))
+            beam_sum.sub_(1000.0 * is_end.to(F32))
+            return word_ix
+
+        nb = 1
+        logp = [logp]
+        # t = 0 (the hypothesis count grows from B to B*beam here) runs eagerly
+        w = book(0, max_len == 1)
+        if max_len > 1:
+            logp[0] = st.step(w.reshape(-1))
             nb = beam
+            R = B * beam
+            pos = torch.ones(1, dtype=torch.long, device=dev)            # device-side step index t
+            ar = torch.arange(max_len, device=dev).unsqueeze(0)
+            logp_buf = logp[0].clone()
+            logp[0] = logp_buf
+
+            def body():
+                """steps 1 .. max_len-2: bookkeeping at position `pos`, then the decoder step that writes position pos+1."""
+                w_ = book(None, False)
+                pos.add_(1)
+                kmask = (ar <= pos).expand(R, -1).to(torch.uint8).contiguous()
+                logp_buf.copy_(st.step_static(w_.reshape(-1), pos, kmask))
+
+            n_body = max_len - 2                                         # iterations t = 1 .. max_len-2
+            graph = None
+            done = 0
+            if n_body > 3 and _GRAPH_ENABLED[0]:
+                cur = torch.cuda.current_stream()
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):                           # warm-up iterations (real steps) off the default stream
+                    body()
+                    body()
+                cur.wait_stream(side)
+                done = 2
+                try:
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        body()
+                except Exception as e:                                   # stay on the HIP path, just without the graph
+                    import warnings
+                    warnings.warn('decode: HIP graph capture failed (%s); running the steps eagerly' % e)
+                    graph = None
+            for _ in range(done, n_body):
+                if graph is not None:
+                    graph.replay()
+                else:
+                    body()
+            book(None, True)                                             # t = max_len - 1: every live beam is closed
         if return_scores:
             return best_seq, best_p
         return best_seq
