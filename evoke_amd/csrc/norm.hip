@@ -427,6 +427,88 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
 
 inline int row_blocks(long rows) { return (int)cdiv(rows, WPB); }
 
+// ------------------------------------------------------------------------------------------------
+// single-query attention of the incremental decode step: out[r][h] = softmax(scale * q[r][h] . K[r][:, h]) V[r][:, h]
+// for one new token per hypothesis (T = 1).  One wavefront per (row, head), head size 64: lanes own key positions for the
+// scores (16-byte loads of a 128-byte key row against q broadcast from LDS), wave-shuffle softmax in f32, then lanes own
+// the 64 output features and walk the keys with the probabilities broadcast by shuffle.  Replaces three launches (batched
+// QK^T GEMM with M = 1, softmax, batched PV GEMM) whose tiles were 99 % padding.
+// ------------------------------------------------------------------------------------------------
+struct DecAttP { const bf16_t* q; const bf16_t* k; const bf16_t* v; const unsigned char* mask; bf16_t* out; int R, S, H; float scale; };
+
+__global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttP p) {
+  // lane = (g, c): g = lane >> 3 picks one of 8 key rows per pass, c = lane & 7 one 16-byte chunk of the 128-byte head row, so
+  // every load instruction of the wave reads 8 whole rows and all passes are independent (no load waits on a shuffle)
+  __shared__ float sl[4][256];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int w = blockIdx.x * 4 + wv;
+  if (w >= p.R * p.H) return;
+  const int r = w / p.H, h = w - r * p.H;
+  const int g = lane >> 3, c = lane & 7;
+  const long HD = (long)p.H * 64;
+  float qr[8];
+  {
+    const uint4 u = *reinterpret_cast<const uint4*>(p.q + (long)r * HD + h * 64 + c * 8);
+    qr[0] = lo_bf(u.x); qr[1] = hi_bf(u.x); qr[2] = lo_bf(u.y); qr[3] = hi_bf(u.y);
+    qr[4] = lo_bf(u.z); qr[5] = hi_bf(u.z); qr[6] = lo_bf(u.w); qr[7] = hi_bf(u.w);
+  }
+  const bf16_t* kb = p.k + (long)r * p.S * HD + h * 64 + c * 8;
+  const bf16_t* vb = p.v + (long)r * p.S * HD + h * 64 + c * 8;
+  const unsigned char* mk = p.mask ? p.mask + (long)r * p.S : nullptr;
+  const int passes = (p.S + 7) >> 3;
+  for (int it = 0; it < passes; ++it) {
+    const int s = it * 8 + g;
+    float a = 0.f;
+    if (s < p.S) {
+      const uint4 u = *reinterpret_cast<const uint4*>(kb + (long)s * HD);
+      a = lo_bf(u.x) * qr[0] + hi_bf(u.x) * qr[1] + lo_bf(u.y) * qr[2] + hi_bf(u.y) * qr[3] + lo_bf(u.z) * qr[4] + hi_bf(u.z) * qr[5] +
+          lo_bf(u.w) * qr[6] + hi_bf(u.w) * qr[7];
+    }
+    a += __shfl_xor(a, 1, 64);
+    a += __shfl_xor(a, 2, 64);
+    a += __shfl_xor(a, 4, 64);
+    if (c == 0 && s < p.S) sl[wv][s] = (mk && !mk[s]) ? -INFINITY : a * p.scale;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float mx = -INFINITY;
+  for (int s = lane; s < p.S; s += 64) mx = fmaxf(mx, sl[wv][s]);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int s = lane; s < p.S; s += 64) {
+    const float x = sl[wv][s];
+    const float e = (x == -INFINITY || mx == -INFINITY) ? 0.f : __expf(x - mx);
+    sl[wv][s] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  const float inv = sum > 0.f ? 1.f / sum : 0.f;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < passes; ++it) {
+    const int s = it * 8 + g;
+    if (s < p.S) {
+      const uint4 u = *reinterpret_cast<const uint4*>(vb + (long)s * HD);
+      const float ps = sl[wv][s];
+      o[0] += ps * lo_bf(u.x); o[1] += ps * hi_bf(u.x); o[2] += ps * lo_bf(u.y); o[3] += ps * hi_bf(u.y);
+      o[4] += ps * lo_bf(u.z); o[5] += ps * hi_bf(u.z); o[6] += ps * lo_bf(u.w); o[7] += ps * hi_bf(u.w);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    o[j] += __shfl_xor(o[j], 8, 64);
+    o[j] += __shfl_xor(o[j], 16, 64);
+    o[j] += __shfl_xor(o[j], 32, 64);
+  }
+  if (g == 0) {
+    *reinterpret_cast<uint4*>(p.out + (long)r * HD + h * 64 + c * 8) =
+        make_uint4(pack2bf(o[0] * inv, o[1] * inv), pack2bf(o[2] * inv, o[3] * inv), pack2bf(o[4] * inv, o[5] * inv), pack2bf(o[6] * inv, o[7] * inv));
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -537,6 +619,17 @@ int evk_softce(const float* z, const float* t, float* loss_acc, float* dz, const
   ProfScope ps(EVK_FAM_NORM, s);
   hipLaunchKernelGGL(softce_kernel, dim3(row_blocks(rows)), dim3(256), 0, s, p);
   return evk_check_launch("softce");
+}
+
+int evk_decode_attention(const void* q, const void* k, const void* v, const unsigned char* mask, void* out, int32_t R, int32_t S,
+                         int32_t heads, int32_t head_dim, float scale, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(q && k && v && out && R > 0 && S > 0 && heads > 0, "decode_attention: null/empty");
+  EVK_REQUIRE(head_dim == 64 && S <= 256, "decode_attention: head_dim must be 64 and S <= 256 (got %d, %d)", head_dim, S);
+  DecAttP p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, mask, (bf16_t*)out, R, S, heads, scale};
+  ProfScope ps(EVK_FAM_NORM, s);
+  hipLaunchKernelGGL(decode_attn_kernel, dim3((int)cdiv((long)R * heads, 4)), dim3(256), 0, s, p);
+  return evk_check_launch("decode_attention");
 }
 
 }  // extern "C"

@@ -8,6 +8,7 @@ incremental: per-layer self-attention K/V caches, cross-attention K/V projected 
 as state, the per-position conditional-LayerNorm inputs taken from the current memory, and all beam bookkeeping
 (segmented top-k, EOS handling, the -1000 penalty, best-finished-beam tracking) done on the device.
 """
+import ctypes as C
 import math
 
 import torch
@@ -25,6 +26,18 @@ def _topk(x, k):
     idx = torch.empty(rows, k, dtype=torch.long, device=x.device)
     H.check(H.lib.evk_topk_rows(H.ptr(x), H.ptr(vals), H.ptr(idx), rows, n, k, H.stream()), 'topk_rows')
     return vals, idx
+
+
+def _attend1(q, k, v, heads, mask):
+    """One-query attention: q (R, 1, H*dh), k / v (R, S, H*dh), mask uint8 (R, S) or None -> (R, 1, H*dh)."""
+    R, S, HD = k.shape
+    dh = HD // heads
+    if dh != 64 or S > 256:
+        return ops.attention(q, k, v, heads, mask=mask)
+    out = torch.empty_like(q)
+    H.check(H.lib.evk_decode_attention(H.ptr(q), H.ptr(k), H.ptr(v), H.ptr(mask) if mask is not None else None, H.ptr(out), R, S, heads,
+                                       dh, C.c_float(1.0 / math.sqrt(dh)), H.stream()), 'decode_attention')
+    return out
 
 
 class _FusedDecodeWeights:
@@ -142,11 +155,11 @@ class _DecoderState:
             q = qkv[:, :d].contiguous().view(-1, 1, d)
             self.ks[i].index_copy_(1, pos, qkv[:, d:2 * d].unsqueeze(1))
             self.vs[i].index_copy_(1, pos, qkv[:, 2 * d:].unsqueeze(1))
-            c = ops.attention(q, self.ks[i], self.vs[i], h, mask=kmask)
+            c = _attend1(q, self.ks[i], self.vs[i], h, kmask)
             x = sa.linears[3](c, resid=x)
             n = fw.norm(3 * i + 1, x, deltas)
             ca = layer.src_attn
-            c = ops.attention(ca.linears[0](n), self.kc[i], self.vc[i], h, mask=self.src_mask)
+            c = _attend1(ca.linears[0](n), self.kc[i], self.vc[i], h, self.src_mask)
             x = ca.linears[3](c, resid=x)
             n = fw.norm(3 * i + 2, x, deltas)
             x = layer.feed_forward(n, resid=x)

@@ -387,3 +387,30 @@ def test_native_trunk_matches_module_walk():
         for (na, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
             assert rel(ba.float(), bb.float()) < (0.15 if train else 1e-6), (train, na)
         print('   native trunk vs module walk (train=%s): out %.3g, worst grad %.3g' % (train, e_out, worst))
+
+
+def test_decode_attention_matches_reference():
+    """evk_decode_attention (one query per row, whole K/V cache, key mask) against fp32 torch on the same bf16 inputs."""
+    import ctypes as C
+    from evoke_amd import hip as H
+    torch.manual_seed(5)
+    for (R, S, heads, masked) in [(7, 100, 8, True), (256, 144, 8, False), (3, 1, 8, True), (5, 256, 4, True)]:
+        HD = heads * 64
+        q = (torch.randn(R, 1, HD, device='cuda') * 0.8).to(BF)
+        k = (torch.randn(R, S, HD, device='cuda') * 0.8).to(BF)
+        v = torch.randn(R, S, HD, device='cuda').to(BF)
+        mask = None
+        if masked:
+            lens = torch.randint(1, S + 1, (R,), device='cuda')
+            mask = (torch.arange(S, device='cuda').unsqueeze(0) < lens.unsqueeze(1)).to(torch.uint8).contiguous()
+        out = torch.empty_like(q)
+        H.check(H.lib.evk_decode_attention(H.ptr(q), H.ptr(k), H.ptr(v), H.ptr(mask) if mask is not None else None, H.ptr(out), R, S,
+                                           heads, 64, C.c_float(0.125), H.stream()))
+        qf = q.float().view(R, heads, 1, 64)
+        kf = k.float().view(R, S, heads, 64).permute(0, 2, 1, 3)
+        vf = v.float().view(R, S, heads, 64).permute(0, 2, 1, 3)
+        sc = (qf @ kf.transpose(-1, -2)) * 0.125
+        if mask is not None:
+            sc = sc.masked_fill(mask.view(R, 1, 1, S) == 0, float('-inf'))
+        ref_o = (torch.softmax(sc, -1) @ vf).permute(0, 2, 1, 3).reshape(R, 1, HD)
+        close(out.float(), ref_o.cpu(), 1e-2, 1e-2, 'decode attention R=%d S=%d' % (R, S))
