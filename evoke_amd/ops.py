@@ -7,6 +7,8 @@ Conventions: activations are contiguous bf16 CUDA tensors [rows.., features]; pa
 cached bf16 "shadow" that the GEMMs read; parameter gradients are accumulated in f32 directly into ``p.grad``
 (the backward returns None for them and fires ``grad_ready`` callbacks, which the DDP reducer listens to).
 """
+import contextlib
+import os
 import ctypes as C
 import math
 
@@ -157,6 +159,56 @@ def index_tensor(values, device):
     return up.put(values)
 
 
+WGRAD_SIDE_STREAM = [os.environ.get('EVK_LINEAR_WGRAD_SIDE', '1') == '1']      # linear-layer dW on the 'wgrad' stream
+
+
+_wgrad_join_queued = [False]
+
+
+def _wgrad_join_callback():
+    _wgrad_join_queued[0] = False
+    cur = torch.cuda.current_stream()
+    for (name, dev), st in _side_streams.items():
+        if name == 'wgrad' and dev == cur.device.index:
+            cur.wait_stream(st)
+
+
+def join_wgrad_at_backward_end():
+    """Parameter gradients computed on the 'wgrad' stream must be visible to whoever reads `.grad` after `backward()`
+    returns: queue (once per backward pass) an autograd-engine callback that makes the calling stream wait for it -- the
+    engine itself only joins the streams of the graph's own nodes."""
+    if not _wgrad_join_queued[0]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_wgrad_join_callback)
+            _wgrad_join_queued[0] = True
+        except RuntimeError:          # not inside a backward pass (direct call of a backward function in a test)
+            pass
+
+
+class wgrad_stream:
+    """context: side stream 'wgrad' ordered after the current stream; `tensors` are kept alive for it."""
+
+    def __init__(self, *tensors):
+        self.tensors = tensors
+        self.ctx = None
+
+    def __enter__(self):
+        if SIDE_STREAMS_ENABLED[0] and WGRAD_SIDE_STREAM[0]:
+            side = side_stream('wgrad')
+            join_wgrad_at_backward_end()
+            side.wait_stream(torch.cuda.current_stream())
+            for t in self.tensors:
+                t.record_stream(side)
+            self.ctx = torch.cuda.stream(side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
 def _z(*shape, dtype=BF16, device='cuda'):
     return torch.zeros(*shape, dtype=dtype, device=device)
 
@@ -241,13 +293,19 @@ class _Linear(torch.autograd.Function):
             dx = _e(M, K, device=dy.device)
             gemm(dy, w, dx, M, K, Np, b_mode=H.B_KSTR, lda=Np, ldb=K, ldc=K)
             dx = dx.view(x.shape)
-        if W.requires_grad:
-            gw = grad_buffer(W)
-            gemm(dy, x, gw, N, K, M, a_mode=H.A_KSTR, b_mode=H.B_KSTR, lda=Np, ldb=K, ldc=K, accumulate=True)
-            grad_done(W)
-        if b is not None and b.requires_grad:
-            H.check(H.lib.evk_colsum(H.ptr(dy), H.ptr(grad_buffer(b)), M, N, Np, H.stream()), 'colsum')
-            grad_done(b)
+        wg, bg = W.requires_grad, b is not None and b.requires_grad
+        if wg or bg:
+            # parameter gradients feed nothing before the optimizer: second stream, overlapping the rest of the backward --
+            # unless dy itself is handed on as the residual branch's gradient (autograd may then accumulate into it in place)
+            with (wgrad_stream(dy, x) if dres is None else contextlib.nullcontext()):
+                if wg:
+                    gemm(dy, x, grad_buffer(W), N, K, M, a_mode=H.A_KSTR, b_mode=H.B_KSTR, lda=Np, ldb=K, ldc=K, accumulate=True)
+                if bg:
+                    H.check(H.lib.evk_colsum(H.ptr(dy), H.ptr(grad_buffer(b)), M, N, Np, H.stream()), 'colsum')
+            if wg:
+                grad_done(W)
+            if bg:
+                grad_done(b)
         return dx, None, None, dres, None, None
 
 

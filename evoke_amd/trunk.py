@@ -44,35 +44,12 @@ class _Conv(torch.autograd.Function):
         if W.requires_grad:
             # the weight gradient feeds nothing before the optimizer: run it on a side stream so its long, latency-bound
             # split-K blocks share the CUs with the (HBM-bound) data-gradient / batch-norm kernels of the main stream
-            with _wgrad_stream(dy, x):
+            with ops.wgrad_stream(dy, x):
                 nb = H.lib.evk_conv2d_wgrad_ws_bytes(C.byref(g))
                 ws = torch.empty(max(nb // 4, 1), dtype=F32, device=x.device)
                 H.check(H.lib.evk_conv2d_wgrad(H.ptr(dy), H.ptr(x), H.ptr(grad_buffer(W)), C.byref(g), H.ptr(ws), nb, H.stream()), 'conv_wgrad')
             grad_done(W)
         return dx, None, None, None
-
-
-class _wgrad_stream:
-    """context: side stream 'wgrad' ordered after the current stream; `tensors` are kept alive for it."""
-
-    def __init__(self, *tensors):
-        self.tensors = tensors
-        self.ctx = None
-
-    def __enter__(self):
-        if ops.SIDE_STREAMS_ENABLED[0]:
-            side = ops.side_stream('wgrad')
-            side.wait_stream(torch.cuda.current_stream())
-            for t in self.tensors:
-                t.record_stream(side)
-            self.ctx = torch.cuda.stream(side)
-            self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        if self.ctx is not None:
-            self.ctx.__exit__(*exc)
-        return False
 
 
 def conv2d(x, W, stride=1, pad=0):
@@ -104,7 +81,7 @@ class _Stem(torch.autograd.Function):
         N, Hh, Ww = ctx.dims
         if W.requires_grad:
             dy = dy.contiguous()
-            with _wgrad_stream(dy, xpad):
+            with ops.wgrad_stream(dy, xpad):
                 st = H.stream()
                 dwp = _z(64 * 224, dtype=F32, device=dy.device)
                 nb = H.lib.evk_stem_wgrad_ws_bytes(N, Hh, Ww)
@@ -183,7 +160,8 @@ class _TrunkFn(torch.autograd.Function):
         dout = dout.contiguous()
         side = None
         if ops.SIDE_STREAMS_ENABLED[0]:
-            side = ops.side_stream('wgrad')       # joined by the optimizer / gradient reducer before the workspace's next use
+            side = ops.side_stream('wgrad')       # joined at the end of the backward pass (and by the optimizer / reducer)
+            ops.join_wgrad_at_backward_end()
         H.check(H.lib.evk_trunk_backward(C.byref(cfg), arr, len(pairs), N, Hh, Ww, H.ptr(ws), ws.numel(), H.ptr(dout), int(ctx.training),
                                          H.stream(), side.cuda_stream if side is not None else None), 'trunk_backward')
         ctx.lease = None
