@@ -29,6 +29,7 @@ struct GemmP {
   long sAo, sAi, sBo, sBi, sCo, sCi, sRo, sRi;
   float alpha; int act, c_f32, r_f32, accumulate, vec_ok;
   int ksteps_per_split, tilesN, kslice_xcd;
+  int lds_store;                    // bf16 output rows leave through LDS in 16-byte pieces (needs N % 8 == 0, ldc % 8 == 0, aligned C)
   const bf16_t* gate; long ldg;     // optional ReLU gate: C = (gate > 0) ? C : 0, applied last (bf16 [M][ldg], batch 1)
   float* colstats;                  // per 64-row block partial column sums / sums of squares [row block][2][N] (or null)
   float* slab; long slab_mn;        // split-K partial slabs [z][split][M][N] f32 (accumulate mode with splitk > 1)
@@ -338,7 +339,12 @@ __device__ __forceinline__ float row16_sum(float v) {
 // ---- epilogue shared by the GEMM kernels: lane holds C[m][n0..n0+3], m = ..+(lane&15), n0 = ..+(lane>>4)*4 ----
 template <int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[4][4], int tm, int tn, int wm, int wn, int frow, int fq,
-                                              int zo, int zi, int by, int bz) {
+                                              int zo, int zi, int by, int bz, char* smem) {
+  // bf16 outputs can leave through LDS: the MFMA layout gives every lane 4 consecutive n of one row (8-byte stores, 16 rows x
+  // 32 B per wave instruction); staged through a wave-private 64 x 64 tile the wave stores 8 whole 128-byte rows at a time
+  const bool stage = p.lds_store && !p.accumulate && !p.c_f32;
+  char* stg = smem + (wm * (TN / 64) + wn) * 8192;
+  if (stage) __syncthreads();          // every wave is done reading the operand tiles
   if (p.colstats) {
     // Batch-norm statistics of a convolution output, taken from the f32 accumulators: every wave reduces its 64 rows
     // (4 in-lane sub-tiles, then the 16 lanes of a DPP row) and writes one partial row [2][N]; rows beyond M are zero
@@ -448,6 +454,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[4][4]
 #pragma unroll
           for (int j = 0; j < 4; ++j) if (n0 + j < p.N) c[j] = v[j];
         }
+      } else if (stage) {
+        const int row = im * 16 + frow, q8 = in * 4 + fq;
+        *reinterpret_cast<uint2*>(stg + row * 128 + ((((q8 >> 1) ^ (row & 7)) << 4) | ((q8 & 1) << 3))) =
+            make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
       } else {
         bf16_t* c = reinterpret_cast<bf16_t*>(Cb) + (long)m * p.ldc + n0;
         if (full) *reinterpret_cast<uint2*>(c) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
@@ -456,6 +466,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[4][4]
           for (int j = 0; j < 4; ++j) if (n0 + j < p.N) c[j] = f2bf(v[j]);
         }
       }
+    }
+  }
+  if (stage) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int lane = frow + 16 * fq;
+    const int ch = lane & 7;
+    const int ncol = tn * TN + wn * 64 + ch * 8;
+    bf16_t* cb = reinterpret_cast<bf16_t*>(Cb);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 8 + (lane >> 3);
+      const int m = tm * TM + wm * 64 + row;
+      if (m < p.M && ncol < p.N)
+        *reinterpret_cast<uint4*>(cb + (long)m * p.ldc + ncol) = *reinterpret_cast<const uint4*>(stg + row * 128 + ((ch ^ (row & 7)) << 4));
     }
   }
 }
@@ -584,7 +610,7 @@ __global__ __launch_bounds__(NTHR, (SB && WM == 2) ? 3 : 2) void gemm_kernel(con
     }
   }
 
-  gemm_epilogue<TM, TN>(p, acc, tm, tn, wm, wn, frow, fq, zo, zi, by, bz);
+  gemm_epilogue<TM, TN>(p, acc, tm, tn, wm, wn, frow, fq, zo, zi, by, bz, smem);
 }
 
 
@@ -693,7 +719,7 @@ __global__ __launch_bounds__(NTHR) void gemm_pipe_kernel(const GemmP p) {
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the zero-fill loads past the K range still target this block's LDS
-  gemm_epilogue<TM, TN>(p, acc, tm, tn, wm, wn, frow, fq, zo, zi, by, bz);
+  gemm_epilogue<TM, TN>(p, acc, tm, tn, wm, wn, frow, fq, zo, zi, by, bz, smem);
 }
 
 template <int AMODE, int BMODE>
@@ -963,6 +989,12 @@ extern "C" int evk_gemm_launch(const evk_gemm* d, evk_stream_t stream) {
   p.alpha = d->alpha; p.act = d->act; p.c_f32 = d->c_dtype == EVK_F32; p.r_f32 = d->r_dtype == EVK_F32;
   p.accumulate = d->accumulate;
   p.colstats = reinterpret_cast<float*>(d->colstats);
+  {
+    // measured (cold caches, tools/gemm_bench.py --cold): +20 % on the write-dominated K = 64 convolutions of layer1, neutral
+    // elsewhere -> on for short-K problems; EVK_LDS_STORE=0/1 forces it off / on for every eligible launch
+    static const int lds_store = [] { const char* e = getenv("EVK_LDS_STORE"); return e ? atoi(e) : -1; }();
+    p.lds_store = (lds_store < 0 ? d->K <= 128 : lds_store != 0) && !p.c_f32 && !p.accumulate && (d->N % 8 == 0) && (d->ldc % 8 == 0) && al(d->C, 16) && (d->sCo % 8 == 0) && (d->sCi % 8 == 0);
+  }
   p.gate = reinterpret_cast<const bf16_t*>(d->relu_gate); p.ldg = d->ldg;
   EVK_REQUIRE(!p.gate || (!p.accumulate && d->batch_outer * d->batch_inner == 1 && d->ldg >= d->N), "evk_gemm: relu_gate needs batch 1, no accumulate, ldg >= N");
   EVK_REQUIRE(!p.colstats || (!p.accumulate && d->batch_outer * d->batch_inner == 1), "evk_gemm: colstats needs batch 1 and no accumulate");
