@@ -235,6 +235,72 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const bf16_t* __restri
   }
 }
 
+// forward that also records, per output element, which of the 9 window taps (kh * 3 + kw) held the FIRST maximum
+__global__ __launch_bounds__(256) void maxpool_fwd_idx_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, unsigned char* __restrict__ idx,
+                                                              int N, int H, int W, int C) {
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1, G = C >> 3;
+  const long total = (long)N * Ho * Wo * G;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % G);
+    long t = i / G;
+    const int ow = (int)(t % Wo); t /= Wo;
+    const int oh = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    float m[8]; int am[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { m[j] = -INFINITY; am[j] = -1; }
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ih = oh * 2 - 1 + kh;
+      if ((unsigned)ih >= (unsigned)H) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int iw = ow * 2 - 1 + kw;
+        if ((unsigned)iw >= (unsigned)W) continue;
+        float v[8];
+        ld8(x + (((long)n * H + ih) * W + iw) * C + cg * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (v[j] > m[j] || am[j] < 0) { m[j] = v[j]; am[j] = kh * 3 + kw; }
+      }
+    }
+    st8(y + i * 8, m);
+    uint2 pk;
+    pk.x = (unsigned)am[0] | ((unsigned)am[1] << 8) | ((unsigned)am[2] << 16) | ((unsigned)am[3] << 24);
+    pk.y = (unsigned)am[4] | ((unsigned)am[5] << 8) | ((unsigned)am[6] << 16) | ((unsigned)am[7] << 24);
+    *reinterpret_cast<uint2*>(idx + i * 8) = pk;
+  }
+}
+
+// backward from the recorded taps: an input pixel sits at tap (ih - 2 oh + 1, iw - 2 ow + 1) of each window containing it
+__global__ __launch_bounds__(256) void maxpool_bwd_idx_kernel(const unsigned char* __restrict__ idx, const bf16_t* __restrict__ dy,
+                                                              bf16_t* __restrict__ dx, int N, int H, int W, int C) {
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1, G = C >> 3;
+  const long total = (long)N * H * W * G;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % G);
+    long t = i / G;
+    const int iw = (int)(t % W); t /= W;
+    const int ih = (int)(t % H);
+    const int n = (int)(t / H);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int oh = ih / 2; oh <= (ih + 1) / 2 && oh < Ho; ++oh) {
+      for (int ow = iw / 2; ow <= (iw + 1) / 2 && ow < Wo; ++ow) {
+        const unsigned tap = (unsigned)((ih - 2 * oh + 1) * 3 + (iw - 2 * ow + 1));
+        const long o = (((long)n * Ho + oh) * Wo + ow) * C + cg * 8;
+        const uint2 pk = *reinterpret_cast<const uint2*>(idx + o);
+        float g[8];
+        ld8(dy + o, g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const unsigned a = ((j < 4 ? pk.x : pk.y) >> (8 * (j & 3))) & 0xffu;
+          if (a == tap) acc[j] += g[j];
+        }
+      }
+    }
+    st8(dx + i * 8, acc);
+  }
+}
+
 // gather form of the backward: each input pixel sums dy of the (<=4) windows whose FIRST maximum (scan order kh,kw,
 // strict >, as torch's max_pool2d indices) is this pixel -- deterministic, no atomics.
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
@@ -429,6 +495,24 @@ int evk_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int32_t N, int
   ProfScope ps(EVK_FAM_ELTWISE, s);
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C);
   return evk_check_launch("maxpool_bwd");
+}
+
+int evk_maxpool3x3s2_fwd_idx(const void* x, void* y, void* idx, int32_t N, int32_t H, int32_t W, int32_t C, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(x && y && idx && N > 0 && H > 0 && W > 0 && C % 8 == 0, "maxpool_fwd_idx: bad args");
+  const long total = (long)N * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * (C / 8);
+  ProfScope ps(EVK_FAM_ELTWISE, s);
+  hipLaunchKernelGGL(maxpool_fwd_idx_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, (unsigned char*)idx, N, H, W, C);
+  return evk_check_launch("maxpool_fwd_idx");
+}
+
+int evk_maxpool3x3s2_bwd_idx(const void* idx, const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(idx && dy && dx && N > 0 && H > 0 && W > 0 && C % 8 == 0, "maxpool_bwd_idx: bad args");
+  const long total = (long)N * H * W * (C / 8);
+  ProfScope ps(EVK_FAM_ELTWISE, s);
+  hipLaunchKernelGGL(maxpool_bwd_idx_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, (const unsigned char*)idx, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C);
+  return evk_check_launch("maxpool_bwd_idx");
 }
 
 int evk_patch_mean_fwd(const void* att, void* fc, int32_t N, int32_t P, int32_t C, evk_stream_t stream) {

@@ -22,7 +22,7 @@ struct Plan {
   std::vector<Pair> pairs;  // [0] stem, then per block conv1, conv2, conv3, (downsample)
   std::vector<int> has_down;  // per block
   int N, H, W;
-  long xpad, wp, dwp, pooled, red, slab, zeros, part, gbuf[6];
+  long xpad, wp, dwp, pooled, pool_idx, red, slab, zeros, part, gbuf[6];
   long gcap, slab_bytes, red_bytes, part_bytes;
   long total;
 };
@@ -59,6 +59,7 @@ int make_plan(const evk_trunk_cfg* cfg, int N, int H, int W, Plan& P) {
   add_pair(evk_conv_geom{}, 64, (long)N * h * w);                 // stem
   h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1;
   P.pooled = take((long)N * h * w * 64 * 2);
+  P.pool_idx = take((long)N * h * w * 64);
   int inpl = 64;
   for (int L = 0; L < 4; ++L) {
     const int planes = cfg->planes[L];
@@ -203,7 +204,7 @@ int evk_trunk_forward(const evk_trunk_cfg* cfg, const evk_trunk_layer* layers, i
   TRY(evk_stem_pack_weight(reinterpret_cast<const float*>(layers[0].w), c.at(P.wp), stream));
   TRY(evk_stem_fwd_stats(c.at(P.xpad), c.at(P.wp), c.at(P.pairs[0].y), N, H, W, part, P.part_bytes, &nblk, stream));
   TRY(bn_forward(c, 0, nullptr, 1, nblk));
-  TRY(evk_maxpool3x3s2_fwd(c.at(P.pairs[0].z), c.at(P.pooled), N, H / 2, W / 2, 64, stream));
+  TRY(evk_maxpool3x3s2_fwd_idx(c.at(P.pairs[0].z), c.at(P.pooled), c.at(P.pool_idx), N, H / 2, W / 2, 64, stream));
 
   const void* x = c.at(P.pooled);
   int i = 1;
@@ -285,7 +286,7 @@ int evk_trunk_backward(const evk_trunk_cfg* cfg, const evk_trunk_layer* layers, 
   }
   // max-pool, stem BN, stem weight gradient (images get no gradient)
   void* gS = c.at(P.gbuf[2]);
-  TRY(evk_maxpool3x3s2_bwd(c.at(P.pairs[0].z), gZ, gS, N, H / 2, W / 2, 64, stream));
+  TRY(evk_maxpool3x3s2_bwd_idx(c.at(P.pool_idx), gZ, gS, N, H / 2, W / 2, 64, stream));
   TRY(bn_backward(c, 0, gS, nullptr, 1));
   if (layers[0].dw) {
     evk_stream_t s2 = q.fork();

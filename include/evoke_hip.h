@@ -230,6 +230,10 @@ int evk_bn_bwd_apply(const void* dz, const void* z, const void* x, const float* 
                      evk_stream_t stream);
 int evk_maxpool3x3s2_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, evk_stream_t stream);
 int evk_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, evk_stream_t stream);
+/* same pooling with the window tap (kh*3+kw, one byte per output element) of the first maximum recorded, so the backward needs
+ * neither the input tensor nor a recomputation of the 3x3 windows                                                 */
+int evk_maxpool3x3s2_fwd_idx(const void* x, void* y, void* idx, int32_t N, int32_t H, int32_t W, int32_t C, evk_stream_t stream);
+int evk_maxpool3x3s2_bwd_idx(const void* idx, const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, evk_stream_t stream);
 /* visual_extractor.py:40-42: avg_feats = mean over patches */
 int evk_patch_mean_fwd(const void* att, void* fc, int32_t N, int32_t P, int32_t C, evk_stream_t stream);
 int evk_patch_mean_bwd(const void* datt_in, const void* dfc, void* datt, int32_t N, int32_t P, int32_t C, evk_stream_t stream);
