@@ -836,6 +836,99 @@ int launch_skinny(const GemmP& p, hipStream_t s) {
   return evk_check_launch("gemm_skinny_kernel");
 }
 
+// ------------------------------------------------------------------------------------------------
+// gemm_small_kernel: weight gradients with M <= 64 output rows (the 64-channel convolutions of layer1 and the stem): a
+// 64 x 64 output tile per block, both operands K-strided.  The throughput kernel's smallest tile (256 x 64 / 128 x 128)
+// wastes 75 % of its MFMAs and of its block slots on such problems.  Here the four waves split every K-step instead of
+// the tile: wave = (half, ksel) multiplies MFMA k-step `ksel` of the 64-deep tile into the 32 output columns `half`, and
+// the two k-step partials leave as two split-K slabs that splitk_reduce_kernel sums anyway.
+// ------------------------------------------------------------------------------------------------
+template <int BMODE>
+__global__ __launch_bounds__(NTHR) void gemm_small_kernel(const GemmP p) {
+  constexpr int TILE_BYTES = (64 + 64) * BK * 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int wg = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  const int tm = wg / p.tilesN, tn = wg - tm * p.tilesN;
+  const int zo = bz / p.bi, zi = bz - zo * p.bi;
+  const int k_begin = by * p.ksteps_per_split * BK;
+  const int k_end = min(p.K, k_begin + p.ksteps_per_split * BK);
+  using LA = KstrLoader<64, 0>;
+  using LB = KstrLoader<64, BMODE == EVK_B_WGATHER ? 1 : 0>;
+  LA la;
+  LB lb;
+  la.init(p, p.A + zo * p.sAo + zi * p.sAi, p.lda, tm * 64, p.M, tid, 0, false);
+  lb.init(p, p.B + zo * p.sBo + zi * p.sBi, p.ldb, tn * 64, p.N, tid, zi, true);
+  uint4 ra[LA::NI], rb[LB::NI];
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int lane = tid & 63, wave = tid >> 6;
+  const int ksel = wave & 1, half = wave >> 1;
+  const int frow = lane & 15, fq = lane >> 4;
+
+  unsigned ma = la.load(p, k_begin, k_end, tid, ra);
+  unsigned mb = lb.load(p, k_begin, k_end, tid, rb);
+  la.store(smem, tid, ra, ma);
+  lb.store(smem + 64 * 128, tid, rb, mb);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+    const bool more = (k0 + BK) < k_end;
+    if (more) {
+      ma = la.load(p, k0 + BK, k_end, tid, ra);
+      mb = lb.load(p, k0 + BK, k_end, tid, rb);
+    }
+    const char* As = smem + buf * TILE_BYTES;
+    const char* Bs = As + 64 * 128;
+    bf16x8 af[4], bfr[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = LA::frag(As, 0, i, ksel, frow, fq);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bfr[j] = LB::frag(Bs, 0, half * 2 + j, ksel, frow, fq);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int im = 0; im < 4; ++im) acc[j][im] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[im], acc[j][im], 0, 0, 0);
+    if (more) {
+      char* nxt = smem + (buf ^ 1) * TILE_BYTES;
+      la.store(nxt, tid, ra, ma);
+      lb.store(nxt + 64 * 128, tid, rb, mb);
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+  float* slab = p.slab + (((long)bz * gridDim.y + by) * 2 + ksel) * p.slab_mn;
+#pragma unroll
+  for (int im = 0; im < 4; ++im) {
+    const int m = tm * 64 + im * 16 + frow;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n0 = tn * 64 + (half * 2 + j) * 16 + fq * 4;
+      if (n0 >= p.N) continue;                       // N % 4 == 0 on this path
+      *reinterpret_cast<float4*>(slab + (long)m * p.N + n0) =
+          make_float4(acc[j][im][0] * p.alpha, acc[j][im][1] * p.alpha, acc[j][im][2] * p.alpha, acc[j][im][3] * p.alpha);
+    }
+  }
+}
+
+constexpr int SMALL_TARGET_BLOCKS = 768;
+
+inline int small_splitk(int M, int N, int K, int batch) {
+  const long tiles = cdiv(M, 64) * cdiv(N, 64) * batch;
+  const int ksteps = (int)cdiv(K, BK);
+  long sk = cdiv(SMALL_TARGET_BLOCKS, tiles);
+  if (sk > ksteps) sk = ksteps;
+  if (sk < 1) sk = 1;
+  const int per = (int)cdiv(ksteps, sk);
+  return (int)cdiv(ksteps, per);
+}
+
+inline bool small_eligible(int M, int N, int a_mode, int accumulate) { return accumulate && a_mode == EVK_A_KSTR && M <= 64 && (N % 4) == 0; }
+
 // C[z][m][n] += sum_split slab[z][split][m][n].  Block = 16 float4 columns x 16 split lanes.
 struct SkrP { const float* slab; float* C; long mn; int M, N, splitk, bi; long ldc, sCo, sCi; };
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const SkrP p) {
@@ -935,6 +1028,26 @@ inline int choose_splitk(int M, int N, int K, int batch, int splitk_req) {
 
 template <int AMODE, int BMODE>
 int launch_modes(GemmP& p, int batch, int splitk_req, void* ws, long ws_bytes, const evk_gemm* d, hipStream_t s) {
+  if constexpr (AMODE == EVK_A_KSTR) {
+    if (small_eligible(p.M, p.N, AMODE, p.accumulate) && ws) {
+      const int sk = small_splitk(p.M, p.N, p.K, batch);
+      p.slab_mn = (long)p.M * p.N;
+      if (ws_bytes >= 2L * sk * batch * p.slab_mn * 4) {
+        p.slab = reinterpret_cast<float*>(ws);
+        p.tilesN = (int)cdiv(p.N, 64);
+        p.ksteps_per_split = (int)cdiv(cdiv(p.K, BK), sk);
+        constexpr int LDS = 2 * (64 + 64) * BK * 2;
+        hipLaunchKernelGGL(gemm_small_kernel<BMODE>, dim3((int)cdiv(p.M, 64) * p.tilesN, sk, batch), dim3(NTHR), LDS, s, p);
+        int rc = evk_check_launch("gemm_small_kernel");
+        if (rc == EVK_OK) {
+          SkrP r{p.slab, reinterpret_cast<float*>(p.C), p.slab_mn, p.M, p.N, 2 * sk, p.bi, p.ldc, p.sCo, p.sCi};
+          hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)cdiv(p.slab_mn / 4, 16), batch), dim3(256), 0, s, r);
+          rc = evk_check_launch("splitk_reduce");
+        }
+        return rc;
+      }
+    }
+  }
   const bool narrow = p.N <= 64;
   const int TM = narrow ? 256 : 128, TN = narrow ? 64 : 128;
   const int tilesM = (int)cdiv(p.M, TM);
@@ -970,6 +1083,8 @@ inline bool al(const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) % 
 extern "C" int64_t evk_gemm_workspace_bytes(const evk_gemm* d) {
   if (!d || !d->accumulate || d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->N % 4)) return 0;
   const int batch = d->batch_outer * d->batch_inner;
+  if (small_eligible(d->M, d->N, d->a_mode, d->accumulate))
+    return 2LL * small_splitk(d->M, d->N, d->K, batch) * batch * d->M * d->N * 4;
   const int sk = choose_splitk(d->M, d->N, d->K, batch, d->splitk);
   return sk > 1 ? (int64_t)sk * batch * d->M * d->N * 4 : 0;
 }

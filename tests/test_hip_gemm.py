@@ -129,7 +129,8 @@ def test_gemm_tn_dw_accumulate(H, M, N, K):
 
 CONVS = [  # N, Hi, Wi, Ci, Co, KH, stride, pad
     (2, 12, 12, 64, 64, 3, 1, 1), (3, 14, 10, 128, 64, 3, 2, 1), (2, 8, 8, 256, 512, 1, 2, 0),
-    (2, 9, 9, 64, 256, 1, 1, 0), (1, 24, 24, 256, 256, 3, 1, 1), (2, 7, 7, 512, 512, 3, 1, 1),
+    (2, 9, 9, 64, 256, 1, 1, 0), (1, 24, 24, 256, 256, 3, 1, 1), (2, 7, 7, 512, 512, 3, 1, 1), (2, 11, 13, 256, 64, 1, 1, 0),
+    (5, 31, 29, 64, 64, 3, 1, 1),
 ]
 
 

@@ -57,6 +57,8 @@ CASES = [
     ('conv3x3 l3 fwd 64x24x24 256->256', lambda: conv_case(64, 24, 256, 256, 3, 1, 'fwd'), 2 * 36864 * 256 * 2304),
     ('conv3x3 l3 dgrad', lambda: conv_case(64, 24, 256, 256, 3, 1, 'dgrad'), 2 * 36864 * 256 * 2304),
     ('conv3x3 l3 wgrad', lambda: conv_case(64, 24, 256, 256, 3, 1, 'wgrad'), 2 * 36864 * 256 * 2304),
+    ('conv3x3 l1 wgrad 64->64', lambda: conv_case(64, 96, 64, 64, 3, 1, 'wgrad'), 2 * 589824 * 64 * 576),
+    ('conv1x1 l1 wgrad 256->64', lambda: conv_case(64, 96, 256, 64, 1, 1, 'wgrad'), 2 * 589824 * 64 * 256),
     ('conv1x1 l3 fwd 256->1024', lambda: conv_case(64, 24, 256, 1024, 1, 1, 'fwd'), 2 * 36864 * 256 * 1024),
     ('conv1x1 l3 fwd 1024->256', lambda: conv_case(64, 24, 1024, 256, 1, 1, 'fwd'), 2 * 36864 * 256 * 1024),
     ('conv1x1 l3 dgrad 1024->256', lambda: conv_case(64, 24, 1024, 256, 1, 1, 'dgrad'), 2 * 36864 * 256 * 1024),
