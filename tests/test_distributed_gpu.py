@@ -1,0 +1,139 @@
+"""Two ranks on ONE GPU (gloo carries the collectives; RCCL refuses two ranks per device): the real data-parallel training
+step of bench.py -- HIP kernels, side streams, bucketed all-reduce of the flat gradients launched from the backward, fused
+optimizer -- for FineTune, and the cross-rank gather of the contrastive negatives for Pretrain.  Checks: no dead-lock, finite
+losses, parameters bit-identical across ranks after two steps, and (FineTune) the reduced gradient of rank 0 equals the mean
+of the per-rank gradients of single-process runs on the same shards."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _shard(kind, rank, V):
+    g = torch.Generator().manual_seed(100 + rank)
+    B, views, L = 2, 2, 12
+    images = torch.randn(B * views, 3, 224, 224, generator=g)
+    ids = torch.randint(5, V, (B, L), generator=g)
+    ids[:, 0] = V - 2 if kind == 'finetune' else 1
+    masks = torch.ones(B, L, dtype=torch.long)
+    pids = np.array(['r%d_s%d' % (rank, i % B) for i in range(B * views)])
+    inc = torch.randint(5, V, (B, 6), generator=g)
+    inc[:, 0] = 1
+    return images.cuda(), ids.cuda(), masks.cuda(), pids, inc, torch.ones(B, 6, dtype=torch.long)
+
+
+def _build(kind, args):
+    from evoke_amd import distributed as D, ops, optim
+    from evoke_amd.model_pretrain_finetune import FineTune, Pretrain
+    from tests.helpers import load_tokenizer
+    ops.clear_grad_callbacks()
+    torch.manual_seed(77)
+    model = (FineTune if kind == 'finetune' else Pretrain)(args, load_tokenizer(), 'mimic_cxr').cuda().train()
+    opt = optim.build_two_stage_optimizer(args, model, clip_value=0.1)
+    return model, opt, D.GradReducer.for_optimizer(opt, bucket_bytes=64 << 20)
+
+
+def _step(kind, model, opt, red, shard, world):
+    images, ids, masks, pids, inc, incm = shard
+    opt.zero_grad()
+    red.begin(kind)
+    if kind == 'finetune':
+        ret = model(images, ids, masks, pids, inc, incm, mode='train')
+    else:
+        ret = model(images, ids, masks, pids)
+    loss = ret['all_loss']
+    (loss / world).backward()
+    red.finish()
+    return float(loss.detach())
+
+
+def _worker(rank, world, port, kind, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
+    import torch.distributed as dist
+    from evoke_amd import distributed as D, ops
+    from tests.helpers import ARGS, V
+    torch.cuda.set_device(0)
+    D.init_distributed('gloo')
+    try:
+        ops.set_dropout_enabled(False)
+        args = dict(ARGS, task=kind if kind == 'finetune' else 'pretrain', pt_lr=5e-5, ft_lr=5e-4, optim='RAdam', weight_decay=5e-5, amsgrad=True)
+        model, opt, red = _build(kind, args)
+        if kind == 'pretrain':
+            model.gather = D.gather_rows
+        shard = _shard(kind, rank, V)
+        losses = [_step(kind, model, opt, red, shard, world)]
+        torch.cuda.synchronize()
+        g0 = opt.flat_grads()[0][:200000].clone()             # reduced gradient (mean over ranks) of the first parameters
+        opt.step()
+        losses.append(_step(kind, model, opt, red, shard, world))
+        opt.step()
+        torch.cuda.synchronize()
+        sig = torch.stack([st['p'].double().sum() for st in opt.flat] + [st['p'].double().abs().sum() for st in opt.flat]).cpu()
+        sigs = [torch.zeros_like(sig) for _ in range(world)]
+        dist.all_gather(sigs, sig)
+        q.put((rank, losses, [s.tolist() for s in sigs], g0.cpu().numpy()))
+    except Exception as e:          # noqa: BLE001 -- reported to the parent
+        import traceback
+        q.put((rank, 'error', traceback.format_exc(), None))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(kind):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, kind, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    out.sort(key=lambda t: t[0])
+    for r in out:
+        assert r[1] != 'error', r[2]
+    return out
+
+
+def test_two_rank_finetune_step_on_one_gpu():
+    out = _run('finetune')
+    for rank, losses, sigs, _ in out:
+        assert all(np.isfinite(losses)), losses
+        assert sigs[0] == sigs[1], 'parameters diverged across ranks: %s' % (sigs,)
+    # reduced gradient == mean of the two single-process shard gradients (same seeds -> same initial weights)
+    from evoke_amd import ops
+    from tests.helpers import ARGS, V
+    ops.set_dropout_enabled(False)
+    args = dict(ARGS, task='finetune', pt_lr=5e-5, ft_lr=5e-4, optim='RAdam', weight_decay=5e-5, amsgrad=True)
+    acc = None
+    for r in range(2):
+        model, opt, red = _build('finetune', args)
+        _step('finetune', model, opt, red, _shard('finetune', r, V), 1)
+        torch.cuda.synchronize()
+        g = opt.flat_grads()[0][:200000].double().cpu().numpy()
+        acc = g if acc is None else acc + g
+    ops.clear_grad_callbacks()
+    ops.set_dropout_enabled(True)
+    want = acc / 2
+    got = out[0][3].astype(np.float64)
+    assert np.abs(got - want).max() <= 1e-6 + 1e-4 * np.abs(want).max(), np.abs(got - want).max()
+
+
+def test_two_rank_pretrain_step_on_one_gpu():
+    out = _run('pretrain')
+    for rank, losses, sigs, _ in out:
+        assert all(np.isfinite(losses)), losses
+        assert sigs[0] == sigs[1], 'parameters diverged across ranks: %s' % (sigs,)
