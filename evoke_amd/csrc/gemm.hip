@@ -42,18 +42,6 @@ struct GemmP {
 };
 
 // ------------------------------------------------------------------------------------------------
-// LDS-DMA (global_load_lds_dwordx4) helpers for gemm_pipe_kernel: 16 bytes per lane straight into LDS at
-// (wave-uniform base) + lane * 16; the per-lane SOURCE address is free, so LDS swizzles are applied to the source.
-// ------------------------------------------------------------------------------------------------
-__device__ __attribute__((aligned(64))) const unsigned g_zero64[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-
-__device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
-  typedef const __attribute__((address_space(1))) void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  __builtin_amdgcn_global_load_lds((gptr_t)(uintptr_t)g, (lptr_t)(uintptr_t)(uint32_t)(uintptr_t)lds_wave_base, 16, 0, 0);
-}
-
-// ------------------------------------------------------------------------------------------------
 // K-contiguous loaders (PLAIN / CONV / DGRAD): thread -> row (tid>>3)+32i, 16-byte chunk kc = tid&7
 // ------------------------------------------------------------------------------------------------
 template <int ROWS, int MODE>
@@ -133,41 +121,6 @@ struct RowLoader {
       }
     }
     return mask;
-  }
-
-  // LDS-DMA form (gemm_pipe_kernel): same thread -> row assignment, but the LDS image is written lane-linearly, so the lane
-  // at LDS position (row, c') fetches data chunk c' ^ (row & 7).  Invalid chunks read 16 bytes of zeros.
-  __device__ __forceinline__ void issue(const GemmP& p, int k0, int kend, int tid, char* lds_wave) const {
-    const int k = k0 + (((tid & 7) ^ ((tid >> 3) & 7)) << 3);
-    const bool kin = k < kend;
-    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero64);
-    if constexpr (MODE == EVK_A_PLAIN) {
-#pragma unroll
-      for (int i = 0; i < NI; ++i) glds16((ok[i] && kin) ? base + off[i] + k : zero, lds_wave + i * 4096);
-    } else {
-      const int tap = k >> p.lgC;
-      const int c = k & (p.Cg - 1);
-      const int kh = tap / p.KW;
-      const int kw = tap - kh * p.KW;
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        bool valid = ok[i] && kin;
-        long a;
-        if constexpr (MODE == EVK_A_CONV) {
-          const int ih = y0[i] + kh, iw = x0[i] + kw;
-          valid = valid && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
-          a = off[i] + (long)ih * p.sH + (long)iw * p.sW + c;
-        } else {
-          const int th = y0[i] - kh, tw = x0[i] - kw;
-          const int m = (1 << p.lgs) - 1;
-          valid = valid && th >= 0 && tw >= 0 && !(th & m) && !(tw & m);
-          const int oh = th >> p.lgs, ow = tw >> p.lgs;
-          valid = valid && oh < p.Ho && ow < p.Wo;
-          a = off[i] + ((long)oh * p.Wo + ow) * p.Cg + c;
-        }
-        glds16(valid ? base + a : zero, lds_wave + i * 4096);
-      }
-    }
   }
 
   __device__ __forceinline__ void store(char* lds, int tid, const uint4 (&v)[NI], unsigned mask) const {
@@ -250,44 +203,6 @@ struct KstrLoader {
       mask |= (valid ? 1u : 0u) << i;
     }
     return mask;
-  }
-
-  // LDS-DMA form (ROWS == 128): the lane writing LDS position (k-row kr, 16-byte slot p16) fetches the data chunk that the
-  // register-staged store() would have put there: m8 = ((p16 >> 1) ^ kswz(kr)) << 1 | (p16 & 1); kswz(kr) is the same for
-  // all NI k-rows of a thread (they differ by multiples of 16).
-  __device__ __forceinline__ void init_pipe(const GemmP& p, const bf16_t* b, long ld_, int row0, int nrows, int tid, int tap,
-                                            bool two_level) {
-    static_assert(ROWS == 128, "LDS-DMA K-strided loader is built for 128-row tiles");
-    init(p, b, ld_, row0, nrows, tid, tap, two_level);
-    const int p16 = tid % CPR, kr = tid / CPR;
-    const int m8 = ((((p16 >> 1) ^ kswz(kr)) & (NCH - 1)) << 1) | (p16 & 1);
-    const int r0 = row0 + m8 * 8;
-    rok = r0 < nrows;
-    ptr = b + (rok ? r0 : 0);
-  }
-
-  __device__ __forceinline__ void issue(const GemmP& p, int k0, int kend, int tid, char* lds_wave) const {
-    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero64);
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int k = k0 + tid / CPR + i * KSTEP;
-      bool valid = rok && k < kend;
-      long a;
-      if constexpr (MODE == 0) {
-        a = (long)(k & kmask) * ld + (long)(k >> klog) * tapstride;
-      } else {
-        int n = (int)((float)k * inv_rpi);
-        int rem = k - n * p.rows_per_img;
-        if (rem < 0) { --n; rem += p.rows_per_img; } else if (rem >= p.rows_per_img) { ++n; rem -= p.rows_per_img; }
-        int oh = (int)((float)rem * inv_rw);
-        int ow = rem - oh * p.row_w;
-        if (ow < 0) { --oh; ow += p.row_w; } else if (ow >= p.row_w) { ++oh; ow -= p.row_w; }
-        const int ih = oh * p.sh - p.ph + kh, iw = ow * p.sw - p.pw + kw;
-        valid = valid && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
-        a = (long)n * p.sN + (long)ih * p.sH + (long)iw * p.sW;
-      }
-      glds16(valid ? ptr + a : zero, lds_wave + i * 4096);
-    }
   }
 
   __device__ __forceinline__ void store(char* lds, int tid, const uint4 (&v)[NI], unsigned mask) const {
@@ -613,127 +528,6 @@ __global__ __launch_bounds__(NTHR, (SB && WM == 2) ? 3 : 2) void gemm_kernel(con
   gemm_epilogue<TM, TN>(p, acc, tm, tn, wm, wn, frow, fq, zo, zi, by, bz, smem);
 }
 
-
-// ------------------------------------------------------------------------------------------------
-// gemm_pipe_kernel: the same 128 x 128 x 64 tile and fragment layout, but staged by LDS-DMA into a ring of PIPE_NS LDS
-// stages with PIPE_NS - 1 K-steps of loads in flight -- one block per CU no longer waits a full memory latency per K-step
-// (the register-staged kernel keeps one K-step in flight per block and relies on 3 blocks per CU to cover the rest, which
-// the trunk's mid-sized convolutions, 1-2 tiles per CU, cannot provide).
-// Per K-step: counted s_waitcnt vmcnt (own loads of this stage landed; younger stages stay in flight) -> s_barrier
-// (everyone's loads landed, everyone finished reading the stage about to be refilled) -> issue the loads of K-step
-// kt + PIPE_NS - 1 -> fragment reads + 32 MFMAs.  Loads past the K range read zeros, so the count per step is constant.
-// ------------------------------------------------------------------------------------------------
-constexpr int PIPE_NS = 4;
-constexpr int PIPE_STAGE = (128 + 128) * BK * 2;
-
-template <int AMODE, int BMODE>
-__global__ __launch_bounds__(NTHR) void gemm_pipe_kernel(const GemmP p) {
-  constexpr int TM = 128, TN = 128, WN = 2;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  int wg, by = blockIdx.y, bz = blockIdx.z;
-  if (p.kslice_xcd && gridDim.y > 1 && (gridDim.y & 7) == 0) {
-    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    const int per = gridDim.x * gridDim.z;
-    const int xcd = lin & 7, j = lin >> 3;
-    const int sl = j / per, w = j - sl * per;
-    by = xcd + 8 * sl;
-    bz = w / gridDim.x;
-    wg = w - bz * gridDim.x;
-  } else {
-    const int bid = blockIdx.x, nwg = gridDim.x;
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int tm = wg / p.tilesN, tn = wg - tm * p.tilesN;
-  const int zo = bz / p.bi, zi = bz - zo * p.bi;
-  const int k_begin = by * p.ksteps_per_split * BK;
-  const int k_end = min(p.K, k_begin + p.ksteps_per_split * BK);
-  if (k_begin >= k_end) return;
-
-  using LA = typename LoaderSel<TM, AMODE, true>::T;
-  using LB = typename LoaderSel<TN, BMODE, false>::T;
-  constexpr bool AKS = LoaderSel<TM, AMODE, true>::KS;
-  constexpr bool BKS = LoaderSel<TN, BMODE, false>::KS;
-  LA la;
-  LB lb;
-  const bf16_t* Ab = p.A + zo * p.sAo + zi * p.sAi;
-  const bf16_t* Bb = p.B + zo * p.sBo + zi * p.sBi;
-  if constexpr (AKS) la.init_pipe(p, Ab, p.lda, tm * TM, p.M, tid, 0, false);
-  else la.init(p, Ab, p.lda, tm * TM, p.M, tid);
-  if constexpr (BKS) lb.init_pipe(p, Bb, p.ldb, tn * TN, p.N, tid, zi, true);
-  else lb.init(p, Bb, p.ldb, tn * TN, p.N, tid);
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave - wm * WN;
-  const int frow = lane & 15, fq = lane >> 4;
-
-  auto issue = [&](int kt) {
-    char* st = smem + (kt & (PIPE_NS - 1)) * PIPE_STAGE + wave * 1024;
-    const int k0 = k_begin + kt * BK;
-    la.issue(p, k0, k_end, tid, st);
-    lb.issue(p, k0, k_end, tid, st + TM * 128);
-  };
-
-  const int nk = (k_end - k_begin + BK - 1) / BK;
-#pragma unroll
-  for (int kt = 0; kt < PIPE_NS - 1; ++kt) issue(kt);
-
-  for (int kt = 0; kt < nk; ++kt) {
-    // 8 LDS-DMA instructions per thread per stage; two younger stages may stay in flight
-    asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
-    issue(kt + PIPE_NS - 1);
-    const char* As = smem + (kt & (PIPE_NS - 1)) * PIPE_STAGE;
-    const char* Bs = As + TM * 128;
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[4], bfr[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if constexpr (AKS) af[i] = LA::frag(As, wm * 64, i, ks, frow, fq);
-        else {
-          const int row = wm * 64 + i * 16 + frow;
-          af[i] = *reinterpret_cast<const bf16x8*>(As + row * 128 + (((ks * 4 + fq) ^ (row & 7)) << 4));
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if constexpr (BKS) bfr[i] = LB::frag(Bs, wn * 64, i, ks, frow, fq);
-        else {
-          const int row = wn * 64 + i * 16 + frow;
-          bfr[i] = *reinterpret_cast<const bf16x8*>(Bs + row * 128 + (((ks * 4 + fq) ^ (row & 7)) << 4));
-        }
-      }
-#pragma unroll
-      for (int in = 0; in < 4; ++in)
-#pragma unroll
-        for (int im = 0; im < 4; ++im)
-          acc[in][im] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[in], af[im], acc[in][im], 0, 0, 0);
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the zero-fill loads past the K range still target this block's LDS
-  gemm_epilogue<TM, TN>(p, acc, tm, tn, wm, wn, frow, fq, zo, zi, by, bz, smem);
-}
-
-template <int AMODE, int BMODE>
-int launch_pipe(const GemmP& p, dim3 grid, hipStream_t s) {
-  constexpr int LDS = PIPE_NS * PIPE_STAGE;
-  static bool attr_done = false;
-  auto kern = gemm_pipe_kernel<AMODE, BMODE>;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(kern, grid, dim3(NTHR), LDS, s, p);
-  return evk_check_launch("gemm_pipe_kernel");
-}
 
 // ------------------------------------------------------------------------------------------------
 // latency-optimised kernel for small problems (the relational-memory recurrence, decode steps):
@@ -1065,9 +859,7 @@ int launch_modes(GemmP& p, int batch, int splitk_req, void* ws, long ws_bytes, c
   static const int kslice = [] { const char* e = getenv("EVK_KSLICE_XCD"); return e ? atoi(e) : 1; }();
   p.kslice_xcd = kslice;
   dim3 grid(tilesM * p.tilesN, splitk, batch);
-  static const int pipe = [] { const char* e = getenv("EVK_GEMM_PIPE"); return e ? atoi(e) : 0; }();
-  int rc = narrow ? launch_cfg<4, 1, AMODE, BMODE>(p, grid, s)
-                  : (pipe ? launch_pipe<AMODE, BMODE>(p, grid, s) : launch_cfg<2, 2, AMODE, BMODE>(p, grid, s));
+  int rc = narrow ? launch_cfg<4, 1, AMODE, BMODE>(p, grid, s) : launch_cfg<2, 2, AMODE, BMODE>(p, grid, s);
   if (rc == EVK_OK && p.slab) {
     SkrP r{p.slab, reinterpret_cast<float*>(p.C), p.slab_mn, p.M, p.N, splitk, p.bi, p.ldc, p.sCo, p.sCi};
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)cdiv(p.slab_mn / 4, 16), batch), dim3(256), 0, s, r);
