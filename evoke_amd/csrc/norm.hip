@@ -434,7 +434,7 @@ inline int row_blocks(long rows) { return (int)cdiv(rows, WPB); }
 // the 64 output features and walk the keys with the probabilities broadcast by shuffle.  Replaces three launches (batched
 // QK^T GEMM with M = 1, softmax, batched PV GEMM) whose tiles were 99 % padding.
 // ------------------------------------------------------------------------------------------------
-struct DecAttP { const bf16_t* q; const bf16_t* k; const bf16_t* v; const unsigned char* mask; bf16_t* out; int R, S, H; float scale; };
+struct DecAttP { const bf16_t* q; const bf16_t* k; const bf16_t* v; const unsigned char* mask; bf16_t* out; int R, S, H, kv_div; float scale; };
 
 __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttP p) {
   // lane = (g, c): g = lane >> 3 picks one of 8 key rows per pass, c = lane & 7 one 16-byte chunk of the 128-byte head row, so
@@ -452,9 +452,10 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttP p) {
     qr[0] = lo_bf(u.x); qr[1] = hi_bf(u.x); qr[2] = lo_bf(u.y); qr[3] = hi_bf(u.y);
     qr[4] = lo_bf(u.z); qr[5] = hi_bf(u.z); qr[6] = lo_bf(u.w); qr[7] = hi_bf(u.w);
   }
-  const bf16_t* kb = p.k + (long)r * p.S * HD + h * 64 + c * 8;
-  const bf16_t* vb = p.v + (long)r * p.S * HD + h * 64 + c * 8;
-  const unsigned char* mk = p.mask ? p.mask + (long)r * p.S : nullptr;
+  const long rk = r / p.kv_div;          // kv_div consecutive query rows (the beams of one sample) share one K / V / mask row
+  const bf16_t* kb = p.k + rk * p.S * HD + h * 64 + c * 8;
+  const bf16_t* vb = p.v + rk * p.S * HD + h * 64 + c * 8;
+  const unsigned char* mk = p.mask ? p.mask + rk * p.S : nullptr;
   const int passes = (p.S + 7) >> 3;
   for (int it = 0; it < passes; ++it) {
     const int s = it * 8 + g;
@@ -622,11 +623,12 @@ int evk_softce(const float* z, const float* t, float* loss_acc, float* dz, const
 }
 
 int evk_decode_attention(const void* q, const void* k, const void* v, const unsigned char* mask, void* out, int32_t R, int32_t S,
-                         int32_t heads, int32_t head_dim, float scale, evk_stream_t stream) {
+                         int32_t heads, int32_t head_dim, int32_t kv_div, float scale, evk_stream_t stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   EVK_REQUIRE(q && k && v && out && R > 0 && S > 0 && heads > 0, "decode_attention: null/empty");
   EVK_REQUIRE(head_dim == 64 && S <= 256, "decode_attention: head_dim must be 64 and S <= 256 (got %d, %d)", head_dim, S);
-  DecAttP p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, mask, (bf16_t*)out, R, S, heads, scale};
+  EVK_REQUIRE(kv_div >= 1 && R % kv_div == 0, "decode_attention: R=%d must be a multiple of kv_div=%d", R, kv_div);
+  DecAttP p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, mask, (bf16_t*)out, R, S, heads, kv_div, scale};
   ProfScope ps(EVK_FAM_NORM, s);
   hipLaunchKernelGGL(decode_attn_kernel, dim3((int)cdiv((long)R * heads, 4)), dim3(256), 0, s, p);
   return evk_check_launch("decode_attention");

@@ -29,14 +29,20 @@ def _topk(x, k):
 
 
 def _attend1(q, k, v, heads, mask):
-    """One-query attention: q (R, 1, H*dh), k / v (R, S, H*dh), mask uint8 (R, S) or None -> (R, 1, H*dh)."""
-    R, S, HD = k.shape
+    """One-query attention: q (R, 1, H*dh); k / v (R/div, S, H*dh) and mask uint8 (R/div, S) or None, where `div` consecutive
+    query rows (the beams of one sample) share a K / V row -> (R, 1, H*dh)."""
+    R = q.shape[0]
+    Rk, S, HD = k.shape
     dh = HD // heads
+    div = R // Rk
     if dh != 64 or S > 256:
+        if div > 1:
+            k, v = k.repeat_interleave(div, 0), v.repeat_interleave(div, 0)
+            mask = mask.repeat_interleave(div, 0) if mask is not None else None
         return ops.attention(q, k, v, heads, mask=mask)
     out = torch.empty_like(q)
     H.check(H.lib.evk_decode_attention(H.ptr(q), H.ptr(k), H.ptr(v), H.ptr(mask) if mask is not None else None, H.ptr(out), R, S, heads,
-                                       dh, C.c_float(1.0 / math.sqrt(dh)), H.stream()), 'decode_attention')
+                                       dh, div, C.c_float(1.0 / math.sqrt(dh)), H.stream()), 'decode_attention')
     return out
 
 
@@ -108,14 +114,11 @@ class _DecoderState:
             self.vs.append(torch.zeros(R, max_len, d, dtype=BF16, device=enc.device))
 
     def reorder(self, ix):
+        """first beam expansion (B -> B*beam hypotheses).  The encoder states, their mask and the cross-attention K/V stay at
+        one row per SAMPLE: every beam of a sample reads the same row (evk_decode_attention kv_div)."""
         self.mem = self.mem.index_select(0, ix)
-        self.enc = self.enc.index_select(0, ix)
-        if self.src_mask is not None:
-            self.src_mask = self.src_mask.index_select(0, ix)
         t = self.t
         for i in range(len(self.ks)):
-            self.kc[i] = self.kc[i].index_select(0, ix)
-            self.vc[i] = self.vc[i].index_select(0, ix)
             if ix.numel() != self.ks[i].shape[0]:
                 nk = torch.zeros(ix.numel(), *self.ks[i].shape[1:], dtype=BF16, device=ix.device)
                 nv = torch.zeros_like(nk)
@@ -250,12 +253,11 @@ def beam_search(dec, enc_states, enc_mask, args, return_scores=False):
         # t = 0 (the hypothesis count grows from B to B*beam here) runs eagerly
         w = book(0, max_len == 1)
         if max_len > 1:
-            logp[0] = st.step(w.reshape(-1))
             nb = beam
             R = B * beam
             pos = torch.ones(1, dtype=torch.long, device=dev)            # device-side step index t
             ar = torch.arange(max_len, device=dev).unsqueeze(0)
-            logp_buf = logp[0].clone()
+            logp_buf = st.step_static(w.reshape(-1), pos, (ar <= pos).expand(R, -1).to(torch.uint8).contiguous()).clone()
             logp[0] = logp_buf
 
             def body():

@@ -191,9 +191,10 @@ int evk_softmax_bwd(const void* dp, int dp_dtype, int32_t ld_dp, const void* pro
  * acc2[0] += sum(-logp[target]*wmask), acc2[1] += sum(wmask)   (encoder_decoder.py:393 + loss.py:9-16)       */
 /* single-query attention of the incremental decode step (MultiHeadedAttention with one new token per hypothesis,
  * encoder_decoder.py:182-214 as driven by caption_model.py beam_search): out[r] = concat_h softmax(scale q_h.K_h^T [masked]) V_h;
- * q/out bf16 [R][heads*64], k/v bf16 [R][S][heads*64], mask uint8 [R][S] (1 = attend) or NULL; head_dim 64, S <= 256       */
+ * q/out bf16 [R][heads*64], k/v bf16 [R/kv_div][S][heads*64], mask uint8 [R/kv_div][S] (1 = attend) or NULL; kv_div consecutive
+ * query rows (the beams of one sample) share one K/V row -- 1 for the self-attention caches; head_dim 64, S <= 256            */
 int evk_decode_attention(const void* q, const void* k, const void* v, const unsigned char* mask, void* out, int32_t R, int32_t S,
-                         int32_t heads, int32_t head_dim, float scale, evk_stream_t stream);
+                         int32_t heads, int32_t head_dim, int32_t kv_div, float scale, evk_stream_t stream);
 int evk_log_softmax_nll_fwd(const float* logits, float* logp, float* lse, const int64_t* target, const float* wmask, float* acc2,
                             int64_t rows, int32_t V, int32_t ld, int32_t ld_out, evk_stream_t stream);
 int evk_nll_bwd(const float* logits, const float* lse, const int64_t* target, const float* wmask, const float* gscale,

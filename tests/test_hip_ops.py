@@ -405,7 +405,7 @@ def test_decode_attention_matches_reference():
             mask = (torch.arange(S, device='cuda').unsqueeze(0) < lens.unsqueeze(1)).to(torch.uint8).contiguous()
         out = torch.empty_like(q)
         H.check(H.lib.evk_decode_attention(H.ptr(q), H.ptr(k), H.ptr(v), H.ptr(mask) if mask is not None else None, H.ptr(out), R, S,
-                                           heads, 64, C.c_float(0.125), H.stream()))
+                                           heads, 64, 1, C.c_float(0.125), H.stream()))
         qf = q.float().view(R, heads, 1, 64)
         kf = k.float().view(R, S, heads, 64).permute(0, 2, 1, 3)
         vf = v.float().view(R, S, heads, 64).permute(0, 2, 1, 3)
@@ -414,3 +414,15 @@ def test_decode_attention_matches_reference():
             sc = sc.masked_fill(mask.view(R, 1, 1, S) == 0, float('-inf'))
         ref_o = (torch.softmax(sc, -1) @ vf).permute(0, 2, 1, 3).reshape(R, 1, HD)
         close(out.float(), ref_o.cpu(), 1e-2, 1e-2, 'decode attention R=%d S=%d' % (R, S))
+        if R % 4 == 0:          # beams of a sample sharing one K / V / mask row
+            q4 = q.repeat_interleave(4, 0).contiguous()
+            q4 = (q4 + torch.randn_like(q4.float()).to(BF) * 0.1).contiguous()
+            out4 = torch.empty_like(q4)
+            H.check(H.lib.evk_decode_attention(H.ptr(q4), H.ptr(k), H.ptr(v), H.ptr(mask) if mask is not None else None, H.ptr(out4), 4 * R, S,
+                                               heads, 64, 4, C.c_float(0.125), H.stream()))
+            k4, v4 = k.repeat_interleave(4, 0).contiguous(), v.repeat_interleave(4, 0).contiguous()
+            m4 = mask.repeat_interleave(4, 0).contiguous() if mask is not None else None
+            ref4 = torch.empty_like(q4)
+            H.check(H.lib.evk_decode_attention(H.ptr(q4), H.ptr(k4), H.ptr(v4), H.ptr(m4) if m4 is not None else None, H.ptr(ref4), 4 * R, S,
+                                               heads, 64, 1, C.c_float(0.125), H.stream()))
+            assert torch.equal(out4, ref4)
