@@ -536,58 +536,61 @@ __global__ __launch_bounds__(NTHR, (SB && WM == 2) ? 3 : 2) void gemm_kernel(con
 // ALL loads of a chunk in flight at once (80 KB of LDS per chunk): a K = 512 product pays 2 global-load latencies
 // instead of the 8 of the throughput kernel's 64-deep pipeline.
 // ------------------------------------------------------------------------------------------------
-constexpr int SK_KC = 256, SK_TM = 128, SK_TN = 32;
-__device__ __forceinline__ int sk_off(int row, int chunk) { return row * (SK_KC * 2) + ((chunk ^ (row & 15)) << 4); }
+constexpr int SK_KC = 256, SK_TM = 128;      // SK_KC: the K granularity the launcher requires
+template <int KC>
+__device__ __forceinline__ int sk_off(int row, int chunk) { return row * (KC * 2) + ((chunk ^ (row & 15)) << 4); }
 
+// KC = K-chunk depth (all loads of a chunk in flight at once), TN = output columns per block (16 or 32)
+template <int KC, int TN>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmP p) {
+  constexpr int CPR = KC / 8;                    // 16-byte chunks per row
+  constexpr int NA = SK_TM * CPR / 256, NB = TN * CPR / 256, NT = TN / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* As = smem;                               // [128][256] bf16, 512-byte rows, chunk index XOR (row & 15)
-  char* Bs = smem + SK_TM * SK_KC * 2;           // [32][256]
+  char* As = smem;                               // [128][KC] bf16, chunk index XOR (row & 15)
+  char* Bs = smem + SK_TM * KC * 2;              // [TN][KC]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int frow = lane & 15, fq = lane >> 4;
-  const int m0 = blockIdx.y * SK_TM, n0 = blockIdx.x * SK_TN;
-  // staging: A chunk = 128 rows x 32 chunks(16B) = 4096 -> 16 per thread; B chunk = 32 x 32 = 1024 -> 4 per thread
-  uint4 ra[16], rb[4];
+  const int m0 = blockIdx.y * SK_TM, n0 = blockIdx.x * TN;
+  uint4 ra[NA], rb[NB];
   auto load = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int c = tid + 256 * i, row = c >> 5, ch = c & 31;
+    for (int i = 0; i < NA; ++i) {
+      const int c = tid + 256 * i, row = c / CPR, ch = c % CPR;
       const int m = m0 + row;
       ra[i] = m < p.M ? *reinterpret_cast<const uint4*>(p.A + (long)m * p.lda + k0 + ch * 8) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + 256 * i, row = c >> 5, ch = c & 31;
+    for (int i = 0; i < NB; ++i) {
+      const int c = tid + 256 * i, row = c / CPR, ch = c % CPR;
       const int n = n0 + row;
       rb[i] = n < p.N ? *reinterpret_cast<const uint4*>(p.B + (long)n * p.ldb + k0 + ch * 8) : make_uint4(0, 0, 0, 0);
     }
   };
   auto store = [&]() {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { const int c = tid + 256 * i; *reinterpret_cast<uint4*>(As + sk_off(c >> 5, c & 31)) = ra[i]; }
+    for (int i = 0; i < NA; ++i) { const int c = tid + 256 * i; *reinterpret_cast<uint4*>(As + sk_off<KC>(c / CPR, c % CPR)) = ra[i]; }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const int c = tid + 256 * i; *reinterpret_cast<uint4*>(Bs + sk_off(c >> 5, c & 31)) = rb[i]; }
+    for (int i = 0; i < NB; ++i) { const int c = tid + 256 * i; *reinterpret_cast<uint4*>(Bs + sk_off<KC>(c / CPR, c % CPR)) = rb[i]; }
   };
-  f32x4 acc[2][2];     // [n tile][m tile]; wave owns rows wave*32 .. +32
+  f32x4 acc[NT][2];     // [n tile][m tile]; wave owns rows wave*32 .. +32
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NT; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   load(0);
-  for (int k0 = 0; k0 < p.K; k0 += SK_KC) {
+  for (int k0 = 0; k0 < p.K; k0 += KC) {
     store();
     __syncthreads();
-    if (k0 + SK_KC < p.K) load(k0 + SK_KC);
+    if (k0 + KC < p.K) load(k0 + KC);
 #pragma unroll
-    for (int ks = 0; ks < SK_KC / 32; ++ks) {
-      bf16x8 af[2], bfr[2];
+    for (int ks = 0; ks < KC / 32; ++ks) {
+      bf16x8 af[2], bfr[NT];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        af[i] = *reinterpret_cast<const bf16x8*>(As + sk_off(wave * 32 + i * 16 + frow, ks * 4 + fq));
-        bfr[i] = *reinterpret_cast<const bf16x8*>(Bs + sk_off(i * 16 + frow, ks * 4 + fq));
-      }
+      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(As + sk_off<KC>(wave * 32 + i * 16 + frow, ks * 4 + fq));
 #pragma unroll
-      for (int in = 0; in < 2; ++in)
+      for (int i = 0; i < NT; ++i) bfr[i] = *reinterpret_cast<const bf16x8*>(Bs + sk_off<KC>(i * 16 + frow, ks * 4 + fq));
+#pragma unroll
+      for (int in = 0; in < NT; ++in)
 #pragma unroll
         for (int im = 0; im < 2; ++im)
           acc[in][im] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[in], af[im], acc[in][im], 0, 0, 0);
@@ -599,7 +602,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmP p) {
     const int m = m0 + wave * 32 + im * 16 + frow;
     if (m >= p.M) continue;
 #pragma unroll
-    for (int in = 0; in < 2; ++in) {
+    for (int in = 0; in < NT; ++in) {
       const int nn = n0 + in * 16 + fq * 4;
       if (nn >= p.N) continue;
       float v[4] = {acc[in][im][0] * p.alpha, acc[in][im][1] * p.alpha, acc[in][im][2] * p.alpha, acc[in][im][3] * p.alpha};
@@ -618,16 +621,26 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmP p) {
   }
 }
 
-int launch_skinny(const GemmP& p, hipStream_t s) {
-  constexpr int LDS = (SK_TM + SK_TN) * SK_KC * 2;
+template <int KC, int TN>
+int launch_skinny_cfg(const GemmP& p, hipStream_t s) {
+  constexpr int LDS = (SK_TM + TN) * KC * 2;
   static bool attr_done = false;
+  auto kern = gemm_skinny_kernel<KC, TN>;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_done = true;
   }
-  dim3 grid((unsigned)cdiv(p.N, SK_TN), (unsigned)cdiv(p.M, SK_TM), 1);
-  hipLaunchKernelGGL(gemm_skinny_kernel, grid, dim3(NTHR), LDS, s, p);
+  dim3 grid((unsigned)cdiv(p.N, TN), (unsigned)cdiv(p.M, SK_TM), 1);
+  hipLaunchKernelGGL(kern, grid, dim3(NTHR), LDS, s, p);
   return evk_check_launch("gemm_skinny_kernel");
+}
+
+int launch_skinny(const GemmP& p, hipStream_t s) {
+  // <= 256 rows (relational memory, decode step): the whole K = 512 panel in flight at once and 16-column blocks (twice the
+  // blocks) -- one memory round trip per 512 of K instead of two.  Larger M: 2x the LDS per block would halve the residency.
+  static const int deep = [] { const char* e = getenv("EVK_SKINNY_DEEP"); return e ? atoi(e) : 1; }();
+  if (deep && p.K % 512 == 0 && p.M <= 256) return launch_skinny_cfg<512, 16>(p, s);
+  return launch_skinny_cfg<256, 32>(p, s);
 }
 
 // ------------------------------------------------------------------------------------------------
