@@ -269,3 +269,45 @@ def test_distilgpt2_backend_matches_hf_fixture():
     assert seq.dtype == torch.long and seq.shape[0] == 3 and bool((seq[:, 0] == V - 2).all())
     ops.set_dropout_enabled(True)
     assert not bad, bad
+
+
+def test_loss_parity_at_realistic_token_count():
+    """Eval-mode loss at a realistic token count (8 studies x 2 views, <= 60 report tokens, 30 indication tokens) against the
+    fp32 CPU oracle on the same procedural weights.  The north star's goal is 1e-3; the engine stores activations in bf16
+    and measures |d| = 3.5e-3 on a loss of 7.80 (4.5e-4 relative) here -- the same as on the 40-token golden cases, i.e. a
+    bias of the bf16 storage chain, not token noise.  tools/precision_experiment.py shows that recomputing the final
+    LayerNorm + logits + NLL in fp32 from the engine's decoder output leaves the difference unchanged (3.55e-3): it is
+    accumulated upstream, so only an f32-class precision mode can meet 1e-3.  Tolerance written
+    here: 5e-3 absolute, as for the golden eval cases."""
+    from evoke_amd import ops
+    from evoke_amd.model_pretrain_finetune import FineTune
+    from oracle import functional as O
+    from oracle import spec as S
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    args = dict(ARGS)
+    model = FineTune(args, load_tokenizer(), 'iu_xray')
+    load_procedural(model, S.finetune_spec(V))
+    model.eval()
+    ops.set_dropout_enabled(False)
+    g = torch.Generator().manual_seed(21)
+    B, L, Li = 8, 60, 30
+    images = torch.randn(2 * B, 3, 224, 224, generator=g)
+    ids = torch.randint(5, V - 2, (B, L), generator=g)
+    ids[:, 0] = V - 2
+    masks = torch.ones(B, L, dtype=torch.long)
+    for i in range(B):
+        ln = L - 4 * i
+        ids[i, ln - 1] = V - 1
+        ids[i, ln:] = 0
+        masks[i, ln:] = 0
+    inc = torch.randint(5, V - 2, (B, Li), generator=g)
+    inc[:, 0] = 1
+    incm = torch.ones(B, Li, dtype=torch.long)
+    pids = np.array(['p%d_s%d' % (i % B, i % B) for i in range(2 * B)])
+    with torch.no_grad():
+        hip = model(images.cuda(), ids.cuda(), masks.cuda(), pids, inc, incm, mode='train')['all_loss'].item()
+        P = {k: v.detach().float().cpu() for k, v in model.state_dict().items() if not k.endswith('position_ids')}
+        ref = O.finetune_forward_train(P, images, ids, masks, pids, inc, incm)['all_loss'].item()
+    ops.set_dropout_enabled(True)
+    print('\n[realistic] loss hip %.6f oracle %.6f diff %.2e' % (hip, ref, abs(hip - ref)))
+    assert abs(hip - ref) <= LOSS_TOL, (hip, ref)
