@@ -152,7 +152,16 @@ class GradReducer:
             return
         fi, s, e = self.buckets[b]
         if self.flat[fi].is_cuda:
-            ops.join_side_streams()       # gradients are accumulated in place from side streams (wgrad, rm, text)
+            # Gradients are accumulated in place from several streams (main, wgrad, rm, text).  The collective is issued from
+            # a dedicated stream that waits for all of them, so the main stream is NOT held back at every bucket boundary
+            # (RCCL orders itself after the stream that is current at the call); finish() joins the handles.
+            cur = torch.cuda.current_stream()
+            comm = ops.side_stream('comm')
+            comm.wait_stream(cur)
+            ops.join_side_streams(into=comm, skip='comm')
+            with torch.cuda.stream(comm):
+                self.handles.append(dist.all_reduce(self.flat[fi][s:e], op=dist.ReduceOp.SUM, async_op=True))
+            return
         self.handles.append(dist.all_reduce(self.flat[fi][s:e], op=dist.ReduceOp.SUM, async_op=True))
 
     def on_grad(self, p):

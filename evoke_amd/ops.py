@@ -96,12 +96,13 @@ def side_stream(name, device=None):
 _main_stream = {}
 
 
-def join_side_streams():
-    """Make the current stream wait for everything queued on the side streams and on the main stream (called before the
-    optimizer / gradient all-reduce, because parameter gradients are accumulated in place from those streams)."""
-    cur = torch.cuda.current_stream()
+def join_side_streams(into=None, skip=None):
+    """Make `into` (default: the current stream) wait for everything queued on the side streams and on the main stream
+    (called before the optimizer / gradient all-reduce, because parameter gradients are accumulated in place from those
+    streams).  `skip` names a side stream to leave out."""
+    cur = torch.cuda.current_stream() if into is None else into
     for (name, dev), st in _side_streams.items():
-        if dev == cur.device.index and st != cur:
+        if dev == cur.device.index and st != cur and name != skip:
             cur.wait_stream(st)
     main = _main_stream.get(cur.device.index)
     if main is not None and main != cur:
