@@ -204,6 +204,11 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # The step's own (critical-path) stream gets the higher HIP queue priority; the side streams (weight gradients, relational
+    # memory, text encoder, collectives) keep the default one and fill the CUs the main stream leaves idle.
+    main_stream = torch.cuda.Stream(device=dev, priority=-1) if os.environ.get('EVK_MAIN_PRIO', '1') == '1' else torch.cuda.current_stream()
+    main_stream.wait_stream(torch.cuda.current_stream())
+    torch.cuda.set_stream(main_stream)
     for _ in range(a.warmup):
         step()
     barrier()
