@@ -11,6 +11,10 @@ __device__ __forceinline__ void ld8(const bf16_t* p, float (&v)[8]) {
   v[0] = lo_bf(a.x); v[1] = hi_bf(a.x); v[2] = lo_bf(a.y); v[3] = hi_bf(a.y);
   v[4] = lo_bf(a.z); v[5] = hi_bf(a.z); v[6] = lo_bf(a.w); v[7] = hi_bf(a.w);
 }
+__device__ __forceinline__ void unpack8(const uint4& u, float (&v)[8]) {
+  v[0] = lo_bf(u.x); v[1] = hi_bf(u.x); v[2] = lo_bf(u.y); v[3] = hi_bf(u.y);
+  v[4] = lo_bf(u.z); v[5] = hi_bf(u.z); v[6] = lo_bf(u.w); v[7] = hi_bf(u.w);
+}
 __device__ __forceinline__ void st8(bf16_t* p, const float (&v)[8]) {
   *reinterpret_cast<uint4*>(p) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
 }
@@ -151,58 +155,97 @@ __global__ void bn_finalize_kernel(const FinP p) {
   p.invstd[c] = is;
 }
 
-// y = relu?(x*scale[c] + shift[c] + resid)
+// y = relu?(x*scale[c] + shift[c] + resid).  The grid stride (gridDim.x * 256) is a multiple of G (G divides 256), so a thread
+// keeps the same 8 channels for all its iterations: scale / shift are loaded once; two iterations of loads are in flight.
 __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict__ x, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const bf16_t* __restrict__ resid,
                                                        bf16_t* __restrict__ y, long total8, int G, int relu) {
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total8; i += (long)gridDim.x * blockDim.x) {
-    const int cg = (int)(i % G);
-    float v[8], sc[8], sh[8];
-    ld8(x + i * 8, v);
-    *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(scale + cg * 8);
-    *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(scale + cg * 8 + 4);
-    *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(shift + cg * 8);
-    *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(shift + cg * 8 + 4);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + sh[j];
+  const int cg = threadIdx.x % G;
+  float sc[8], sh[8];
+  *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(scale + cg * 8);
+  *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(scale + cg * 8 + 4);
+  *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(shift + cg * 8);
+  *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(shift + cg * 8 + 4);
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total8; i += 2 * stride) {
+    const long i2 = i + stride;
+    const bool two = i2 < total8;
+    uint4 xa = *reinterpret_cast<const uint4*>(x + i * 8), xb = two ? *reinterpret_cast<const uint4*>(x + i2 * 8) : make_uint4(0, 0, 0, 0);
+    uint4 ra = make_uint4(0, 0, 0, 0), rb = ra;
     if (resid) {
-      float r[8];
-      ld8(resid + i * 8, r);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] += r[j];
+      ra = *reinterpret_cast<const uint4*>(resid + i * 8);
+      if (two) rb = *reinterpret_cast<const uint4*>(resid + i2 * 8);
     }
-    if (relu) {
+    float v[8], r[8];
+    unpack8(xa, v);
+    unpack8(ra, r);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-    }
+    for (int j = 0; j < 8; ++j) { v[j] = v[j] * sc[j] + sh[j] + r[j]; if (relu) v[j] = fmaxf(v[j], 0.f); }
     st8(y + i * 8, v);
+    if (two) {
+      unpack8(xb, v);
+      unpack8(rb, r);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { v[j] = v[j] * sc[j] + sh[j] + r[j]; if (relu) v[j] = fmaxf(v[j], 0.f); }
+      st8(y + i2 * 8, v);
+    }
   }
 }
 
-// dx = scale[c] * (g - sum_g[c]/cnt - xhat * sum_gx[c]/cnt), g = dz * (z>0);  dres = g (optional)
 struct BwdP {
   const bf16_t* dz; const bf16_t* z; const bf16_t* x; const float* scale; const float* mean; const float* invstd;
   const float* sum_g; const float* sum_gx; bf16_t* dx; bf16_t* dres; long total8; int G; int relu; float inv_count;
 };
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BwdP p) {
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < p.total8; i += (long)gridDim.x * blockDim.x) {
-    const int c0 = (int)(i % p.G) * 8;
-    float g[8], xv[8], o[8];
-    ld8(p.dz + i * 8, g);
+  // dx = scale * (g - sum_g/n - xhat * sum_gx/n), xhat = (x - mean) * invstd  ==  A*g + B*x + C per channel; a thread keeps its
+  // 8 channels (grid stride is a multiple of G), so the coefficients are formed once instead of 40 scalar loads per iteration
+  const int c0 = (threadIdx.x % p.G) * 8;
+  float A[8], B[8], Cc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float sc = p.scale[c0 + j], is = p.invstd[c0 + j], mu = p.mean[c0 + j];
+    const float sg = p.sum_g[c0 + j] * p.inv_count, sgx = p.sum_gx[c0 + j] * p.inv_count;
+    A[j] = sc;
+    B[j] = -sc * is * sgx;
+    Cc[j] = sc * (mu * is * sgx - sg);
+  }
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < p.total8; i += 2 * stride) {
+    const long i2 = i + stride;
+    const bool two = i2 < p.total8;
+    const uint4 ga = *reinterpret_cast<const uint4*>(p.dz + i * 8), xa = *reinterpret_cast<const uint4*>(p.x + i * 8);
+    const uint4 gb = two ? *reinterpret_cast<const uint4*>(p.dz + i2 * 8) : make_uint4(0, 0, 0, 0);
+    const uint4 xb = two ? *reinterpret_cast<const uint4*>(p.x + i2 * 8) : make_uint4(0, 0, 0, 0);
+    uint4 za = make_uint4(0, 0, 0, 0), zb = za;
     if (p.relu) {
-      float zv[8];
-      ld8(p.z + i * 8, zv);
+      za = *reinterpret_cast<const uint4*>(p.z + i * 8);
+      if (two) zb = *reinterpret_cast<const uint4*>(p.z + i2 * 8);
+    }
+    float g[8], xv[8], zv[8], o[8];
+    unpack8(ga, g);
+    unpack8(xa, xv);
+    if (p.relu) {
+      unpack8(za, zv);
 #pragma unroll
       for (int j = 0; j < 8; ++j) g[j] = zv[j] > 0.f ? g[j] : 0.f;
     }
-    ld8(p.x + i * 8, xv);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float xh = (xv[j] - p.mean[c0 + j]) * p.invstd[c0 + j];
-      o[j] = p.scale[c0 + j] * (g[j] - p.sum_g[c0 + j] * p.inv_count - xh * p.sum_gx[c0 + j] * p.inv_count);
-    }
+    for (int j = 0; j < 8; ++j) o[j] = A[j] * g[j] + B[j] * xv[j] + Cc[j];
     st8(p.dx + i * 8, o);
     if (p.dres) st8(p.dres + i * 8, g);
+    if (two) {
+      unpack8(gb, g);
+      unpack8(xb, xv);
+      if (p.relu) {
+        unpack8(zb, zv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = zv[j] > 0.f ? g[j] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = A[j] * g[j] + B[j] * xv[j] + Cc[j];
+      st8(p.dx + i2 * 8, o);
+      if (p.dres) st8(p.dres + i2 * 8, g);
+    }
   }
 }
 
@@ -443,7 +486,7 @@ int evk_bn_finalize(const float* sum, const float* sumsq, const float* gamma, co
 int evk_bn_apply(const void* x, const float* scale, const float* shift, const void* resid, void* y, int64_t M, int32_t C,
                  int32_t relu, evk_stream_t stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  EVK_REQUIRE(x && scale && shift && y && M > 0 && C % 8 == 0, "bn_apply: bad args");
+  EVK_REQUIRE(x && scale && shift && y && M > 0 && C % 8 == 0 && 256 % (C / 8) == 0, "bn_apply: bad args (C must be a power-of-two multiple of 8, <= 2048)");
   const long total8 = M * (C / 8);
   ProfScope ps(EVK_FAM_ELTWISE, s);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(total8)), dim3(256), 0, s, (const bf16_t*)x, scale, shift,
@@ -471,7 +514,8 @@ int evk_bn_bwd_apply(const void* dz, const void* z, const void* x, const float* 
                      const float* sum_g, const float* sum_gx, void* dx, void* dres, int64_t M, int32_t C, int32_t relu,
                      evk_stream_t stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  EVK_REQUIRE(dz && x && scale && mean && invstd && sum_g && sum_gx && dx && (!relu || z) && M > 0 && C % 8 == 0, "bn_bwd_apply: bad args");
+  EVK_REQUIRE(dz && x && scale && mean && invstd && sum_g && sum_gx && dx && (!relu || z) && M > 0 && C % 8 == 0 && 256 % (C / 8) == 0,
+              "bn_bwd_apply: bad args (C must be a power-of-two multiple of 8, <= 2048)");
   BwdP p{(const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)x, scale, mean, invstd, sum_g, sum_gx, (bf16_t*)dx, (bf16_t*)dres,
          M * (C / 8), C / 8, relu, 1.f / (float)M};
   ProfScope ps(EVK_FAM_ELTWISE, s);
