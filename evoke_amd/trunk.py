@@ -112,8 +112,8 @@ class _WsLease:
 
 
 class _TrunkFn(torch.autograd.Function):
-    """ResNet trunk forward / backward through evk_trunk_forward / evk_trunk_backward.  `anchor` (the stem weight) only ties
-    the node into the autograd graph; parameter gradients are accumulated in place by the runner."""
+    """ResNet trunk forward / backward through evk_trunk_forward / evk_trunk_backward.  `anchor` (any trainable trunk parameter)
+    only ties the node into the autograd graph; parameter gradients are accumulated in place by the runner."""
 
     @staticmethod
     def _layers(pairs, with_grads):
@@ -377,7 +377,8 @@ class ResNetTrunk(nn.Sequential):
         assert images.dtype == F32 and images.is_cuda and images.dim() == 4 and images.shape[1] == 3
         if self.training:
             torch._foreach_add_([bn.num_batches_tracked for _, bn in self.pairs()], 1)
-        return _TrunkFn.apply(images.contiguous(), self[0].weight, self)
+        anchor = next((p for p in self.parameters() if p.requires_grad), self[0].weight)   # ties the node into the autograd graph
+        return _TrunkFn.apply(images.contiguous(), anchor, self)
 
 
 class ResNet(nn.Module):

@@ -426,3 +426,31 @@ def test_decode_attention_matches_reference():
             H.check(H.lib.evk_decode_attention(H.ptr(q4), H.ptr(k4), H.ptr(v4), H.ptr(m4) if m4 is not None else None, H.ptr(ref4), 4 * R, S,
                                                heads, 64, 1, C.c_float(0.125), H.stream()))
             assert torch.equal(out4, ref4)
+
+
+def test_native_trunk_frozen_parameters_and_no_grad():
+    """Partially frozen trunk (conv weights frozen, batch-norm affine trainable), fully frozen trunk, and no_grad inference."""
+    from evoke_amd import ops, trunk as T
+    torch.manual_seed(3)
+    ops.clear_grad_callbacks()
+    t = T.ResNetTrunk().cuda().train()
+    img = torch.randn(2, 3, 64, 64, device='cuda')
+    for cv, bn in t.pairs():
+        cv.weight.requires_grad_(False)
+    y = t(img)
+    y.float().square().mean().backward()
+    ops.join_side_streams()
+    torch.cuda.synchronize()
+    for cv, bn in t.pairs():
+        assert cv.weight.grad is None
+        assert bn.weight.grad is not None and torch.isfinite(bn.weight.grad).all() and torch.isfinite(bn.bias.grad).all()
+    assert float(t[7][2].bn3.weight.grad.abs().sum()) > 0
+    for p in t.parameters():
+        p.requires_grad_(False)
+        p.grad = None
+    y2 = t(img)
+    assert not y2.requires_grad and torch.isfinite(y2.float()).all()
+    t.eval()
+    with torch.no_grad():
+        y3 = t(img)
+    assert y3.shape == (2, 2, 2, 2048) and torch.isfinite(y3.float()).all()
