@@ -26,7 +26,7 @@ struct GemmP {
   int M, N, K;
   long lda, ldb, ldc, ldr;
   int bi;
-  long sAo, sAi, sBo, sBi, sCo, sCi, sRo, sRi;
+  long sAo, sAi, sBo, sBi, sCo, sCi, sRo, sRi, sbias;
   float alpha; int act, c_f32, r_f32, accumulate, vec_ok;
   int ksteps_per_split, tilesN, kslice_xcd;
   int lds_store;                    // bf16 output rows leave through LDS in 16-byte pieces (needs N % 8 == 0, ldc % 8 == 0, aligned C)
@@ -324,9 +324,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[4][4]
         continue;
       }
       if (p.bias) {
+        const float* bias = p.bias + zi * p.sbias;       // per inner-batch bias rows (sbias = 0: shared)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          if (n0 + j < p.N) v[j] += p.bias[n0 + j];
+          if (n0 + j < p.N) v[j] += bias[n0 + j];
       }
       if (p.act != EVK_ACT_NONE) {
 #pragma unroll
@@ -906,6 +907,7 @@ extern "C" int evk_gemm_launch(const evk_gemm* d, evk_stream_t stream) {
   p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldr = d->ldr;
   p.bi = d->batch_inner;
   p.sAo = d->sAo; p.sAi = d->sAi; p.sBo = d->sBo; p.sBi = d->sBi; p.sCo = d->sCo; p.sCi = d->sCi; p.sRo = d->sRo; p.sRi = d->sRi;
+  p.sbias = d->bias_stride_inner;
   p.alpha = d->alpha; p.act = d->act; p.c_f32 = d->c_dtype == EVK_F32; p.r_f32 = d->r_dtype == EVK_F32;
   p.accumulate = d->accumulate;
   p.colstats = reinterpret_cast<float*>(d->colstats);

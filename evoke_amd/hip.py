@@ -31,7 +31,8 @@ class Gemm(C.Structure):
                 ('sCo', C.c_int64), ('sCi', C.c_int64), ('sRo', C.c_int64), ('sRi', C.c_int64),
                 ('alpha', C.c_float), ('act', C.c_int32), ('c_dtype', C.c_int32), ('r_dtype', C.c_int32),
                 ('accumulate', C.c_int32), ('splitk', C.c_int32), ('b_klog', C.c_int32), ('b_tapstride', C.c_int64),
-                ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64), ('relu_gate', C.c_void_p), ('ldg', C.c_int64),
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64), ('bias_stride_inner', C.c_int64), ('relu_gate', C.c_void_p),
+                ('ldg', C.c_int64),
                 ('colstats', C.c_void_p), ('g', ConvGeom)]
 
 

@@ -351,9 +351,79 @@ class ConditionalLayerNorm(nn.Module):
                 nn.init.constant_(m.bias, 0.1)
 
     def forward(self, x, memory):
-        dg = self.mlp_gamma[2](self.mlp_gamma[0](memory, act=H.ACT_RELU))
-        db = self.mlp_beta[2](self.mlp_beta[0](memory, act=H.ACT_RELU))
+        pre = getattr(memory, 'evk_cln_deltas', None)             # filled by Decoder.forward: all norms' MLPs in two GEMMs
+        if pre is not None and id(self) in pre:
+            dg, db = pre[id(self)]
+        else:
+            dg = self.mlp_gamma[2](self.mlp_gamma[0](memory, act=H.ACT_RELU))
+            db = self.mlp_beta[2](self.mlp_beta[0](memory, act=H.ACT_RELU))
         return ops.layernorm(x, self.gamma, self.beta, eps=self.eps, mode=1, dgam=dg, dbet=db)
+
+
+FUSED_CLN = [True]          # conditional-LayerNorm MLPs of the decoder as two fused GEMMs (training path)
+
+
+class _ClnHolder:
+    def __init__(self, clns):
+        self.clns = clns
+
+
+class _FusedCLNDeltas(torch.autograd.Function):
+    """All conditional-LayerNorm delta MLPs of the decoder in two GEMMs (training-time counterpart of decode._FusedDecodeWeights).
+    The 2*n first layers (mlp_gamma[0] / mlp_beta[0] of every ConditionalLayerNorm, encoder_decoder.py:144-179) read the same
+    relational-memory rows, so their bf16 weight shadows are concatenated along N and run as ONE GEMM (N = 2n x 512) with the
+    ReLU in the epilogue; the second layers run as ONE batched GEMM (batch 2n, per-batch bias).  Backward: one batched GEMM for
+    d(hidden), one GEMM for d(memory); the 4n small weight-gradient GEMMs / bias column sums go to the weight-gradient stream."""
+
+    @staticmethod
+    def forward(ctx, memory, holder):
+        clns = holder.clns
+        lins1 = [m for c in clns for m in (c.mlp_gamma[0], c.mlp_beta[0])]
+        lins2 = [m for c in clns for m in (c.mlp_gamma[2], c.mlp_beta[2])]
+        n, d, K = len(lins1), lins1[0].weight.shape[0], memory.shape[-1]
+        R = memory.numel() // K
+        dev = memory.device
+        W1 = torch.cat([ops.shadow(m.weight).view(-1) for m in lins1]).view(n * d, K)
+        b1 = torch.cat([m.bias.detach() for m in lins1])
+        W2 = torch.cat([ops.shadow(m.weight).view(-1) for m in lins2]).view(n, d, d)
+        b2 = torch.cat([m.bias.detach() for m in lins2])
+        hid = torch.empty(R, n * d, dtype=BF16, device=dev)
+        ops.gemm(memory, W1, hid, R, n * d, K, lda=K, ldb=K, ldc=n * d, bias=b1, act=H.ACT_RELU)
+        out = torch.empty(n, R, d, dtype=BF16, device=dev)
+        ops.gemm(hid, W2, out, R, d, d, lda=n * d, ldb=d, ldc=d, batch=(1, n), sA=(0, d), sB=(0, d * d), sC=(0, R * d), bias=b2, bias_stride=d)
+        ctx.save_for_backward(memory, hid, W1, W2)
+        ctx.lins, ctx.dims = (lins1, lins2), (n, d, K, R)
+        shape = memory.shape[:-1] + (d,)
+        return tuple(out[i].view(shape) for i in range(n))
+
+    @staticmethod
+    def backward(ctx, *douts):
+        memory, hid, W1, W2 = ctx.saved_tensors
+        lins1, lins2 = ctx.lins
+        n, d, K, R = ctx.dims
+        dev = memory.device
+        dout = torch.stack([(g if g is not None else torch.zeros(R, d, dtype=BF16, device=dev)).reshape(R, d).to(BF16) for g in douts]).contiguous()
+        dhid = torch.empty(R, n * d, dtype=BF16, device=dev)
+        ops.gemm(dout, W2, dhid, R, d, d, b_mode=H.B_KSTR, lda=d, ldb=d, ldc=n * d, batch=(1, n), sA=(0, R * d), sB=(0, d * d), sC=(0, d))
+        H.check(H.lib.evk_act_bwd(H.ptr(dhid), H.ptr(hid), H.ptr(dhid), R * n * d, H.ACT_RELU, H.stream()), 'act_bwd')
+        dmem = torch.empty(R, K, dtype=BF16, device=dev)
+        ops.gemm(dhid, W1, dmem, R, K, n * d, b_mode=H.B_KSTR, lda=n * d, ldb=K, ldc=K)
+        with ops.wgrad_stream(dout, dhid, hid, memory):
+            for i in range(n):
+                l1, l2 = lins1[i], lins2[i]
+                if l2.weight.requires_grad:     # dW2_i += dout_i^T hid_i ; db2_i += colsum(dout_i)
+                    ops.gemm(dout, hid, ops.grad_buffer(l2.weight), d, d, R, a_mode=H.A_KSTR, b_mode=H.B_KSTR, lda=d, ldb=n * d, ldc=d,
+                             accumulate=True, a_off=i * R * d, b_off=i * d)
+                    H.check(H.lib.evk_colsum(dout.data_ptr() + 2 * i * R * d, H.ptr(ops.grad_buffer(l2.bias)), R, d, d, H.stream()), 'colsum')
+                if l1.weight.requires_grad:     # dW1_i += dhid_i^T memory ; db1_i += colsum(dhid_i)
+                    ops.gemm(dhid, memory, ops.grad_buffer(l1.weight), d, K, R, a_mode=H.A_KSTR, b_mode=H.B_KSTR, lda=n * d, ldb=K, ldc=K,
+                             accumulate=True, a_off=i * d)
+                    H.check(H.lib.evk_colsum(dhid.data_ptr() + 2 * i * d, H.ptr(ops.grad_buffer(l1.bias)), R, d, n * d, H.stream()), 'colsum')
+        for lin in list(lins1) + list(lins2):
+            if lin.weight.requires_grad:
+                ops.grad_done(lin.weight)
+                ops.grad_done(lin.bias)
+        return dmem.view(memory.shape), None
 
 
 class MultiHeadedAttention(nn.Module):
@@ -452,6 +522,12 @@ class Decoder(nn.Module):
         self.norm = R2LayerNorm(d_model)
 
     def forward(self, x, enc, src_mask, tgt_key_mask, memory):
+        if memory.is_cuda and FUSED_CLN[0]:
+            if not hasattr(self, '_cln_holder'):
+                object.__setattr__(self, '_cln_holder', _ClnHolder([layer.sublayer[j].norm for layer in self.layers for j in range(3)]))
+            clns = self._cln_holder.clns
+            outs = _FusedCLNDeltas.apply(memory.contiguous(), self._cln_holder)
+            memory.evk_cln_deltas = {id(c): (outs[2 * i], outs[2 * i + 1]) for i, c in enumerate(clns)}
         for layer in self.layers:
             x = layer(x, enc, src_mask, tgt_key_mask, memory)
         return self.norm(x)

@@ -223,7 +223,7 @@ def _e(*shape, dtype=BF16, device='cuda'):
 # ----------------------------------------------------------------------------------------------------
 def gemm(A, B, Cm, M, N, K, a_mode=H.A_PLAIN, b_mode=H.B_PLAIN, lda=0, ldb=0, ldc=0, bias=None, resid=None, ldr=0,
          act=H.ACT_NONE, alpha=1.0, accumulate=False, batch=(1, 1), sA=(0, 0), sB=(0, 0), sC=(0, 0), sR=(0, 0),
-         a_off=0, b_off=0, c_off=0, b_klog=0, b_tapstride=0, splitk=0):
+         a_off=0, b_off=0, c_off=0, b_klog=0, b_tapstride=0, splitk=0, bias_stride=0):
     d = H.Gemm()
     d.A = A.data_ptr() + a_off * A.element_size()
     d.B = B.data_ptr() + b_off * B.element_size()
@@ -243,6 +243,7 @@ def gemm(A, B, Cm, M, N, K, a_mode=H.A_PLAIN, b_mode=H.B_PLAIN, lda=0, ldb=0, ld
     d.accumulate = 1 if accumulate else 0
     d.splitk = splitk
     d.b_klog, d.b_tapstride = b_klog, b_tapstride
+    d.bias_stride_inner = bias_stride
     if accumulate:
         nb = H.lib.evk_gemm_workspace_bytes(C.byref(d))
         if nb > 0:

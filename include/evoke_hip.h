@@ -66,6 +66,7 @@ typedef struct evk_gemm {
   int32_t b_klog; int64_t b_tapstride;   /* EVK_B_KSTR two-level K (see enum)                           */
   void* workspace; int64_t workspace_bytes; /* accumulate + split-K: partial slabs (evk_gemm_workspace_bytes);
                                             without it split-K falls back to f32 atomics                  */
+  int64_t bias_stride_inner;     /* bias row used by inner batch index zi = bias + zi * bias_stride_inner (0: one shared bias)   */
   const void* relu_gate; int64_t ldg; /* optional bf16 [M][ldg]: C = relu_gate > 0 ? C : 0, applied after resid (the gradient of
                                     a ReLU whose forward output is relu_gate); batch 1, no accumulate                   */
   void* colstats;                /* optional f32 [ceil(M/64) (rounded to the tile)][2][N]: per 64-row block column sums and
