@@ -107,10 +107,11 @@ class BertAttention(nn.Module):
         self.heads, self.p_attn, self.p_hidden = heads, p_attn, p_hidden
 
     def forward(self, x, kv=None, mask=None):
-        kv = x if kv is None else kv
-        q = self.self.query(x)
-        k = self.self.key(kv)
-        v = self.self.value(kv)
+        if kv is None:
+            q, k, v = ops.sibling_linears(x, (self.self.query, self.self.key, self.self.value))
+        else:
+            q = self.self.query(x)
+            k, v = ops.sibling_linears(kv, (self.self.key, self.self.value))
         c = ops.attention(q, k, v, self.heads, mask=mask, p_drop=self.p_attn, training=self.training)
         o = ops.linear_dropout_resid(c, self.output.dense.weight, self.output.dense.bias, x, self.p_hidden, self.training)
         return self.output.LayerNorm(o)
@@ -435,9 +436,13 @@ class MultiHeadedAttention(nn.Module):
         self.linears = nn.ModuleList([LinearP(d_model, d_model) for _ in range(4)])
 
     def forward(self, q_in, k_in, v_in, mask=None, causal=False, resid=None):
-        q = self.linears[0](q_in)
-        k = self.linears[1](k_in)
-        v = self.linears[2](v_in)
+        if q_in is k_in and k_in is v_in:
+            q, k, v = ops.sibling_linears(q_in, (self.linears[0], self.linears[1], self.linears[2]))
+        elif k_in is v_in:
+            q = self.linears[0](q_in)
+            k, v = ops.sibling_linears(k_in, (self.linears[1], self.linears[2]))
+        else:
+            q, k, v = self.linears[0](q_in), self.linears[1](k_in), self.linears[2](v_in)
         c = ops.attention(q, k, v, self.h, mask=mask, causal=causal, p_drop=self.p, training=self.training)
         return self.linears[3](c, resid=resid)
 

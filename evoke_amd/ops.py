@@ -354,6 +354,68 @@ class _LinearT(torch.autograd.Function):
         return dx, None, None, (dy if ctx.has_resid else None)
 
 
+class _SiblingLinears(torch.autograd.Function):
+    """n nn.Linear layers with EQUAL shapes applied to the SAME input (q / k / v projections; k / v of a cross-attention):
+    forward = one batched GEMM over the concatenated bf16 weight shadows (shared A, per-batch bias, one contiguous output
+    plane per layer); backward = one GEMM for dX over the concatenated output gradients; the n weight / bias gradients go to
+    the weight-gradient stream.  Replaces n GEMMs + (n - 1) gradient-accumulation adds per direction."""
+
+    @staticmethod
+    def forward(ctx, x, holder):
+        lins = holder.lins
+        n, N, K = len(lins), lins[0].weight.shape[0], x.shape[-1]
+        R = x.numel() // K
+        W = torch.cat([shadow(m.weight).view(-1) for m in lins]).view(n * N, K)
+        b = torch.cat([m.bias.detach() for m in lins])
+        out = torch.empty(n, R, N, dtype=BF16, device=x.device)
+        gemm(x, W, out, R, N, K, lda=K, ldb=K, ldc=N, batch=(1, n), sB=(0, N * K), sC=(0, R * N), bias=b, bias_stride=N)
+        ctx.save_for_backward(x, W)
+        ctx.lins, ctx.dims = lins, (n, N, K, R)
+        shape = x.shape[:-1] + (N,)
+        return tuple(out[i].view(shape) for i in range(n))
+
+    @staticmethod
+    def backward(ctx, *dys):
+        x, W = ctx.saved_tensors
+        lins = ctx.lins
+        n, N, K, R = ctx.dims
+        dev = x.device
+        dy = torch.cat([(g if g is not None else torch.zeros(R, N, dtype=BF16, device=dev)).reshape(R, N).to(BF16) for g in dys], dim=1).contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(R, K, dtype=BF16, device=dev)
+            gemm(dy, W, dx, R, K, n * N, b_mode=H.B_KSTR, lda=n * N, ldb=K, ldc=K)
+            dx = dx.view(x.shape)
+        with wgrad_stream(dy, x):
+            for i, m in enumerate(lins):
+                if m.weight.requires_grad:
+                    gemm(dy, x, grad_buffer(m.weight), N, K, R, a_mode=H.A_KSTR, b_mode=H.B_KSTR, lda=n * N, ldb=K, ldc=K, accumulate=True, a_off=i * N)
+                if m.bias is not None and m.bias.requires_grad:
+                    H.check(H.lib.evk_colsum(dy.data_ptr() + 2 * i * N, H.ptr(grad_buffer(m.bias)), R, N, n * N, H.stream()), 'colsum')
+        for m in lins:
+            if m.weight.requires_grad:
+                grad_done(m.weight)
+            if m.bias is not None and m.bias.requires_grad:
+                grad_done(m.bias)
+        return dx, None
+
+
+class _LinHolder:
+    def __init__(self, lins):
+        self.lins = lins
+
+
+FUSED_SIBLINGS = [True]
+
+
+def sibling_linears(x, lins):
+    """[lin(x) for lin in lins] for parameter holders with .weight (N, K) / .bias (N) of equal shape (N, K multiples of 8)."""
+    N, K = lins[0].weight.shape
+    if (not FUSED_SIBLINGS[0] or not x.is_cuda or len(lins) < 2 or N % 8 or K % 8 or any(m.weight.shape != (N, K) or m.bias is None for m in lins)):
+        return tuple(linear(x, m.weight, m.bias) for m in lins)
+    return _SiblingLinears.apply(x.contiguous(), _LinHolder(list(lins)))
+
+
 def linear_t(x, W, b=None, resid=None):
     """x (.., in) @ W (in, out) + b (+ resid): the Conv1D layout of HF GPT-2 (in and out multiples of 8)."""
     assert x.dtype == BF16 and x.is_contiguous() and W.shape[0] % 8 == 0 and W.shape[1] % 8 == 0
