@@ -250,8 +250,8 @@ def multi_pos_contra_images(global_image_embed, patient_ids, temp, gather=None):
         return torch.tensor([0.0], requires_grad=True, device=global_image_embed.device)
     labels = labels[idx][:, idx]
     labels = labels / labels.sum(1, keepdims=True)
-    t = torch.from_numpy(labels).to(g.device)
-    gi = l2_normalize(g.index_select(0, torch.from_numpy(idx).to(g.device)))
+    t = ops.upload(labels, g.device)
+    gi = l2_normalize(g.index_select(0, ops.index_tensor(idx, g.device)))
     logits = matmul_nt(gi, gi) / temp
     # the reference subtracts the detached row max after the -1e9 diagonal fill: a no-op for log-softmax
     return soft_cross_entropy(logits, t, diag_mask=True)
@@ -265,7 +265,7 @@ def global_alignment(global_image_embed, global_text_embed, patient_ids, temp, g
         t, pid = gather(t, pid)
     labels = _same_study(pid)
     labels = labels / labels.sum(1, keepdims=True)
-    tg = torch.from_numpy(labels).to(v.device)
+    tg = ops.upload(labels, v.device)
     v, t = l2_normalize(v), l2_normalize(t)
     sim = matmul_nt(v, t) / temp
     sim_t = matmul_nt(t, v) / temp

@@ -109,31 +109,32 @@ def join_side_streams(into=None, skip=None):
         cur.wait_stream(main)
 
 
-class _IndexUploader:
-    """Host -> device upload of small int64 index arrays without stalling the host behind queued compute: a blocking
-    `torch.tensor(list, device=...)` is a synchronous copy ON THE CURRENT STREAM and therefore waits for every kernel queued
-    before it (the whole ResNet forward at the multi-view grouping point).  Here the data goes through a ring of pinned
-    staging buffers on a dedicated copy stream; the compute stream only waits for the copy's event on the GPU side."""
+class _Uploader:
+    """Host -> device upload of small arrays without stalling the host behind queued compute: a blocking
+    `torch.tensor(list, device=...)` / `.to(device)` of pageable memory is a synchronous copy ON THE CURRENT STREAM and therefore
+    waits for every kernel queued before it (the whole ResNet forward at the multi-view grouping point).  Here the data goes
+    through a ring of pinned staging buffers on a dedicated copy stream; the compute stream only waits for the copy's event."""
 
-    def __init__(self, device, slots=16, cap=1 << 15):
+    def __init__(self, device, slots=16, cap=1 << 18):
         self.device = device
-        self.bufs = [torch.empty(cap, dtype=torch.int64).pin_memory() for _ in range(slots)]
+        self.bufs = [torch.empty(cap, dtype=torch.uint8).pin_memory() for _ in range(slots)]
         self.events = [None] * slots
         self.i = 0
         self.stream = torch.cuda.Stream(device=device)
 
-    def put(self, values):
+    def put(self, arr):
         import numpy as np
-        arr = np.ascontiguousarray(np.asarray(values, dtype=np.int64).reshape(-1))
-        n = arr.shape[0]
-        if n > self.bufs[0].numel():
-            return torch.from_numpy(arr).to(self.device)          # oversize: plain (blocking) path
+        arr = np.ascontiguousarray(arr)
+        nb = arr.nbytes
+        tdt = torch.from_numpy(arr[:0].reshape(-1)).dtype
+        if nb > self.bufs[0].numel() or nb == 0:
+            return torch.from_numpy(arr).to(self.device)          # oversize / empty: plain (blocking) path
         k = self.i % len(self.bufs)
         self.i += 1
         if self.events[k] is not None:
             self.events[k].synchronize()                          # the copy issued `slots` uploads ago; long done
-        stage = self.bufs[k][:n]
-        stage.numpy()[:] = arr
+        stage = self.bufs[k][:nb]
+        stage.numpy()[:] = arr.reshape(-1).view(np.uint8)
         main = torch.cuda.current_stream(self.device)
         with torch.cuda.stream(self.stream):
             t = stage.to(self.device, non_blocking=True)
@@ -142,22 +143,31 @@ class _IndexUploader:
         self.events[k] = ev
         main.wait_event(ev)
         t.record_stream(main)
-        return t
+        return t.view(tdt).view(arr.shape)
 
 
 _uploaders = {}
 
 
-def index_tensor(values, device):
-    """int64 device tensor from a host list / array, uploaded asynchronously (see _IndexUploader)."""
+def upload(arr, device):
+    """device tensor (same dtype / shape) from a host numpy array, uploaded asynchronously (see _Uploader)."""
     device = torch.device(device)
     if device.type != 'cuda':
-        return torch.as_tensor(values, dtype=torch.long, device=device)
+        return torch.from_numpy(arr).to(device)
     key = device.index if device.index is not None else torch.cuda.current_device()
     up = _uploaders.get(key)
     if up is None:
-        up = _uploaders[key] = _IndexUploader(torch.device('cuda', key))
-    return up.put(values)
+        up = _uploaders[key] = _Uploader(torch.device('cuda', key))
+    return up.put(arr)
+
+
+def index_tensor(values, device):
+    """int64 device tensor from a host list / array, uploaded asynchronously."""
+    import numpy as np
+    device = torch.device(device)
+    if device.type != 'cuda':
+        return torch.as_tensor(values, dtype=torch.long, device=device)
+    return upload(np.asarray(values, dtype=np.int64).reshape(-1), device)
 
 
 WGRAD_SIDE_STREAM = [os.environ.get('EVK_LINEAR_WGRAD_SIDE', '1') == '1']      # linear-layer dW on the 'wgrad' stream

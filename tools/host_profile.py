@@ -1,10 +1,12 @@
-"""cProfile of the host side of the training step (where the Python launch time goes)."""
+"""cProfile of the host side of a bench workload: python tools/host_profile.py [finetune|pretrain] [res]"""
 import cProfile
 import io
 import pstats
 import sys
 
-sys.argv = ['bench.py', '--steps', '6', '--warmup', '3', '--no-prof', '--no-cpu-baseline']
+wl = sys.argv[1] if len(sys.argv) > 1 else 'finetune'
+res = sys.argv[2] if len(sys.argv) > 2 else '384'
+sys.argv = ['bench.py', '--workload', wl, '--res', res, '--steps', '20', '--warmup', '3', '--no-prof', '--no-cpu-baseline']
 sys.path.insert(0, '.')
 import bench  # noqa: E402
 
@@ -14,6 +16,5 @@ bench.main()
 pr.disable()
 s = io.StringIO()
 st = pstats.Stats(pr, stream=s)
-st.sort_stats('cumulative').print_stats(60)
-st.sort_stats('tottime').print_stats(45)
+st.sort_stats('tottime').print_stats(70)
 print(s.getvalue())
