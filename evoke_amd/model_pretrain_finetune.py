@@ -21,6 +21,12 @@ from .trunk import ResNet
 NO_FINDING = "there is no evidence of pulmonary."
 
 
+def _to_device_async(t, device):
+    if t.is_cuda:
+        return t
+    return ops.upload(t.contiguous().numpy(), device)
+
+
 class _Base(nn.Module):
     def __str__(self):
         params = sum(int(np.prod(p.size())) for p in self.parameters() if p.requires_grad)
@@ -115,7 +121,9 @@ class FineTune(_Base):
         y = side = None
         if inc_ids is not None:
             # the indication branch depends on the text only: run it on a side stream under the ResNet
-            inc_ids, inc_masks = inc_ids.to(device, non_blocking=True), inc_masks.to(device, non_blocking=True)
+            # the loaders hand the indication tokens over on the CPU (trainer_v0401.py:430): pinned ring + copy stream, never a
+            # pageable copy on the compute stream (that one blocks the host until the stream has drained)
+            inc_ids, inc_masks = _to_device_async(inc_ids, device), _to_device_async(inc_masks, device)
             y, side = self._side_branch('text', lambda: self.text_head(self.text_encoder(input_ids=inc_ids, attention_mask=inc_masks)))
         _, x = self._image_tokens(images, patient_ids, batch_size)
         enc_mask = torch.ones(x.shape[:2], dtype=torch.long, device=device)

@@ -17,4 +17,6 @@ pr.disable()
 s = io.StringIO()
 st = pstats.Stats(pr, stream=s)
 st.sort_stats('tottime').print_stats(70)
+st.print_callers("method 'to' of")
+st.print_callers("method 'contiguous' of")
 print(s.getvalue())
