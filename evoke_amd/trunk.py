@@ -105,9 +105,19 @@ class _WsLease:
         free = _WsLease._pool.setdefault(self.key, [])
         self.ws = free.pop() if free else torch.empty(int(nbytes), dtype=torch.uint8, device=device)
 
+    LIMIT = 64 << 30          # bytes kept idle in the pool per process (other shapes are evicted first)
+
     def __del__(self):
-        pool = _WsLease._pool.get(self.key)
-        if pool is not None and len(pool) < 2:
+        pools = _WsLease._pool
+        pool = pools.get(self.key)
+        if pool is None or len(pool) >= 1:
+            return
+        idle = sum(k[1] * len(v) for k, v in pools.items())
+        if idle + self.key[1] > _WsLease.LIMIT:
+            for k, v in pools.items():
+                if k != self.key:
+                    del v[:]
+        if self.key[1] <= _WsLease.LIMIT:
             pool.append(self.ws)
 
 
