@@ -13,6 +13,7 @@
 // other LDS buffer after them (one barrier per K-tile).
 // MFMA orientation is swapped (weights tile as the "A" operand) so each lane ends up with 4 consecutive
 // n of one row m -> 8/16-byte epilogue stores.
+#include <type_traits>
 #include <stdlib.h>
 #include "common.h"
 
@@ -29,6 +30,7 @@ struct GemmP {
   long sAo, sAi, sBo, sBi, sCo, sCi, sRo, sRi, sbias;
   float alpha; int act, c_f32, r_f32, accumulate, vec_ok;
   int ksteps_per_split, tilesN, kslice_xcd;
+  int fast_loads;                   // interior tiles take the select-free loader path (EVK_FAST_LOADS=0 disables)
   int lds_store;                    // bf16 output rows leave through LDS in 16-byte pieces (needs N % 8 == 0, ldc % 8 == 0, aligned C)
   const bf16_t* gate; long ldg;     // optional ReLU gate: C = (gate > 0) ? C : 0, applied last (bf16 [M][ldg], batch 1)
   float* colstats;                  // per 64-row block partial column sums / sums of squares [row block][2][N] (or null)
@@ -48,13 +50,27 @@ template <int ROWS, int MODE>
 struct RowLoader {
   static constexpr int NI = ROWS / 32;
   static constexpr int NREG = NI * 4;
+  static constexpr bool HAS_FULL = MODE == EVK_A_PLAIN;
   const bf16_t* base;
   long off[NI];
   int y0[NI], x0[NI];
   bool ok[NI];
+  // interior-tile fast path (PLAIN): one uniform tile pointer + a 32-bit per-lane byte offset per row, so the K advance is
+  // scalar arithmetic and neither the loads nor the LDS stores carry validity selects
+  const char* tbase;
+  unsigned voff[NI];
+  bool full;
 
   __device__ __forceinline__ void init(const GemmP& p, const bf16_t* b, long ld, int row0, int nrows, int tid) {
     base = b;
+    if constexpr (HAS_FULL) {
+      tbase = reinterpret_cast<const char*>(b + (long)row0 * ld);
+      full = row0 + ROWS <= nrows;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) voff[i] = (unsigned)(((tid >> 3) + 32 * i) * ld * 2 + (tid & 7) * 16);
+    } else {
+      tbase = nullptr; full = false;
+    }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int r = row0 + (tid >> 3) + 32 * i;
@@ -129,6 +145,18 @@ struct RowLoader {
 #pragma unroll
     for (int i = 0; i < NI; ++i) *reinterpret_cast<uint4*>(d + i * 4096) = ((mask >> i) & 1u) ? v[i] : make_uint4(0, 0, 0, 0);
   }
+
+  __device__ __forceinline__ void load_full(const GemmP&, int k0, uint4 (&v)[NI]) const {
+    const char* sb = tbase + (long)k0 * 2;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) v[i] = *reinterpret_cast<const uint4*>(sb + voff[i]);
+  }
+  __device__ __forceinline__ void store_full(char* lds, int tid, const uint4 (&v)[NI]) const {
+    const int rl = tid >> 3;
+    char* d = lds + rl * 128 + (((tid & 7) ^ (rl & 7)) << 4);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) *reinterpret_cast<uint4*>(d + i * 4096) = v[i];
+  }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -155,12 +183,17 @@ struct KstrLoader {
   static constexpr int KSTEP = NTHR / CPR;      // k-rows covered by one pass of the block
   static constexpr int ROWB = ROWS * 2;
   static constexpr int NCH = ROWS / 16;         // 32-byte chunks per k-row
+  static constexpr bool HAS_FULL = MODE == 0;
   const bf16_t* ptr;
   const bf16_t* safe;     // always-readable address for masked-off chunks
   long ld, tapstride;
   bool rok;
   int kh, kw, klog, kmask;
   float inv_rpi, inv_rw;
+  // interior-tile fast path (MODE 0, K-steps that do not straddle a tap): uniform pointer + 32-bit lane offsets
+  const char* tbase;
+  unsigned voff[NI];
+  bool full;
 
   __device__ __forceinline__ void init(const GemmP& p, const bf16_t* b, long ld_, int row0, int nrows, int tid, int tap,
                                        bool two_level) {
@@ -176,6 +209,14 @@ struct KstrLoader {
     tapstride = two_level ? p.b_tapstride : 0;
     inv_rpi = 1.f / (float)p.rows_per_img;
     inv_rw = 1.f / (float)p.row_w;
+    if constexpr (HAS_FULL) {
+      tbase = reinterpret_cast<const char*>(b + row0);
+      full = row0 + ROWS <= nrows && klog >= 6;          // klog >= 6: the 64 k of a step share one tap
+#pragma unroll
+      for (int i = 0; i < NI; ++i) voff[i] = (unsigned)(((tid % CPR) * 8 + (long)(tid / CPR + i * KSTEP) * ld) * 2);
+    } else {
+      tbase = nullptr; full = false;
+    }
   }
 
   __device__ __forceinline__ unsigned load(const GemmP& p, int k0, int kend, int tid, uint4 (&v)[NI]) const {
@@ -212,6 +253,21 @@ struct KstrLoader {
       const int kr = tid / CPR + i * KSTEP;
       const int ch = (m8 >> 1) ^ (kswz(kr) & (NCH - 1));
       *reinterpret_cast<uint4*>(lds + kr * ROWB + (ch << 5) + ((m8 & 1) << 4)) = ((mask >> i) & 1u) ? v[i] : make_uint4(0, 0, 0, 0);
+    }
+  }
+
+  __device__ __forceinline__ void load_full(const GemmP&, int k0, uint4 (&v)[NI]) const {
+    const char* sb = tbase + ((long)(k0 & kmask) * ld + (long)(k0 >> klog) * tapstride) * 2;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) v[i] = *reinterpret_cast<const uint4*>(sb + voff[i]);
+  }
+  __device__ __forceinline__ void store_full(char* lds, int tid, const uint4 (&v)[NI]) const {
+    const int m8 = tid % CPR;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int kr = tid / CPR + i * KSTEP;
+      const int ch = (m8 >> 1) ^ (kswz(kr) & (NCH - 1));
+      *reinterpret_cast<uint4*>(lds + kr * ROWB + (ch << 5) + ((m8 & 1) << 4)) = v[i];
     }
   }
 
@@ -487,43 +543,67 @@ __global__ __launch_bounds__(NTHR, (SB && WM == 2) ? 3 : 2) void gemm_kernel(con
     }
   };
 
-  unsigned ma = la.load(p, k_begin, k_end, tid, ra);
-  unsigned mb = lb.load(p, k_begin, k_end, tid, rb);
-  if constexpr (SB) {
-    // single LDS buffer (32-40 KB/block -> 4 blocks per CU): the next tile's global loads are in flight in registers
-    // while this tile is multiplied; two barriers per K-step
-    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-      __syncthreads();
-      la.store(smem, tid, ra, ma);
-      lb.store(smem + TM * 128, tid, rb, mb);
-      __syncthreads();
-      if (k0 + BK < k_end) {
-        ma = la.load(p, k0 + BK, k_end, tid, ra);
-        mb = lb.load(p, k0 + BK, k_end, tid, rb);
+  // FA / FB: the operand's tile is interior (every row valid, the K range a whole number of steps) -> loads and LDS stores
+  // without validity selects and with scalar K advance (measured: the masked path spends ~70 of its ~118 VALU instructions
+  // per K-step on selects and 64-bit address arithmetic, and these kernels are issue-bound at 3 waves per SIMD)
+  auto mainloop = [&](auto FA, auto FB) {
+    constexpr bool fa = decltype(FA)::value, fb = decltype(FB)::value;
+    unsigned ma = 0, mb = 0;
+    auto loadA = [&](int k0) { if constexpr (fa) la.load_full(p, k0, ra); else ma = la.load(p, k0, k_end, tid, ra); };
+    auto loadB = [&](int k0) { if constexpr (fb) lb.load_full(p, k0, rb); else mb = lb.load(p, k0, k_end, tid, rb); };
+    auto storeA = [&](char* d) { if constexpr (fa) la.store_full(d, tid, ra); else la.store(d, tid, ra, ma); };
+    auto storeB = [&](char* d) { if constexpr (fb) lb.store_full(d, tid, rb); else lb.store(d, tid, rb, mb); };
+    loadA(k_begin);
+    loadB(k_begin);
+    if constexpr (SB) {
+      // single LDS buffer (32-40 KB/block -> 4 blocks per CU): the next tile's global loads are in flight in registers
+      // while this tile is multiplied; two barriers per K-step
+      for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+        __syncthreads();
+        storeA(smem);
+        storeB(smem + TM * 128);
+        __syncthreads();
+        if (k0 + BK < k_end) {
+          loadA(k0 + BK);
+          loadB(k0 + BK);
+        }
+        compute(smem, smem + TM * 128);
       }
-      compute(smem, smem + TM * 128);
+    } else {
+      storeA(smem);
+      storeB(smem + TM * 128);
+      __syncthreads();
+      int buf = 0;
+      for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+        const bool more = (k0 + BK) < k_end;
+        if (more) {
+          loadA(k0 + BK);
+          loadB(k0 + BK);
+        }
+        const char* As = smem + buf * TILE_BYTES;
+        compute(As, As + TM * 128);
+        if (more) {
+          char* nxt = smem + (buf ^ 1) * TILE_BYTES;
+          storeA(nxt);
+          storeB(nxt + TM * 128);
+        }
+        __syncthreads();
+        buf ^= 1;
+      }
     }
+  };
+  const bool kfull = p.fast_loads && ((k_end - k_begin) % BK) == 0;
+  const bool fullA = LA::HAS_FULL && kfull && la.full, fullB = LB::HAS_FULL && kfull && lb.full;
+  using T1 = std::integral_constant<bool, true>;
+  using T0 = std::integral_constant<bool, false>;
+  if constexpr (LA::HAS_FULL && LB::HAS_FULL) {
+    if (fullA && fullB) mainloop(T1{}, T1{});
+    else mainloop(T0{}, T0{});
+  } else if constexpr (LB::HAS_FULL) {
+    if (fullB) mainloop(T0{}, T1{});
+    else mainloop(T0{}, T0{});
   } else {
-    la.store(smem, tid, ra, ma);
-    lb.store(smem + TM * 128, tid, rb, mb);
-    __syncthreads();
-    int buf = 0;
-    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-      const bool more = (k0 + BK) < k_end;
-      if (more) {
-        ma = la.load(p, k0 + BK, k_end, tid, ra);
-        mb = lb.load(p, k0 + BK, k_end, tid, rb);
-      }
-      const char* As = smem + buf * TILE_BYTES;
-      compute(As, As + TM * 128);
-      if (more) {
-        char* nxt = smem + (buf ^ 1) * TILE_BYTES;
-        la.store(nxt, tid, ra, ma);
-        lb.store(nxt + TM * 128, tid, rb, mb);
-      }
-      __syncthreads();
-      buf ^= 1;
-    }
+    mainloop(T0{}, T0{});
   }
 
   gemm_epilogue<TM, TN>(p, acc, tm, tn, wm, wn, frow, fq, zo, zi, by, bz, smem);
@@ -916,6 +996,10 @@ extern "C" int evk_gemm_launch(const evk_gemm* d, evk_stream_t stream) {
     // elsewhere -> on for short-K problems; EVK_LDS_STORE=0/1 forces it off / on for every eligible launch
     static const int lds_store = [] { const char* e = getenv("EVK_LDS_STORE"); return e ? atoi(e) : -1; }();
     p.lds_store = (lds_store < 0 ? d->K <= 128 : lds_store != 0) && !p.c_f32 && !p.accumulate && (d->N % 8 == 0) && (d->ldc % 8 == 0) && al(d->C, 16) && (d->sCo % 8 == 0) && (d->sCi % 8 == 0);
+  }
+  {
+    static const int fast_loads = [] { const char* e = getenv("EVK_FAST_LOADS"); return e ? atoi(e) : 1; }();
+    p.fast_loads = fast_loads;
   }
   p.gate = reinterpret_cast<const bf16_t*>(d->relu_gate); p.ldg = d->ldg;
   EVK_REQUIRE(!p.gate || (!p.accumulate && d->batch_outer * d->batch_inner == 1 && d->ldg >= d->N), "evk_gemm: relu_gate needs batch 1, no accumulate, ldg >= N");
