@@ -46,9 +46,10 @@ struct GemmP {
 // ------------------------------------------------------------------------------------------------
 // K-contiguous loaders (PLAIN / CONV / DGRAD): thread -> row (tid>>3)+32i, 16-byte chunk kc = tid&7
 // ------------------------------------------------------------------------------------------------
-template <int ROWS, int MODE>
+template <int ROWS, int MODE, int NT = NTHR>
 struct RowLoader {
-  static constexpr int NI = ROWS / 32;
+  static constexpr int RPP = NT / 8;            // rows covered by one pass of the block
+  static constexpr int NI = ROWS / RPP;
   static constexpr int NREG = NI * 4;
   static constexpr bool HAS_FULL = MODE == EVK_A_PLAIN;
   const bf16_t* base;
@@ -67,13 +68,13 @@ struct RowLoader {
       tbase = reinterpret_cast<const char*>(b + (long)row0 * ld);
       full = row0 + ROWS <= nrows;
 #pragma unroll
-      for (int i = 0; i < NI; ++i) voff[i] = (unsigned)(((tid >> 3) + 32 * i) * ld * 2 + (tid & 7) * 16);
+      for (int i = 0; i < NI; ++i) voff[i] = (unsigned)(((tid >> 3) + RPP * i) * ld * 2 + (tid & 7) * 16);
     } else {
       tbase = nullptr; full = false;
     }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int r = row0 + (tid >> 3) + 32 * i;
+      const int r = row0 + (tid >> 3) + RPP * i;
       ok[i] = r < nrows;
       const int rr = ok[i] ? r : 0;
       if constexpr (MODE == EVK_A_PLAIN) {
@@ -143,7 +144,7 @@ struct RowLoader {
     const int rl = tid >> 3;
     char* d = lds + rl * 128 + (((tid & 7) ^ (rl & 7)) << 4);
 #pragma unroll
-    for (int i = 0; i < NI; ++i) *reinterpret_cast<uint4*>(d + i * 4096) = ((mask >> i) & 1u) ? v[i] : make_uint4(0, 0, 0, 0);
+    for (int i = 0; i < NI; ++i) *reinterpret_cast<uint4*>(d + i * (RPP * 128)) = ((mask >> i) & 1u) ? v[i] : make_uint4(0, 0, 0, 0);
   }
 
   __device__ __forceinline__ void load_full(const GemmP&, int k0, uint4 (&v)[NI]) const {
@@ -155,7 +156,7 @@ struct RowLoader {
     const int rl = tid >> 3;
     char* d = lds + rl * 128 + (((tid & 7) ^ (rl & 7)) << 4);
 #pragma unroll
-    for (int i = 0; i < NI; ++i) *reinterpret_cast<uint4*>(d + i * 4096) = v[i];
+    for (int i = 0; i < NI; ++i) *reinterpret_cast<uint4*>(d + i * (RPP * 128)) = v[i];
   }
 };
 
@@ -176,11 +177,12 @@ __device__ __forceinline__ s16x4 lds_tr_read(const char* generic_lds_ptr) {
 }
 __device__ __forceinline__ int kswz(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
 
-template <int ROWS, int MODE>  // MODE: 0 = plain/2-level K-strided, 1 = conv weight-gradient gather
+template <int ROWS, int MODE, int NT = NTHR>  // MODE: 0 = plain/2-level K-strided, 1 = conv weight-gradient gather
 struct KstrLoader {
-  static constexpr int NI = ROWS / 32;
   static constexpr int CPR = ROWS / 8;          // 16-byte chunks per k-row
-  static constexpr int KSTEP = NTHR / CPR;      // k-rows covered by one pass of the block
+  static constexpr int KSTEP = NT / CPR;        // k-rows covered by one pass of the block
+  static constexpr int NI = BK / KSTEP;
+  static_assert(KSTEP >= 1 && KSTEP <= BK && BK % KSTEP == 0, "K-strided loader: bad rows / threads combination");
   static constexpr int ROWB = ROWS * 2;
   static constexpr int NCH = ROWS / 16;         // 32-byte chunks per k-row
   static constexpr bool HAS_FULL = MODE == 0;
@@ -285,14 +287,14 @@ struct KstrLoader {
   }
 };
 
-template <int ROWS, int MODE, bool IS_A> struct LoaderSel;
-template <int ROWS> struct LoaderSel<ROWS, EVK_A_PLAIN, true> { using T = RowLoader<ROWS, EVK_A_PLAIN>; static constexpr bool KS = false; };
-template <int ROWS> struct LoaderSel<ROWS, EVK_A_CONV, true> { using T = RowLoader<ROWS, EVK_A_CONV>; static constexpr bool KS = false; };
-template <int ROWS> struct LoaderSel<ROWS, EVK_A_DGRAD, true> { using T = RowLoader<ROWS, EVK_A_DGRAD>; static constexpr bool KS = false; };
-template <int ROWS> struct LoaderSel<ROWS, EVK_A_KSTR, true> { using T = KstrLoader<ROWS, 0>; static constexpr bool KS = true; };
-template <int ROWS> struct LoaderSel<ROWS, EVK_B_PLAIN, false> { using T = RowLoader<ROWS, EVK_A_PLAIN>; static constexpr bool KS = false; };
-template <int ROWS> struct LoaderSel<ROWS, EVK_B_KSTR, false> { using T = KstrLoader<ROWS, 0>; static constexpr bool KS = true; };
-template <int ROWS> struct LoaderSel<ROWS, EVK_B_WGATHER, false> { using T = KstrLoader<ROWS, 1>; static constexpr bool KS = true; };
+template <int ROWS, int MODE, bool IS_A, int NT> struct LoaderSel;
+template <int ROWS, int NT> struct LoaderSel<ROWS, EVK_A_PLAIN, true, NT> { using T = RowLoader<ROWS, EVK_A_PLAIN, NT>; static constexpr bool KS = false; };
+template <int ROWS, int NT> struct LoaderSel<ROWS, EVK_A_CONV, true, NT> { using T = RowLoader<ROWS, EVK_A_CONV, NT>; static constexpr bool KS = false; };
+template <int ROWS, int NT> struct LoaderSel<ROWS, EVK_A_DGRAD, true, NT> { using T = RowLoader<ROWS, EVK_A_DGRAD, NT>; static constexpr bool KS = false; };
+template <int ROWS, int NT> struct LoaderSel<ROWS, EVK_A_KSTR, true, NT> { using T = KstrLoader<ROWS, 0, NT>; static constexpr bool KS = true; };
+template <int ROWS, int NT> struct LoaderSel<ROWS, EVK_B_PLAIN, false, NT> { using T = RowLoader<ROWS, EVK_A_PLAIN, NT>; static constexpr bool KS = false; };
+template <int ROWS, int NT> struct LoaderSel<ROWS, EVK_B_KSTR, false, NT> { using T = KstrLoader<ROWS, 0, NT>; static constexpr bool KS = true; };
+template <int ROWS, int NT> struct LoaderSel<ROWS, EVK_B_WGATHER, false, NT> { using T = KstrLoader<ROWS, 1, NT>; static constexpr bool KS = true; };
 
 // sum over the 16 lanes of a DPP row (lanes sharing lane >> 4); every lane of the row ends up with the total
 template <int CTRL>
@@ -459,8 +461,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[4][4]
 }
 
 template <int WM, int WN, int AMODE, int BMODE, bool SB>
-__global__ __launch_bounds__(NTHR, (SB && WM == 2) ? 3 : 2) void gemm_kernel(const GemmP p) {
-  constexpr int TM = 64 * WM, TN = 64 * WN;
+__global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : ((SB && WM == 2) ? 3 : 2)) void gemm_kernel(const GemmP p) {
+  constexpr int TM = 64 * WM, TN = 64 * WN, NT = 64 * WM * WN;
   constexpr int TILE_BYTES = (TM + TN) * BK * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -489,10 +491,10 @@ __global__ __launch_bounds__(NTHR, (SB && WM == 2) ? 3 : 2) void gemm_kernel(con
   const int k_end = min(p.K, k_begin + p.ksteps_per_split * BK);
   if (k_begin >= k_end) return;
 
-  using LA = typename LoaderSel<TM, AMODE, true>::T;
-  using LB = typename LoaderSel<TN, BMODE, false>::T;
-  constexpr bool AKS = LoaderSel<TM, AMODE, true>::KS;
-  constexpr bool BKS = LoaderSel<TN, BMODE, false>::KS;
+  using LA = typename LoaderSel<TM, AMODE, true, NT>::T;
+  using LB = typename LoaderSel<TN, BMODE, false, NT>::T;
+  constexpr bool AKS = LoaderSel<TM, AMODE, true, NT>::KS;
+  constexpr bool BKS = LoaderSel<TN, BMODE, false, NT>::KS;
   LA la;
   LB lb;
   const bf16_t* Ab = p.A + zo * p.sAo + zi * p.sAi;
@@ -864,14 +866,16 @@ inline int single_buf_override() {
 
 template <int WM, int WN, int AMODE, int BMODE, bool SB>
 int launch_cfg_sb(const GemmP& p, dim3 grid, hipStream_t s) {
-  constexpr int LDS = (SB ? 1 : 2) * (64 * WM + 64 * WN) * BK * 2;
+  constexpr int TILE_LDS = (SB ? 1 : 2) * (64 * WM + 64 * WN) * BK * 2;
+  constexpr int STAGE_LDS = WM * WN * 8192;            // the epilogue's per-wave 64 x 64 bf16 staging tiles
+  constexpr int LDS = TILE_LDS > STAGE_LDS ? TILE_LDS : STAGE_LDS;
   static bool attr_done = false;
   auto kern = gemm_kernel<WM, WN, AMODE, BMODE, SB>;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(NTHR), LDS, s, p);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), LDS, s, p);
   return evk_check_launch("gemm_kernel");
 }
 
@@ -891,6 +895,19 @@ inline long split_target() {
   return v;
 }
 
+// 256 x 256 tile, 16 waves, one block per CU, double-buffered LDS (A_PLAIN x B_PLAIN only).  Measured with rocprofv3
+// (TCP_PENDING_STALL_CYCLES ~47 % of the kernel, TCP_TCC_READ_REQ_LATENCY 500-800 cycles per request): a CU's vector L1
+// sustains ~25-30 GB/s of fills at the loaded latency, ~6.4 TB/s chip-wide whether the lines come from HBM or from L2, so
+// the tile kernels are bound by LDS-FILL bytes, A and B re-reads included: 128 x 128 tiles cap near 800 TFLOP/s (measured
+// 848 on 8192^3).  A 256 x 256 tile halves the fill bytes per flop (1056 TFLOP/s on 8192^3) but runs ONE lock-stepped block
+// per CU, which loses on problems of few tiles -> only when the big tiles alone give every CU four rounds of blocks, and not for
+// the convolutions with fused statistics (neutral within noise on the trunk's 1x1 shapes; their partial-row layout stays).
+inline bool use_big_tile(long M, long N, long nz) {
+  static const int mode = [] { const char* e = getenv("EVK_TILE256"); return e ? atoi(e) : -1; }();
+  if (mode == 0 || M < 256 || N < 256) return false;
+  if (mode == 1) return true;
+  return cdiv(M, 256) * cdiv(N, 256) * nz >= 1024;
+}
 // split-K choice shared by the launcher and evk_gemm_workspace_bytes
 inline int choose_splitk(int M, int N, int K, int batch, int splitk_req) {
   const bool narrow = N <= 64;
@@ -937,7 +954,8 @@ int launch_modes(GemmP& p, int batch, int splitk_req, void* ws, long ws_bytes, c
     }
   }
   const bool narrow = p.N <= 64;
-  const int TM = narrow ? 256 : 128, TN = narrow ? 64 : 128;
+  const bool big = AMODE == EVK_A_PLAIN && BMODE == EVK_B_PLAIN && !p.accumulate && !p.colstats && use_big_tile(p.M, p.N, batch);
+  const int TM = narrow || big ? 256 : 128, TN = narrow ? 64 : (big ? 256 : 128);
   const int tilesM = (int)cdiv(p.M, TM);
   p.tilesN = (int)cdiv(p.N, TN);
   const int ksteps = (int)cdiv(p.K, BK);
@@ -953,7 +971,13 @@ int launch_modes(GemmP& p, int batch, int splitk_req, void* ws, long ws_bytes, c
   static const int kslice = [] { const char* e = getenv("EVK_KSLICE_XCD"); return e ? atoi(e) : 1; }();
   p.kslice_xcd = kslice;
   dim3 grid(tilesM * p.tilesN, splitk, batch);
-  int rc = narrow ? launch_cfg<4, 1, AMODE, BMODE>(p, grid, s) : launch_cfg<2, 2, AMODE, BMODE>(p, grid, s);
+  int rc;
+  if constexpr (AMODE == EVK_A_PLAIN && BMODE == EVK_B_PLAIN) {
+    rc = narrow ? launch_cfg<4, 1, AMODE, BMODE>(p, grid, s)
+                : (big ? launch_cfg_sb<4, 4, AMODE, BMODE, false>(p, grid, s) : launch_cfg<2, 2, AMODE, BMODE>(p, grid, s));
+  } else {
+    rc = narrow ? launch_cfg<4, 1, AMODE, BMODE>(p, grid, s) : launch_cfg<2, 2, AMODE, BMODE>(p, grid, s);
+  }
   if (rc == EVK_OK && p.slab) {
     SkrP r{p.slab, reinterpret_cast<float*>(p.C), p.slab_mn, p.M, p.N, splitk, p.bi, p.ldc, p.sCo, p.sCi};
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)cdiv(p.slab_mn / 4, 16), batch), dim3(256), 0, s, r);

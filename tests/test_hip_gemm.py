@@ -41,7 +41,8 @@ def base_desc(H, A, B, Cm, M, N, K, a_mode=0, b_mode=0, lda=None, ldb=None, ldc=
 
 
 @pytest.mark.parametrize('M,N,K', [(128, 128, 64), (200, 136, 72), (4640, 2048, 512), (37, 64, 256), (300, 1445, 512), (1, 8, 8),
-                                   (96, 512, 512), (200, 1536, 1024), (256, 1445, 512), (96, 512, 1536)])
+                                   (96, 512, 512), (200, 1536, 1024), (256, 1445, 512), (96, 512, 1536),
+                                   (8200, 8264, 72)])       # last: 33 x 33 tiles of 256 x 256 (16-wave kernel), ragged in M, N and K
 def test_gemm_nt(H, M, N, K):
     a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)
     bias = torch.randn(N)

@@ -311,7 +311,8 @@ def test_conv_fwd_stats_and_dgrad_add():
     import ctypes as C
     from evoke_amd import hip as H
     torch.manual_seed(3)
-    for (N, Hh, Ci, Co, k, stride) in [(3, 20, 64, 128, 3, 1), (2, 24, 128, 64, 1, 1), (2, 18, 64, 256, 3, 2), (5, 12, 256, 1024, 1, 1)]:
+    for (N, Hh, Ci, Co, k, stride) in [(3, 20, 64, 128, 3, 1), (2, 24, 128, 64, 1, 1), (2, 18, 64, 256, 3, 2), (5, 12, 256, 1024, 1, 1),
+                                     (1, 513, 64, 256, 1, 1)]:       # last: 263k ragged rows (1029 row blocks of statistics partials)
         g = H.conv_geom(N, Hh, Hh, Ci, Co, k, k, stride, k // 2)
         x = (torch.randn(N, Hh, Hh, Ci, device='cuda') * 0.7).to(BF)
         w = (torch.randn(Co, k, k, Ci, device='cuda') * 0.05).to(BF)
