@@ -139,7 +139,7 @@ def bench_decode(a, rank, world, dev):
     print(json.dumps({
         'metric': 'decode tokens/sec (beam search, %d^2)' % a.res, 'value': toks / float(tt.item()), 'unit': 'tokens/s', 'n_gpus': world,
         'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * float(tt.item()) / a.steps, 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'vs_baseline': None, 'dtype': os.environ.get('EVK_STORE', 'bf16').lower(), 'data': 'synthetic',
         'config': {'workload': 'EVOKE-%d inference: beam=%d, batch %d studies x %d views, max_seq_len %d (all steps run, as the reference), '
                                'incremental decoder state, visual extractor + fusion included, V=%d, random-init weights'
                                % (a.res, a.beam, B, a.views, L, V), 'parallelism': 'replicas x%d' % world,
@@ -254,7 +254,7 @@ def main():
     out = {
         'metric': 'studies/sec (train step, 2-view %d^2)' % a.res, 'value': studies / dt, 'unit': 'studies/s', 'n_gpus': world,
         'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps, 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'vs_baseline': None, 'dtype': os.environ.get('EVK_STORE', 'bf16').lower(), 'data': 'synthetic',
         'config': {'workload': 'EVOKE-%d two-view %s train step (fwd+bwd+allreduce+clip+RAdam), %d studies (%d images) per GPU, '
                                'L=%d, Li=%d, V=%d, random-init weights' % (a.res, kind, a.batch, a.batch * a.views, L, Li, V),
                    'parallelism': 'dp%d' % world, 'loss_last': float(losses[-1].item()),

@@ -10,6 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, 'obj')
 LIB = os.path.join(HERE, 'libevoke_hip.so')
+LIB_F16 = os.path.join(HERE, 'libevoke_hip_f16.so')      # same sources, -DEVK_STORE_F16 (fp16 storage: the parity mode)
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function', '-ffp-contract=fast']
 
@@ -21,17 +22,17 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(verbose=False, force=False):
-    os.makedirs(OBJ, exist_ok=True)
+def _build_one(lib, obj_dir, extra, verbose, force):
+    os.makedirs(obj_dir, exist_ok=True)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith('.hip'))
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
     hdrs.append(os.path.join(os.path.dirname(HERE), 'include', 'evoke_hip.h'))
     objs, jobs = [], []
     for s in srcs:
-        o = os.path.join(OBJ, s[:-4] + '.o')
+        o = os.path.join(obj_dir, s[:-4] + '.o')
         objs.append(o)
         if force or _stale(o, [os.path.join(CSRC, s)] + hdrs):
-            jobs.append([HIPCC] + FLAGS + ['-c', os.path.join(CSRC, s), '-o', o])
+            jobs.append([HIPCC] + FLAGS + extra + ['-c', os.path.join(CSRC, s), '-o', o])
 
     def run(cmd):
         if verbose:
@@ -45,9 +46,15 @@ def build(verbose=False, force=False):
         for warn in ex.map(run, jobs):
             if verbose and warn.strip():
                 print(warn)
-    if jobs or force or _stale(LIB, objs):
-        run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs)
-    return LIB
+    if jobs or force or _stale(lib, objs):
+        run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs)
+    return lib
+
+
+def build(verbose=False, force=False):
+    """Both libraries: bf16 storage (default) and fp16 storage (EVK_STORE=f16)."""
+    _build_one(LIB_F16, os.path.join(CSRC, 'obj_f16'), ['-DEVK_STORE_F16'], verbose, force)
+    return _build_one(LIB, OBJ, [], verbose, force)
 
 
 if __name__ == '__main__':

@@ -5,16 +5,30 @@
 #include <stdio.h>
 #include "../../include/evoke_hip.h"
 
-typedef unsigned short bf16_t;  // raw bf16 bits
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+// 16-bit storage format of activations, weights shadows and gradients.  The default build stores bf16 (8-bit exponent: safe
+// for gradients, the training format).  -DEVK_STORE_F16 builds the SAME kernels over IEEE fp16 storage (libevoke_hip_f16.so:
+// 11-bit mantissa, eight times less rounding noise per stored tensor; forward / evaluation parity mode, no loss scaling is
+// implemented for its backward).  Every kernel converts through the helpers below and multiplies through EVK_MFMA_16x16x32,
+// so the type names keep their historical "bf" spelling in both builds.
+typedef unsigned short bf16_t;  // raw bits of one stored value
 typedef __attribute__((ext_vector_type(4))) float f32x4;
-
+#ifdef EVK_STORE_F16
+typedef __attribute__((ext_vector_type(8))) _Float16 bf16x8;
+#define EVK_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_f16
+__device__ __forceinline__ float bf2f(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ bf16_t f2bf(float f) { _Float16 h = (_Float16)f; return __builtin_bit_cast(bf16_t, h); }   // RNE
+__device__ __forceinline__ float lo_bf(uint32_t v) { return bf2f((bf16_t)(v & 0xffffu)); }
+__device__ __forceinline__ float hi_bf(uint32_t v) { return bf2f((bf16_t)(v >> 16)); }
+#else
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+#define EVK_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 // plain cast -> v_cvt_pk_bf16_f32 (RNE, NaN stays NaN: MI355X_MICROARCH.md "Correctness boundaries")
 __device__ __forceinline__ bf16_t f2bf(float f) { __bf16 b = (__bf16)f; return __builtin_bit_cast(bf16_t, b); }
-__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
 __device__ __forceinline__ float lo_bf(uint32_t v) { return __uint_as_float(v << 16); }
 __device__ __forceinline__ float hi_bf(uint32_t v) { return __uint_as_float(v & 0xffff0000u); }
+#endif
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -541,7 +541,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : ((SB && WM == 2) ? 
       for (int in = 0; in < 4; ++in)
 #pragma unroll
         for (int im = 0; im < 4; ++im)
-          acc[in][im] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[in], af[im], acc[in][im], 0, 0, 0);
+          acc[in][im] = EVK_MFMA_16x16x32(bfr[in], af[im], acc[in][im], 0, 0, 0);
     }
   };
 
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmP p) {
       for (int in = 0; in < NT; ++in)
 #pragma unroll
         for (int im = 0; im < 2; ++im)
-          acc[in][im] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[in], af[im], acc[in][im], 0, 0, 0);
+          acc[in][im] = EVK_MFMA_16x16x32(bfr[in], af[im], acc[in][im], 0, 0, 0);
     }
     __syncthreads();
   }
@@ -781,7 +781,7 @@ __global__ __launch_bounds__(NTHR) void gemm_small_kernel(const GemmP p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int im = 0; im < 4; ++im) acc[j][im] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[im], acc[j][im], 0, 0, 0);
+      for (int im = 0; im < 4; ++im) acc[j][im] = EVK_MFMA_16x16x32(bfr[j], af[im], acc[j][im], 0, 0, 0);
     if (more) {
       char* nxt = smem + (buf ^ 1) * TILE_BYTES;
       la.store(nxt, tid, ra, ma);

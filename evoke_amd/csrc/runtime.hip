@@ -59,6 +59,13 @@ void evk_prof_end(int family, hipStream_t s, double flops) {
 extern "C" {
 
 int evk_version(void) { return 100; }
+int evk_storage_format(void) {
+#ifdef EVK_STORE_F16
+  return 16;
+#else
+  return 0;
+#endif
+}
 const char* evk_last_error(void) { return g_err; }
 
 int evk_prof_enable(int on) {

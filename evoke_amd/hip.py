@@ -8,7 +8,13 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libevoke_hip.so')
+# EVK_STORE=f16 selects the fp16-storage build of the same kernels (11-bit mantissa: the forward / evaluation parity mode,
+# DESIGN.md section 4); the default is bf16 storage, the training format.  One format per process.
+STORE = os.environ.get('EVK_STORE', 'bf16').lower()
+if STORE not in ('bf16', 'f16'):
+    raise RuntimeError('EVK_STORE must be bf16 or f16, not %r' % STORE)
+STORE_DTYPE = torch.float16 if STORE == 'f16' else torch.bfloat16
+LIB_PATH = os.path.join(_HERE, 'libevoke_hip_f16.so' if STORE == 'f16' else 'libevoke_hip.so')
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH, ACT_SIGMOID, ACT_GELU_NEW = 0, 1, 2, 3, 4, 5
@@ -85,6 +91,9 @@ def _load():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_int64 if name.endswith('_bytes') else C.c_int
+    want = 16 if STORE == 'f16' else 0
+    if lib.evk_storage_format() != want:
+        raise RuntimeError('evoke_amd: %s stores format %d, EVK_STORE=%s needs %d -- rebuild' % (LIB_PATH, lib.evk_storage_format(), STORE, want))
     return lib
 
 
@@ -105,8 +114,8 @@ def ptr(t):
 
 
 def dt(t):
-    if t.dtype == torch.bfloat16:
-        return BF16
+    if t.dtype == STORE_DTYPE:
+        return BF16          # "the library's 16-bit storage format"
     if t.dtype == torch.float32:
         return F32
     raise TypeError('unsupported dtype %s' % t.dtype)

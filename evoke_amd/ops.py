@@ -16,7 +16,7 @@ import torch
 
 from . import hip as H
 
-BF16, F32 = torch.bfloat16, torch.float32
+BF16, F32 = H.STORE_DTYPE, torch.float32      # BF16 = the 16-bit storage dtype of the loaded library (bf16, or fp16 under EVK_STORE=f16)
 
 # ----------------------------------------------------------------------------------------------------
 # parameter shadows + direct gradient accumulation

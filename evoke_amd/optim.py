@@ -65,7 +65,7 @@ class FusedOptimizer(torch.optim.Optimizer):
                 tot += _pad8(n)
             fp = torch.zeros(tot, dtype=torch.float32, device=dev)
             fg = torch.zeros(tot, dtype=torch.float32, device=dev)
-            sh = torch.zeros(tot, dtype=torch.bfloat16, device=dev) if dev.type == 'cuda' else None
+            sh = torch.zeros(tot, dtype=ops.BF16, device=dev) if dev.type == 'cuda' else None
             for p, o in zip(ps, offs):
                 n = p.numel()
                 v = _view_like(fp[o:o + n], p)

@@ -75,6 +75,11 @@ typedef struct evk_gemm {
 } evk_gemm;
 
 int evk_version(void);
+/* 16-bit storage format this build of the library computes in: 0 = bf16 (libevoke_hip.so, the default and the training
+ * format), 16 = IEEE fp16 (libevoke_hip_f16.so, built from the same sources with -DEVK_STORE_F16: the forward / evaluation
+ * parity mode).  "bf16" in the comments of this header means "the library's 16-bit storage format".  The reference has no
+ * counterpart: it computes in fp32 (torch CPU / CUDA default dtype). */
+int evk_storage_format(void);
 const char* evk_last_error(void);
 
 /* ---- profiling hooks used by bench.py: HIP-event timing of every launch of a kernel family ---------- */

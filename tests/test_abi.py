@@ -14,16 +14,19 @@ def _declared():
 
 
 def test_library_exports_every_declared_symbol():
+    """Both builds of the sources: bf16 storage (the default) and fp16 storage (EVK_STORE=f16, the parity mode)."""
     from evoke_amd import build
     path = build.build()
-    lib = ctypes.CDLL(path)
     names = _declared()
     assert len(names) >= 10
-    missing = [n for n in names if not hasattr(lib, n)]
-    assert not missing, missing
-    lib.evk_last_error.restype = ctypes.c_char_p
-    assert lib.evk_version() >= 100
-    assert isinstance(lib.evk_last_error(), bytes)
+    for lib_path, fmt in ((path, 0), (build.LIB_F16, 16)):
+        lib = ctypes.CDLL(lib_path)
+        missing = [n for n in names if not hasattr(lib, n)]
+        assert not missing, (lib_path, missing)
+        lib.evk_last_error.restype = ctypes.c_char_p
+        assert lib.evk_version() >= 100
+        assert lib.evk_storage_format() == fmt
+        assert isinstance(lib.evk_last_error(), bytes)
 
 
 def test_argument_validation_without_gpu():
