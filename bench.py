@@ -267,12 +267,12 @@ def main():
         alg_flops = (alg * 1e9 * a.batch * psteps) if alg else launched_flops
         ach = alg_flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         traffic = None          # HBM bytes of the family per step from the committed PMC passes of this very command
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_m_traffic.json')
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_o_traffic.json')
         if kind == 'finetune' and a.res == 384 and a.batch == 32 and os.path.exists(tpath):
             traffic = json.load(open(tpath)).get('gemm_family_hbm_bytes_per_step')
         out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_kernel (MFMA GEMM / implicit-GEMM conv family)', 'achieved': ach,
                            'peak': MFMA_BF16_DENSE_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / MFMA_BF16_DENSE_PEAK_TFLOPS,
-                           'traffic': traffic, 'traffic_source': 'profiles/r01_m_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per step)' if traffic else None,
+                           'traffic': traffic, 'traffic_source': 'profiles/r01_o_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per step)' if traffic else None,
                            'launches_per_step': n / psteps, 'event_timed': '1 extra step after the timed region, single stream', 'avg_launch_us': 1e3 * ms / max(n, 1),
                            'gemm_ms_per_step': ms / psteps, 'launched_tflops': launched_flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
                            'family_ms_per_step': {k: v[0] / psteps for k, v in fam.items()}}

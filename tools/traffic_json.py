@@ -1,0 +1,23 @@
+"""profiles/*_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --steps 1 --warmup 1 --no-prof
+--no-cpu-baseline`: usage traffic_json.py fetch.csv write.csv steps > out.json  (FETCH doubled on gfx950, KB -> bytes)."""
+import json
+import sys
+from traffic_agg import load
+
+fe, cnt = load(sys.argv[1], 2.0)
+wr, _ = load(sys.argv[2], 1.0)
+steps = float(sys.argv[3])
+fam = lambda n: n.startswith('void gemm_') or n.startswith('splitk_reduce')
+names = sorted(set(fe) | set(wr), key=lambda n: -(fe.get(n, 0) + wr.get(n, 0)))
+out = {
+    'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), python bench.py --steps 1 --warmup 1 '
+              '--no-prof --no-cpu-baseline (finetune 384^2, 32 studies); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies '
+              '128-B requests at 64 B); KB -> bytes x1024; divided by the %g steps of the run (includes one-off initialisation)' % steps,
+    'gemm_family_hbm_bytes_per_step': sum(fe.get(n, 0) + wr.get(n, 0) for n in names if fam(n)) / steps,
+    'gemm_family_fetch_bytes_per_step': sum(fe.get(n, 0) for n in names if fam(n)) / steps,
+    'gemm_family_write_bytes_per_step': sum(wr.get(n, 0) for n in names if fam(n)) / steps,
+    'all_kernels_hbm_bytes_per_step': sum(fe.get(n, 0) + wr.get(n, 0) for n in names) / steps,
+    'per_kernel_GB_per_step': {n: {'calls': cnt.get(n, 0) / steps, 'fetch': round(fe.get(n, 0) / 1e9 / steps, 3),
+                                   'write': round(wr.get(n, 0) / 1e9 / steps, 3)} for n in names[:40]},
+}
+print(json.dumps(out, indent=1))
