@@ -11,6 +11,8 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
+from tests.helpers import F16_BUILD, NO_F16_GRADS
+
 pytestmark = pytest.mark.gpu
 
 
@@ -108,6 +110,7 @@ def _run(kind):
     return out
 
 
+@pytest.mark.skipif(F16_BUILD, reason=NO_F16_GRADS)
 def test_two_rank_finetune_step_on_one_gpu():
     out = _run('finetune')
     for rank, losses, sigs, _ in out:

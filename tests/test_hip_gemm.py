@@ -8,6 +8,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from tests.helpers import STORE_DTYPE
+
 pytestmark = pytest.mark.gpu
 
 
@@ -19,7 +21,7 @@ def H():
 
 def rnd(*shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed)
-    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16)
+    return (torch.randn(*shape, generator=g) * scale).to(STORE_DTYPE)
 
 
 def close(got, want, rtol, atol):
@@ -48,11 +50,11 @@ def test_gemm_nt(H, M, N, K):
     bias = torch.randn(N)
     res = rnd(M, N, seed=3)
     ldc = (N + 7) // 8 * 8
-    for c_dtype in (torch.bfloat16, torch.float32):
+    for c_dtype in (STORE_DTYPE, torch.float32):
         for act in (H.ACT_NONE, H.ACT_GELU):
             c = torch.zeros(M, ldc, dtype=c_dtype, device='cuda')
             ad, bd, biasd = a.cuda(), b.cuda(), bias.cuda()
-            resd = torch.zeros(M, ldc, dtype=torch.bfloat16, device='cuda')
+            resd = torch.zeros(M, ldc, dtype=STORE_DTYPE, device='cuda')
             resd[:, :N] = res.cuda()
             d = base_desc(H, ad, bd, c, M, N, K, lda=K, ldb=K, ldc=ldc)
             d.bias, d.resid, d.ldr, d.r_dtype, d.act, d.alpha = biasd.data_ptr(), resd.data_ptr(), ldc, H.BF16, act, 0.5
@@ -62,7 +64,7 @@ def test_gemm_nt(H, M, N, K):
             if act == H.ACT_GELU:
                 want = F.gelu(want)
             want = want + res.float()
-            close(c[:, :N], want, 1e-2 if c_dtype == torch.bfloat16 else 2e-4, 2e-3 * K ** 0.5 if c_dtype == torch.float32 else 2e-2 * (K / 64) ** 0.5)
+            close(c[:, :N], want, 1e-2 if c_dtype == STORE_DTYPE else 2e-4, 2e-3 * K ** 0.5 if c_dtype == torch.float32 else 2e-2 * (K / 64) ** 0.5)
             assert float(c[:, N:].abs().sum()) == 0.0
 
 
@@ -80,14 +82,14 @@ def test_gemm_batched_heads(H):
     H.gemm_launch(d)
     want = torch.einsum('bthd,bshd->bhts', q.float().view(Bz, T, Hh, dh), k.float().view(Bz, S, Hh, dh)) * 0.125
     close(sc[..., :S], want, 2e-4, 2e-3)
-    p = torch.softmax(want, -1).to(torch.bfloat16)
-    pd = torch.zeros(Bz, Hh, T, Sp, dtype=torch.bfloat16, device='cuda')
+    p = torch.softmax(want, -1).to(STORE_DTYPE)
+    pd = torch.zeros(Bz, Hh, T, Sp, dtype=STORE_DTYPE, device='cuda')
     pd[..., :S] = p.cuda()
-    ctx = torch.zeros(Bz, T, Hh * dh, dtype=torch.bfloat16, device='cuda')
+    ctx = torch.zeros(Bz, T, Hh * dh, dtype=STORE_DTYPE, device='cuda')
     d = base_desc(H, pd, vd, ctx, T, dh, Sp, b_mode=H.B_KSTR, lda=Sp, ldb=Hh * dh, ldc=Hh * dh)
     d.K = Sp  # padded K: the pad columns of P are zero, V rows beyond S must not be read -> use K = 56 only if V padded
     d.K = S if S % 8 == 0 else Sp
-    vpad = torch.zeros(Bz, Sp, Hh * dh, dtype=torch.bfloat16, device='cuda')
+    vpad = torch.zeros(Bz, Sp, Hh * dh, dtype=STORE_DTYPE, device='cuda')
     vpad[:, :S] = vd
     d.B = vpad.data_ptr()
     d.batch_outer, d.batch_inner = Bz, Hh
@@ -101,7 +103,7 @@ def test_gemm_batched_heads(H):
 def test_gemm_nn_dx(H, M, N, K):
     # dX[M,N] = dY[M,K] . W[K,N]   (B K-strided)
     dy, w = rnd(M, K, seed=4), rnd(K, N, seed=5, scale=0.1)
-    c = torch.zeros(M, N, dtype=torch.bfloat16, device='cuda')
+    c = torch.zeros(M, N, dtype=STORE_DTYPE, device='cuda')
     dyd, wd = dy.cuda(), w.cuda()
     d = base_desc(H, dyd, wd, c, M, N, K, b_mode=H.B_KSTR, lda=K, ldb=N, ldc=N)
     H.gemm_launch(d)
@@ -112,7 +114,7 @@ def test_gemm_nn_dx(H, M, N, K):
 def test_gemm_tn_dw_accumulate(H, M, N, K):
     # dW[M,N] += dY[K,M]^T . X[K,N]   (both K-strided, split-K with f32 atomics)
     ldy = (M + 7) // 8 * 8
-    dy = torch.zeros(K, ldy, dtype=torch.bfloat16)
+    dy = torch.zeros(K, ldy, dtype=STORE_DTYPE)
     dy[:, :M] = rnd(K, M, seed=6)
     x = rnd(K, N, seed=7)
     c0 = torch.randn(M, N)
@@ -146,7 +148,7 @@ def test_conv_fwd_dgrad_wgrad(H, cfg):
     w = rnd(Co, KH, KH, Ci, seed=9, scale=(2.0 / (KH * KH * Ci)) ** 0.5)
     g = H.conv_geom(N, Hi, Wi, Ci, Co, KH, KH, stride, pad)
     xd, wd = x.cuda(), w.cuda()
-    y = torch.zeros(N, g.Ho, g.Wo, Co, dtype=torch.bfloat16, device='cuda')
+    y = torch.zeros(N, g.Ho, g.Wo, Co, dtype=STORE_DTYPE, device='cuda')
     H.check(H.lib.evk_conv2d_fwd(H.ptr(xd), H.ptr(wd), H.ptr(y), C.byref(g), H.stream()))
     xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
     wr = w.float().permute(0, 3, 1, 2).requires_grad_(True)
@@ -155,7 +157,7 @@ def test_conv_fwd_dgrad_wgrad(H, cfg):
     dy = rnd(N, g.Ho, g.Wo, Co, seed=10)
     yr.backward(dy.float().permute(0, 3, 1, 2))
     dyd = dy.cuda()
-    dx = torch.full((N, Hi, Wi, Ci), 7.0, dtype=torch.bfloat16, device='cuda')
+    dx = torch.full((N, Hi, Wi, Ci), 7.0, dtype=STORE_DTYPE, device='cuda')
     H.check(H.lib.evk_conv2d_dgrad(H.ptr(dyd), H.ptr(wd), H.ptr(dx), C.byref(g), H.stream()))
     close(dx, xr.grad.permute(0, 2, 3, 1), 1e-2, 2e-2 * (KH * KH * Co / 64) ** 0.5 * w.float().std().item())
     dw = torch.zeros(Co, KH, KH, Ci, dtype=torch.float32, device='cuda')
@@ -174,14 +176,14 @@ def test_stem(H, N, Hh, W):
     img = torch.randn(N, 3, Hh, W, generator=g)
     w = torch.randn(64, 3, 7, 7, generator=g) * 0.1
     imgd, wdev = img.cuda(), w.cuda()
-    xpad = torch.empty(N, Hh + 6, W + 8, 4, dtype=torch.bfloat16, device='cuda')
-    wp = torch.empty(64, 7, 8, 4, dtype=torch.bfloat16, device='cuda')
+    xpad = torch.empty(N, Hh + 6, W + 8, 4, dtype=STORE_DTYPE, device='cuda')
+    wp = torch.empty(64, 7, 8, 4, dtype=STORE_DTYPE, device='cuda')
     H.check(H.lib.evk_stem_pack_image(H.ptr(imgd), H.ptr(xpad), N, Hh, W, H.stream()))
     H.check(H.lib.evk_stem_pack_weight(H.ptr(wdev), H.ptr(wp), H.stream()))
-    y = torch.zeros(N, Hh // 2, W // 2, 64, dtype=torch.bfloat16, device='cuda')
+    y = torch.zeros(N, Hh // 2, W // 2, 64, dtype=STORE_DTYPE, device='cuda')
     H.check(H.lib.evk_stem_fwd(H.ptr(xpad), H.ptr(wp), H.ptr(y), N, Hh, W, H.stream()))
-    ir = img.to(torch.bfloat16).float().requires_grad_(False)
-    wr = w.to(torch.bfloat16).float().requires_grad_(True)
+    ir = img.to(STORE_DTYPE).float().requires_grad_(False)
+    wr = w.to(STORE_DTYPE).float().requires_grad_(True)
     yr = F.conv2d(ir, wr, None, 2, 3)
     close(y, yr.detach().permute(0, 2, 3, 1), 1e-2, 3e-2)
     dy = rnd(N, Hh // 2, W // 2, 64, seed=12)
@@ -197,8 +199,8 @@ def test_stem(H, N, Hh, W):
 
 
 def test_gemm_rejects_bad_args(H):
-    a = torch.zeros(8, 12, dtype=torch.bfloat16, device='cuda')
-    c = torch.zeros(8, 8, dtype=torch.bfloat16, device='cuda')
+    a = torch.zeros(8, 12, dtype=STORE_DTYPE, device='cuda')
+    c = torch.zeros(8, 8, dtype=STORE_DTYPE, device='cuda')
     d = base_desc(H, a, a, c, 8, 8, 12, lda=12, ldb=12, ldc=8)
     with pytest.raises(RuntimeError):
         H.gemm_launch(d)
