@@ -3,6 +3,7 @@
 Reference = torch CPU fp32 math on the same bf16-rounded operands, so the only differences are the f32
 accumulation order and the final bf16 rounding of the output (tolerances stated per test)."""
 import ctypes as C
+import os
 
 import pytest
 import torch
@@ -204,3 +205,19 @@ def test_gemm_rejects_bad_args(H):
     d = base_desc(H, a, a, c, 8, 8, 12, lda=12, ldb=12, ldc=8)
     with pytest.raises(RuntimeError):
         H.gemm_launch(d)
+
+
+@pytest.mark.skipif(os.environ.get('EVK_TILE256') is not None, reason='already running with a forced tile choice')
+def test_kernel_suite_with_the_256x256_tile_forced():
+    """gemm.hip picks the 256 x 256 / 16-wave tile only for plain NT products of >= 1024 big tiles; EVK_TILE256=1 forces it
+    for every plain NT product with M, N >= 256 (batched attention scores, linears with bias / activation / residual
+    epilogues, ragged edges), so the kernel tests run once more that way in a child interpreter (the choice is read once)."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(here, 'test_hip_gemm.py'), os.path.join(here, 'test_hip_ops.py'),
+                        '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider'], env=dict(os.environ, EVK_TILE256='1'),
+                       capture_output=True, text=True, timeout=900, cwd=os.path.dirname(here))
+    tail = '\n'.join((r.stdout + r.stderr).splitlines()[-20:])
+    print(tail)
+    assert r.returncode == 0, tail
