@@ -170,10 +170,15 @@ __global__ __launch_bounds__(256) void colsum8_kernel(const bf16_t* __restrict__
 struct OptP {
   float* p; const float* g; float* m; float* v; float* vmax; bf16_t* shadow; long n;
   float lr, beta1, beta2, eps, wd, clip, bc1, bc2_sqrt, rect; int kind; int use_rect;
+  float gscale;      // gradients arrive multiplied by 1/gscale (static loss scale of the fp16-storage build); 1 = off
 };
 __global__ __launch_bounds__(256) void optim_kernel(const OptP o) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < o.n; i += (long)gridDim.x * blockDim.x) {
     float g = o.g[i];
+    if (o.gscale != 1.f) {
+      g *= o.gscale;
+      if (!isfinite(g)) continue;      // an overflowed fp16 gradient: leave this element's state untouched for the step
+    }
     if (o.clip > 0.f) g = fminf(fmaxf(g, -o.clip), o.clip);
     float w = o.p[i];
     if (o.wd != 0.f) g += o.wd * w;
@@ -278,9 +283,15 @@ int evk_colsum(const void* x, float* out, int64_t M, int32_t N, int64_t ld, evk_
 
 int evk_optim_step(float* p, const float* g, float* m, float* v, float* vmax, void* shadow, int64_t n, int32_t kind, float lr,
                    float beta1, float beta2, float eps, float weight_decay, float clip, int64_t step, evk_stream_t stream) {
+  return evk_optim_step_scaled(p, g, m, v, vmax, shadow, n, kind, lr, beta1, beta2, eps, weight_decay, clip, step, 1.f, stream);
+}
+
+int evk_optim_step_scaled(float* p, const float* g, float* m, float* v, float* vmax, void* shadow, int64_t n, int32_t kind, float lr,
+                          float beta1, float beta2, float eps, float weight_decay, float clip, int64_t step, float grad_scale,
+                          evk_stream_t stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  EVK_REQUIRE(p && g && m && v && n > 0 && step >= 1 && (kind == 0 || kind == 1), "optim_step: bad args");
-  OptP o{p, g, m, v, vmax, (bf16_t*)shadow, n, lr, beta1, beta2, eps, weight_decay, clip, 0.f, 0.f, 0.f, kind, 0};
+  EVK_REQUIRE(p && g && m && v && n > 0 && step >= 1 && (kind == 0 || kind == 1) && grad_scale > 0.f, "optim_step: bad args");
+  OptP o{p, g, m, v, vmax, (bf16_t*)shadow, n, lr, beta1, beta2, eps, weight_decay, clip, 0.f, 0.f, 0.f, kind, 0, grad_scale};
   const double b1t = pow((double)beta1, (double)step), b2t = pow((double)beta2, (double)step);
   o.bc1 = (float)(1.0 - b1t);
   o.bc2_sqrt = (float)sqrt(1.0 - b2t);

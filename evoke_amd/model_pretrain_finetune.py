@@ -165,6 +165,7 @@ class FineTune(_Base):
         x, enc_mask = self.encoder_states(images, patient_ids, report_ids.shape[0], inc_ids, inc_masks)
         ret = self.text_decoder_forward(report_ids, report_masks, x, enc_mask, mode=mode, **kw)
         if mode == 'train':
+            ret = ops.scale_loss(ret)
             return {'lm': ret, 'all_loss': ret}
         return [ret[0], ret[1]]
 
@@ -219,4 +220,4 @@ class Pretrain(_Base):
         if self.args['is_multiview_learning']:
             all_loss = all_loss + mul_pos_loss
         return {'sen_image_loss': torch.tensor([0.0]), 'sen_text_loss': sen_text_loss, 'instance_loss': instance_loss,
-                'multiview_loss': mul_pos_loss, 'all_loss': all_loss}
+                'multiview_loss': mul_pos_loss, 'all_loss': ops.scale_loss(all_loss)}

@@ -18,6 +18,28 @@ from . import hip as H
 
 BF16, F32 = H.STORE_DTYPE, torch.float32      # BF16 = the 16-bit storage dtype of the loaded library (bf16, or fp16 under EVK_STORE=f16)
 
+# Static loss scale of the fp16-storage build (EVK_STORE=f16): FineTune / Pretrain return `all_loss` through scale_loss(), whose
+# backward multiplies the incoming gradient by LOSS_SCALE, so every 16-bit activation gradient of the step is 2^10 times
+# larger than its true value and stays in fp16's normal range; the f32 parameter gradients carry the same factor and
+# FusedOptimizer.step() divides it out before clipping (evk_optim_step_scaled).  The value of the loss is unchanged.  bf16
+# storage has fp32's exponent range and needs none (scale 1).  `p.grad` holds SCALED gradients while the scale is not 1.
+LOSS_SCALE = float(os.environ.get('EVK_LOSS_SCALE', '1024' if H.STORE == 'f16' else '1'))
+
+
+class _ScaleGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * LOSS_SCALE
+
+
+def scale_loss(loss):
+    return _ScaleGrad.apply(loss) if LOSS_SCALE != 1.0 and loss.requires_grad else loss
+
+
 # ----------------------------------------------------------------------------------------------------
 # parameter shadows + direct gradient accumulation
 # ----------------------------------------------------------------------------------------------------

@@ -167,11 +167,11 @@ class FusedOptimizer(torch.optim.Optimizer):
                     runs.append(cur)
             for a, b, k in runs:
                 es, eb = 4 * a, 2 * a
-                H.check(H.lib.evk_optim_step(st['p'].data_ptr() + es, st['g'].data_ptr() + es, st['m'].data_ptr() + es,
-                                             st['v'].data_ptr() + es, (st['vmax'].data_ptr() + es) if st['vmax'] is not None else None,
-                                             (st['shadow'].data_ptr() + eb) if st['shadow'] is not None else None, b - a, self.kind,
-                                             float(g['lr']), b1, b2, g['eps'], g['weight_decay'], float(self.clip_value or 0.0), k,
-                                             H.stream()), 'optim_step')
+                H.check(H.lib.evk_optim_step_scaled(st['p'].data_ptr() + es, st['g'].data_ptr() + es, st['m'].data_ptr() + es,
+                                                    st['v'].data_ptr() + es, (st['vmax'].data_ptr() + es) if st['vmax'] is not None else None,
+                                                    (st['shadow'].data_ptr() + eb) if st['shadow'] is not None else None, b - a, self.kind,
+                                                    float(g['lr']), b1, b2, g['eps'], g['weight_decay'], float(self.clip_value or 0.0), k,
+                                                    1.0 / ops.LOSS_SCALE, H.stream()), 'optim_step')
         self._touched.clear()
 
 

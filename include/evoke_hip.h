@@ -262,6 +262,13 @@ int evk_colsum(const void* x, float* out, int64_t M, int32_t N, int64_t ld, evk_
  * optimizers.py:17-53).  kind 0 = torch.optim.RAdam, kind 1 = torch.optim.Adam (vmax != NULL -> amsgrad)      */
 int evk_optim_step(float* p, const float* g, float* m, float* v, float* vmax, void* shadow, int64_t n, int32_t kind, float lr,
                    float beta1, float beta2, float eps, float weight_decay, float clip, int64_t step, evk_stream_t stream);
+/* same with the gradients multiplied by grad_scale first (= 1 / loss scale: the fp16-storage build back-propagates a loss
+ * scaled by a constant so that its 16-bit gradients stay in fp16's normal range; torch.cuda.amp.GradScaler.unscale_ is
+ * the closest public counterpart, the reference itself trains in fp32 and has none).  Elements whose scaled gradient is
+ * not finite are skipped for the step. */
+int evk_optim_step_scaled(float* p, const float* g, float* m, float* v, float* vmax, void* shadow, int64_t n, int32_t kind, float lr,
+                          float beta1, float beta2, float eps, float weight_decay, float clip, int64_t step, float grad_scale,
+                          evk_stream_t stream);
 
 /* ---- relational memory runner (rm.hip): RelationalMemory.forward / forward_step, encoder_decoder.py:274-300 ------
  * The host loop over tokens lives in the library (5 GEMM launches + 2 fused kernels per token forward, BPTT backward,

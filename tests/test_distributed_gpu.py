@@ -110,7 +110,6 @@ def _run(kind):
     return out
 
 
-@pytest.mark.skipif(F16_BUILD, reason=NO_F16_GRADS)
 def test_two_rank_finetune_step_on_one_gpu():
     out = _run('finetune')
     for rank, losses, sigs, _ in out:
@@ -132,7 +131,10 @@ def test_two_rank_finetune_step_on_one_gpu():
     ops.set_dropout_enabled(True)
     want = acc / 2
     got = out[0][3].astype(np.float64)
-    assert np.abs(got - want).max() <= 1e-6 + 1e-4 * np.abs(want).max(), np.abs(got - want).max()
+    # bf16: halving the loss (1/world) is exact, the two computations agree to rounding.  fp16 storage: the halved activation
+    # gradients lose a bit wherever they are subnormal and train-mode BN amplifies that down the trunk (measured 3e-3)
+    rtol = 2e-2 if F16_BUILD else 1e-4
+    assert np.abs(got - want).max() <= 1e-6 + rtol * np.abs(want).max(), np.abs(got - want).max()
 
 
 def test_two_rank_pretrain_step_on_one_gpu():

@@ -305,6 +305,18 @@ def test_optim_step_matches_torch():
                                          kind, 5e-3, 0.9, 0.999, 1e-8, 1e-4, 0.1, step, H.stream()))
         close(pd, pr, 1e-5, 1e-6, 'optim kind %d' % kind)
         close(sh, pr, 1e-2, 1e-3, 'shadow')
+        # loss-scaled gradients (x 1024) with grad_scale = 1/1024 take the same steps; a non-finite gradient skips its element
+        pd2 = p0.clone().cuda()
+        m2, v2, vm2 = torch.zeros(n).cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+        for step, g in enumerate(gs, 1):
+            gsc = (g * 1024.0).cuda()
+            gsc[7] = float('inf')
+            H.check(H.lib.evk_optim_step_scaled(H.ptr(pd2), H.ptr(gsc), H.ptr(m2), H.ptr(v2), H.ptr(vm2) if kind == 1 else None, None, n,
+                                                kind, 5e-3, 0.9, 0.999, 1e-8, 1e-4, 0.1, step, 1.0 / 1024.0, H.stream()))
+        keep = torch.ones(n, dtype=torch.bool)
+        keep[7] = False
+        close(pd2.cpu()[keep], pd.cpu()[keep], 1e-6, 1e-7, 'scaled optim kind %d' % kind)
+        assert float(pd2[7]) == float(p0[7]) and float(m2[7]) == 0.0
 
 
 def test_conv_fwd_stats_and_dgrad_add():

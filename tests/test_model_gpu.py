@@ -26,11 +26,11 @@ from tests.helpers import ARGS, GOLDEN, V, load_procedural, load_tokenizer
 
 pytestmark = pytest.mark.gpu
 
-# EVK_STORE=f16 (fp16 storage build of the same kernels, forward / evaluation parity mode): the north star's 1e-3 on the loss.
-# Its backward has no loss scaling, so the gradient and train-mode legs run in the default bf16 build only.
+# EVK_STORE=f16 (fp16 storage build of the same kernels): the north star's 1e-3 on the eval-mode loss.  Its backward runs under
+# the static loss scale ops.LOSS_SCALE (parameter gradients carry the factor until the optimizer divides it out).
 F16 = os.environ.get('EVK_STORE', 'bf16').lower() == 'f16'
 LOSS_TOL = 1e-3 if F16 else 5e-3
-LOSS_TOL_TRAIN = 6e-2
+LOSS_TOL_TRAIN = 2e-3 if F16 else 6e-2      # train-mode BN amplifies the storage rounding: fp16 storage measures <= 4.4e-4
 ACT_TOL = 8e-2
 GRAD_TOL = 0.4
 GRAD_COS = 0.5
@@ -74,8 +74,6 @@ def test_finetune_matches_reference(name):
     ops.set_dropout_enabled(False)
     bad = []
     for mode in case['modes']:
-        if F16 and mode != 'eval':
-            continue
         load_procedural(model, spec)
         model.train(mode == 'train')
         model.zero_grad(set_to_none=True)
@@ -90,17 +88,16 @@ def test_finetune_matches_reference(name):
         print('\n[%s/%s] loss hip %.6f ref %.6f  diff %.2e' % (name, mode, loss, want, abs(loss - want)))
         if abs(loss - want) > (LOSS_TOL if mode == 'eval' else LOSS_TOL_TRAIN):
             bad.append('%s loss %.6f vs %.6f' % (mode, loss, want))
-        if not F16:
-            ret['all_loss'].backward()
+        ret['all_loss'].backward()
         if mode == 'eval':
             for tap, t in (('att', taps['resnet'][0]), ('fc', taps['resnet'][1]), ('vhead', taps['vhead']), ('enc_states', taps['fusion'])):
                 if not _report(tap, t, gold['%s/tap/%s' % (mode, tap)], ACT_TOL):
                     bad.append('%s %s' % (mode, tap))
             prm = dict(model.named_parameters())
-            for k in ([] if F16 else gold.files):
+            for k in gold.files:
                 if k.startswith('eval/grad/'):
                     g = prm[k[len('eval/grad/'):]].grad
-                    if g is None or not _report_grad(k[10:], g, gold[k]):
+                    if g is None or not _report_grad(k[10:], g / ops.LOSS_SCALE, gold[k]):
                         bad.append(k)
         else:
             assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
@@ -125,8 +122,6 @@ def test_pretrain_matches_reference(name):
     ops.set_dropout_enabled(False)
     bad = []
     for mode in case['modes']:
-        if F16 and mode != 'eval':
-            continue
         load_procedural(model, spec)
         model.train(mode == 'train')
         model.zero_grad(set_to_none=True)
@@ -142,17 +137,16 @@ def test_pretrain_matches_reference(name):
             if abs(got - want) > (LOSS_TOL if mode == 'eval' else LOSS_TOL_TRAIN):
                 bad.append('%s %s %.6f vs %.6f' % (mode, k, got, want))
         assert tuple(ret['sen_image_loss'].shape) == (1,)
-        if not F16:
-            ret['all_loss'].backward()
+        ret['all_loss'].backward()
         if mode == 'eval':
             for tap, t in (('fc', taps['resnet'][1]), ('vhead', taps['vhead']), ('thead', taps['thead'])):
                 if not _report(tap, t, gold['%s/tap/%s' % (mode, tap)], ACT_TOL):
                     bad.append('%s %s' % (mode, tap))
             prm = dict(model.named_parameters())
-            for k in ([] if F16 else gold.files):
+            for k in gold.files:
                 if k.startswith('eval/grad/'):
                     g = prm[k[len('eval/grad/'):]].grad
-                    if g is None or not _report_grad(k[10:], g, gold[k]):
+                    if g is None or not _report_grad(k[10:], g / ops.LOSS_SCALE, gold[k]):
                         bad.append(k)
         else:
             assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
@@ -328,7 +322,8 @@ def test_f16_storage_build_passes_the_gpu_suite_with_1e3_loss_parity():
     child interpreter (the storage format is fixed per process) -- every kernel family against its reference in fp16
     storage, and the model against the reference's golden vectors with LOSS_TOL = 1e-3, the north star's figure (measured
     1.2e-4 .. 4.7e-4 on the golden FineTune cases, <= 1e-5 on the Pretrain losses, 2.2e-4 at the realistic token count; beam
-    search token-exact).  Gradient-exact legs are skipped there (tests/helpers.py NO_F16_GRADS)."""
+    search token-exact), train-mode losses within 2e-3 (measured <= 4.4e-4; bf16: 6e-2), reduced gradients against the golden ones
+    under the static loss scale.  Only the unscaled unit-level contrastive-gradient check is skipped there (tests/helpers.py)."""
     import gc
     import subprocess
     import sys

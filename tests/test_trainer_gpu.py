@@ -44,7 +44,7 @@ def test_fused_optimizer_state_dict_round_trip(kind):
     def fstep(opt, ps, gs):
         opt.zero_grad()
         for p, g in zip(ps, gs):
-            ops.grad_buffer(p).add_(g.cuda())
+            ops.grad_buffer(p).add_(g.cuda() * ops.LOSS_SCALE)      # gradient buffers carry the loss scale (1 in the bf16 build)
             ops.grad_done(p)
         opt.step()
 
