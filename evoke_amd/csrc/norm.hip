@@ -434,12 +434,14 @@ inline int row_blocks(long rows) { return (int)cdiv(rows, WPB); }
 // the 64 output features and walk the keys with the probabilities broadcast by shuffle.  Replaces three launches (batched
 // QK^T GEMM with M = 1, softmax, batched PV GEMM) whose tiles were 99 % padding.
 // ------------------------------------------------------------------------------------------------
-struct DecAttP { const bf16_t* q; const bf16_t* k; const bf16_t* v; const unsigned char* mask; bf16_t* out; int R, S, H, kv_div; float scale; };
+struct DecAttP { const bf16_t* q; const bf16_t* k; const bf16_t* v; const unsigned char* mask; bf16_t* out; int R, S, H, kv_div; float scale;
+                 const int* rowmap; };   // optional [R][S]: cache row that holds position s of hypothesis r (beam-search cache indirection)
 
 __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttP p) {
   // lane = (g, c): g = lane >> 3 picks one of 8 key rows per pass, c = lane & 7 one 16-byte chunk of the 128-byte head row, so
   // every load instruction of the wave reads 8 whole rows and all passes are independent (no load waits on a shuffle)
   __shared__ float sl[4][256];
+  __shared__ int sr[4][256];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int w = blockIdx.x * 4 + wv;
   if (w >= p.R * p.H) return;
@@ -453,15 +455,21 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttP p) {
     qr[4] = lo_bf(u.z); qr[5] = hi_bf(u.z); qr[6] = lo_bf(u.w); qr[7] = hi_bf(u.w);
   }
   const long rk = r / p.kv_div;          // kv_div consecutive query rows (the beams of one sample) share one K / V / mask row
-  const bf16_t* kb = p.k + rk * p.S * HD + h * 64 + c * 8;
-  const bf16_t* vb = p.v + rk * p.S * HD + h * 64 + c * 8;
+  const bf16_t* kb = p.k + h * 64 + c * 8;
+  const bf16_t* vb = p.v + h * 64 + c * 8;
   const unsigned char* mk = p.mask ? p.mask + rk * p.S : nullptr;
   const int passes = (p.S + 7) >> 3;
+  // cache row of every position: r / kv_div, or -- beam search without moving the caches -- the row of the ancestor that
+  // wrote position s (rowmap); staged in LDS so that no K / V load waits on an index load
+  for (int s = lane; s < p.S; s += 64) sr[wv][s] = p.rowmap ? p.rowmap[(long)r * p.S + s] : (int)rk;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   for (int it = 0; it < passes; ++it) {
     const int s = it * 8 + g;
     float a = 0.f;
     if (s < p.S) {
-      const uint4 u = *reinterpret_cast<const uint4*>(kb + (long)s * HD);
+      const uint4 u = *reinterpret_cast<const uint4*>(kb + ((long)sr[wv][s] * p.S + s) * HD);
       a = lo_bf(u.x) * qr[0] + hi_bf(u.x) * qr[1] + lo_bf(u.y) * qr[2] + hi_bf(u.y) * qr[3] + lo_bf(u.z) * qr[4] + hi_bf(u.z) * qr[5] +
           lo_bf(u.w) * qr[6] + hi_bf(u.w) * qr[7];
     }
@@ -492,7 +500,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttP p) {
   for (int it = 0; it < passes; ++it) {
     const int s = it * 8 + g;
     if (s < p.S) {
-      const uint4 u = *reinterpret_cast<const uint4*>(vb + (long)s * HD);
+      const uint4 u = *reinterpret_cast<const uint4*>(vb + ((long)sr[wv][s] * p.S + s) * HD);
       const float ps = sl[wv][s];
       o[0] += ps * lo_bf(u.x); o[1] += ps * hi_bf(u.x); o[2] += ps * lo_bf(u.y); o[3] += ps * hi_bf(u.y);
       o[4] += ps * lo_bf(u.z); o[5] += ps * hi_bf(u.z); o[6] += ps * lo_bf(u.w); o[7] += ps * hi_bf(u.w);
@@ -628,10 +636,21 @@ int evk_decode_attention(const void* q, const void* k, const void* v, const unsi
   EVK_REQUIRE(q && k && v && out && R > 0 && S > 0 && heads > 0, "decode_attention: null/empty");
   EVK_REQUIRE(head_dim == 64 && S <= 256, "decode_attention: head_dim must be 64 and S <= 256 (got %d, %d)", head_dim, S);
   EVK_REQUIRE(kv_div >= 1 && R % kv_div == 0, "decode_attention: R=%d must be a multiple of kv_div=%d", R, kv_div);
-  DecAttP p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, mask, (bf16_t*)out, R, S, heads, kv_div, scale};
+  DecAttP p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, mask, (bf16_t*)out, R, S, heads, kv_div, scale, nullptr};
   ProfScope ps(EVK_FAM_NORM, s);
   hipLaunchKernelGGL(decode_attn_kernel, dim3((int)cdiv((long)R * heads, 4)), dim3(256), 0, s, p);
   return evk_check_launch("decode_attention");
+}
+
+int evk_decode_attention_indirect(const void* q, const void* k, const void* v, const unsigned char* mask, const int32_t* rowmap, void* out,
+                                  int32_t R, int32_t S, int32_t heads, int32_t head_dim, float scale, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(q && k && v && out && rowmap && R > 0 && S > 0 && heads > 0, "decode_attention_indirect: null/empty");
+  EVK_REQUIRE(head_dim == 64 && S <= 256, "decode_attention_indirect: head_dim must be 64 and S <= 256 (got %d, %d)", head_dim, S);
+  DecAttP p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, mask, (bf16_t*)out, R, S, heads, 1, scale, rowmap};
+  ProfScope ps(EVK_FAM_NORM, s);
+  hipLaunchKernelGGL(decode_attn_kernel, dim3((int)cdiv((long)R * heads, 4)), dim3(256), 0, s, p);
+  return evk_check_launch("decode_attention_indirect");
 }
 
 }  // extern "C"

@@ -9,6 +9,7 @@ as state, the per-position conditional-LayerNorm inputs taken from the current m
 (segmented top-k, EOS handling, the -1000 penalty, best-finished-beam tracking) done on the device.
 """
 import ctypes as C
+import os
 import math
 
 import torch
@@ -17,6 +18,7 @@ from . import hip as H
 from . import ops
 from .ops import BF16, F32
 
+_INDIRECT = [os.environ.get('EVK_DECODE_INDIRECT', '1') != '0']      # beam search re-orders a row table, not the K/V caches
 _GRAPH_ENABLED = [True]          # capture the per-token launch sequence in a HIP graph (set False to debug eagerly)
 
 
@@ -28,13 +30,22 @@ def _topk(x, k):
     return vals, idx
 
 
-def _attend1(q, k, v, heads, mask):
+def _attend1(q, k, v, heads, mask, rowmap=None):
     """One-query attention: q (R, 1, H*dh); k / v (R/div, S, H*dh) and mask uint8 (R/div, S) or None, where `div` consecutive
-    query rows (the beams of one sample) share a K / V row -> (R, 1, H*dh)."""
+    query rows (the beams of one sample) share a K / V row -> (R, 1, H*dh).  rowmap int32 (R, S): position s of hypothesis r
+    lives in cache row rowmap[r, s] (beam search that re-orders the index table instead of the caches)."""
     R = q.shape[0]
     Rk, S, HD = k.shape
     dh = HD // heads
     div = R // Rk
+    if rowmap is not None:
+        if dh != 64 or S > 256 or div != 1:
+            raise NotImplementedError('cache indirection needs head_dim 64, S <= 256')
+        out = torch.empty_like(q)
+        H.check(H.lib.evk_decode_attention_indirect(H.ptr(q), H.ptr(k), H.ptr(v), H.ptr(mask) if mask is not None else None, H.ptr(rowmap),
+                                                    H.ptr(out), R, S, heads, dh, C.c_float(1.0 / math.sqrt(dh)), H.stream()),
+                'decode_attention_indirect')
+        return out
     if dh != 64 or S > 256:
         if div > 1:
             k, v = k.repeat_interleave(div, 0), v.repeat_interleave(div, 0)
@@ -105,6 +116,7 @@ class _DecoderState:
         self.enc, self.src_mask = enc, src_mask
         self.mem = model.rm.init_memory(R, enc.device)
         self.t = 0
+        self.anc = self.rows = None      # cache row table of the graph-mode steps (step_static)
         self.fused = _FusedDecodeWeights(model)
         self.kc, self.vc, self.ks, self.vs = [], [], [], []
         for layer in model.decoder.layers:
@@ -134,6 +146,11 @@ class _DecoderState:
         # ix only permutes hypotheses WITHIN a sample (state_ix = beam_ix + sample * beam): the encoder states, their mask and
         # the cross-attention K/V are identical for all beams of a sample and need no reordering once expanded
         self.mem.copy_(self.mem.index_select(0, ix))
+        if self.anc is not None:
+            # the self-attention caches stay where they are: hypothesis r inherits the ROW TABLE of its parent (position s of
+            # r lives in the cache row of the ancestor that wrote it) -- 100 KB moved instead of 6 x 26 MB gathered and copied
+            self.anc.copy_(self.anc.index_select(0, ix))
+            return
         for i in range(len(self.ks)):
             self.ks[i].copy_(self.ks[i].index_select(0, ix))
             self.vs[i].copy_(self.vs[i].index_select(0, ix))
@@ -144,6 +161,12 @@ class _DecoderState:
         sequence can be captured once in a HIP graph and replayed."""
         model = self.model
         h = model.decoder.layers[0].self_attn.h
+        if self.anc is None and _INDIRECT[0] and model.d_model // h == 64 and self.ks[0].shape[1] <= 256:
+            R_, S_ = self.ks[0].shape[0], self.ks[0].shape[1]
+            self.rows = torch.arange(R_, dtype=torch.int32, device=pos.device).view(R_, 1)
+            self.anc = self.rows.expand(R_, S_).contiguous()
+        if self.anc is not None:
+            self.anc.index_copy_(1, pos, self.rows)      # this step's K / V are written to the hypothesis's own cache row
         pe = model.tgt_embed[1].pe[0].index_select(0, pos)
         emb = ops.embedding(it.view(-1, 1).contiguous(), model.tgt_embed[0].lut.weight, pos=pe, scale=math.sqrt(model.d_model))
         memory, new_mem = model.rm.run(emb, self.mem)
@@ -158,7 +181,7 @@ class _DecoderState:
             q = qkv[:, :d].contiguous().view(-1, 1, d)
             self.ks[i].index_copy_(1, pos, qkv[:, d:2 * d].unsqueeze(1))
             self.vs[i].index_copy_(1, pos, qkv[:, 2 * d:].unsqueeze(1))
-            c = _attend1(q, self.ks[i], self.vs[i], h, kmask)
+            c = _attend1(q, self.ks[i], self.vs[i], h, kmask, rowmap=self.anc)
             x = sa.linears[3](c, resid=x)
             n = fw.norm(3 * i + 1, x, deltas)
             ca = layer.src_attn

@@ -441,6 +441,16 @@ def test_decode_attention_matches_reference():
             H.check(H.lib.evk_decode_attention(H.ptr(q4), H.ptr(k4), H.ptr(v4), H.ptr(m4) if m4 is not None else None, H.ptr(ref4), 4 * R, S,
                                                heads, 64, 1, C.c_float(0.125), H.stream()))
             assert torch.equal(out4, ref4)
+        # cache indirection: position s of hypothesis r lives in cache row rowmap[r, s] -> same bits as gathering the caches
+        rowmap = torch.randint(0, R, (R, S), device='cuda', dtype=torch.int32)
+        gi = rowmap.long().unsqueeze(-1).expand(R, S, HD)
+        kg, vg = k.gather(0, gi).contiguous(), v.gather(0, gi).contiguous()
+        ref_i, out_i = torch.empty_like(q), torch.empty_like(q)
+        H.check(H.lib.evk_decode_attention(H.ptr(q), H.ptr(kg), H.ptr(vg), H.ptr(mask) if mask is not None else None, H.ptr(ref_i), R, S,
+                                           heads, 64, 1, C.c_float(0.125), H.stream()))
+        H.check(H.lib.evk_decode_attention_indirect(H.ptr(q), H.ptr(k), H.ptr(v), H.ptr(mask) if mask is not None else None, H.ptr(rowmap),
+                                                    H.ptr(out_i), R, S, heads, 64, C.c_float(0.125), H.stream()))
+        assert torch.equal(out_i, ref_i)
 
 
 def test_native_trunk_frozen_parameters_and_no_grad():
