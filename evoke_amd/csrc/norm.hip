@@ -435,7 +435,8 @@ inline int row_blocks(long rows) { return (int)cdiv(rows, WPB); }
 // QK^T GEMM with M = 1, softmax, batched PV GEMM) whose tiles were 99 % padding.
 // ------------------------------------------------------------------------------------------------
 struct DecAttP { const bf16_t* q; const bf16_t* k; const bf16_t* v; const unsigned char* mask; bf16_t* out; int R, S, H, kv_div; float scale;
-                 const int* rowmap; };   // optional [R][S]: cache row that holds position s of hypothesis r (beam-search cache indirection)
+                 const int* rowmap;      // optional [R][S]: cache row that holds position s of hypothesis r (beam-search cache indirection)
+                 const long long* last_pos; };   // optional device scalar: only positions <= *last_pos exist (neither read nor attended)
 
 __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttP p) {
   // lane = (g, c): g = lane >> 3 picks one of 8 key rows per pass, c = lane & 7 one 16-byte chunk of the 128-byte head row, so
@@ -458,17 +459,18 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttP p) {
   const bf16_t* kb = p.k + h * 64 + c * 8;
   const bf16_t* vb = p.v + h * 64 + c * 8;
   const unsigned char* mk = p.mask ? p.mask + rk * p.S : nullptr;
-  const int passes = (p.S + 7) >> 3;
+  const int Seff = p.last_pos ? min(p.S, (int)*p.last_pos + 1) : p.S;
+  const int passes = (Seff + 7) >> 3;
   // cache row of every position: r / kv_div, or -- beam search without moving the caches -- the row of the ancestor that
   // wrote position s (rowmap); staged in LDS so that no K / V load waits on an index load
-  for (int s = lane; s < p.S; s += 64) sr[wv][s] = p.rowmap ? p.rowmap[(long)r * p.S + s] : (int)rk;
+  for (int s = lane; s < Seff; s += 64) sr[wv][s] = p.rowmap ? p.rowmap[(long)r * p.S + s] : (int)rk;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   for (int it = 0; it < passes; ++it) {
     const int s = it * 8 + g;
     float a = 0.f;
-    if (s < p.S) {
+    if (s < Seff) {
       const uint4 u = *reinterpret_cast<const uint4*>(kb + ((long)sr[wv][s] * p.S + s) * HD);
       a = lo_bf(u.x) * qr[0] + hi_bf(u.x) * qr[1] + lo_bf(u.y) * qr[2] + hi_bf(u.y) * qr[3] + lo_bf(u.z) * qr[4] + hi_bf(u.z) * qr[5] +
           lo_bf(u.w) * qr[6] + hi_bf(u.w) * qr[7];
@@ -476,16 +478,16 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttP p) {
     a += __shfl_xor(a, 1, 64);
     a += __shfl_xor(a, 2, 64);
     a += __shfl_xor(a, 4, 64);
-    if (c == 0 && s < p.S) sl[wv][s] = (mk && !mk[s]) ? -INFINITY : a * p.scale;
+    if (c == 0 && s < Seff) sl[wv][s] = (mk && !mk[s]) ? -INFINITY : a * p.scale;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   float mx = -INFINITY;
-  for (int s = lane; s < p.S; s += 64) mx = fmaxf(mx, sl[wv][s]);
+  for (int s = lane; s < Seff; s += 64) mx = fmaxf(mx, sl[wv][s]);
   mx = wave_max(mx);
   float sum = 0.f;
-  for (int s = lane; s < p.S; s += 64) {
+  for (int s = lane; s < Seff; s += 64) {
     const float x = sl[wv][s];
     const float e = (x == -INFINITY || mx == -INFINITY) ? 0.f : __expf(x - mx);
     sl[wv][s] = e;
@@ -499,7 +501,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttP p) {
   float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int it = 0; it < passes; ++it) {
     const int s = it * 8 + g;
-    if (s < p.S) {
+    if (s < Seff) {
       const uint4 u = *reinterpret_cast<const uint4*>(vb + ((long)sr[wv][s] * p.S + s) * HD);
       const float ps = sl[wv][s];
       o[0] += ps * lo_bf(u.x); o[1] += ps * hi_bf(u.x); o[2] += ps * lo_bf(u.y); o[3] += ps * hi_bf(u.y);
@@ -636,18 +638,20 @@ int evk_decode_attention(const void* q, const void* k, const void* v, const unsi
   EVK_REQUIRE(q && k && v && out && R > 0 && S > 0 && heads > 0, "decode_attention: null/empty");
   EVK_REQUIRE(head_dim == 64 && S <= 256, "decode_attention: head_dim must be 64 and S <= 256 (got %d, %d)", head_dim, S);
   EVK_REQUIRE(kv_div >= 1 && R % kv_div == 0, "decode_attention: R=%d must be a multiple of kv_div=%d", R, kv_div);
-  DecAttP p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, mask, (bf16_t*)out, R, S, heads, kv_div, scale, nullptr};
+  DecAttP p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, mask, (bf16_t*)out, R, S, heads, kv_div, scale, nullptr, nullptr};
   ProfScope ps(EVK_FAM_NORM, s);
   hipLaunchKernelGGL(decode_attn_kernel, dim3((int)cdiv((long)R * heads, 4)), dim3(256), 0, s, p);
   return evk_check_launch("decode_attention");
 }
 
-int evk_decode_attention_indirect(const void* q, const void* k, const void* v, const unsigned char* mask, const int32_t* rowmap, void* out,
-                                  int32_t R, int32_t S, int32_t heads, int32_t head_dim, float scale, evk_stream_t stream) {
+int evk_decode_attention_indirect(const void* q, const void* k, const void* v, const unsigned char* mask, const int32_t* rowmap,
+                                  const int64_t* last_pos, void* out, int32_t R, int32_t S, int32_t heads, int32_t head_dim, float scale,
+                                  evk_stream_t stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   EVK_REQUIRE(q && k && v && out && rowmap && R > 0 && S > 0 && heads > 0, "decode_attention_indirect: null/empty");
   EVK_REQUIRE(head_dim == 64 && S <= 256, "decode_attention_indirect: head_dim must be 64 and S <= 256 (got %d, %d)", head_dim, S);
-  DecAttP p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, mask, (bf16_t*)out, R, S, heads, 1, scale, rowmap};
+  DecAttP p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, mask, (bf16_t*)out, R, S, heads, 1, scale, rowmap,
+            reinterpret_cast<const long long*>(last_pos)};
   ProfScope ps(EVK_FAM_NORM, s);
   hipLaunchKernelGGL(decode_attn_kernel, dim3((int)cdiv((long)R * heads, 4)), dim3(256), 0, s, p);
   return evk_check_launch("decode_attention_indirect");

@@ -30,7 +30,7 @@ def _topk(x, k):
     return vals, idx
 
 
-def _attend1(q, k, v, heads, mask, rowmap=None):
+def _attend1(q, k, v, heads, mask, rowmap=None, last_pos=None):
     """One-query attention: q (R, 1, H*dh); k / v (R/div, S, H*dh) and mask uint8 (R/div, S) or None, where `div` consecutive
     query rows (the beams of one sample) share a K / V row -> (R, 1, H*dh).  rowmap int32 (R, S): position s of hypothesis r
     lives in cache row rowmap[r, s] (beam search that re-orders the index table instead of the caches)."""
@@ -43,7 +43,8 @@ def _attend1(q, k, v, heads, mask, rowmap=None):
             raise NotImplementedError('cache indirection needs head_dim 64, S <= 256')
         out = torch.empty_like(q)
         H.check(H.lib.evk_decode_attention_indirect(H.ptr(q), H.ptr(k), H.ptr(v), H.ptr(mask) if mask is not None else None, H.ptr(rowmap),
-                                                    H.ptr(out), R, S, heads, dh, C.c_float(1.0 / math.sqrt(dh)), H.stream()),
+                                                    H.ptr(last_pos) if last_pos is not None else None, H.ptr(out), R, S, heads, dh,
+                                                    C.c_float(1.0 / math.sqrt(dh)), H.stream()),
                 'decode_attention_indirect')
         return out
     if dh != 64 or S > 256:
@@ -181,7 +182,10 @@ class _DecoderState:
             q = qkv[:, :d].contiguous().view(-1, 1, d)
             self.ks[i].index_copy_(1, pos, qkv[:, d:2 * d].unsqueeze(1))
             self.vs[i].index_copy_(1, pos, qkv[:, 2 * d:].unsqueeze(1))
-            c = _attend1(q, self.ks[i], self.vs[i], h, kmask, rowmap=self.anc)
+            if self.anc is not None:         # positions <= pos only: the kernel reads the step index from the device
+                c = _attend1(q, self.ks[i], self.vs[i], h, None, rowmap=self.anc, last_pos=pos)
+            else:
+                c = _attend1(q, self.ks[i], self.vs[i], h, kmask)
             x = sa.linears[3](c, resid=x)
             n = fw.norm(3 * i + 1, x, deltas)
             ca = layer.src_attn
@@ -287,7 +291,7 @@ def beam_search(dec, enc_states, enc_mask, args, return_scores=False):
                 """steps 1 .. max_len-2: bookkeeping at position `pos`, then the decoder step that writes position pos+1."""
                 w_ = book(None, False)
                 pos.add_(1)
-                kmask = (ar <= pos).expand(R, -1).to(torch.uint8).contiguous()
+                kmask = (ar <= pos).expand(R, -1).to(torch.uint8).contiguous() if st.anc is None else None
                 logp_buf.copy_(st.step_static(w_.reshape(-1), pos, kmask))
 
             n_body = max_len - 2                                         # iterations t = 1 .. max_len-2

@@ -203,10 +203,13 @@ int evk_decode_attention(const void* q, const void* k, const void* v, const unsi
                          int32_t heads, int32_t head_dim, int32_t kv_div, float scale, evk_stream_t stream);
 /* the same over self-attention caches that beam search does NOT re-order: rowmap int32 [R][S] names, for hypothesis r and
  * position s, the cache row that holds that position (the row of the ancestor that wrote it); k/v bf16 [R][S][heads*64],
- * mask uint8 [R][S].  Replaces the per-step state gather of caption_model.py:beam_step (`new_state[_][:, beam_ix]`,
- * caption_model.py:74-86) on the K/V caches by a gather of the [R][S] index table.                                     */
-int evk_decode_attention_indirect(const void* q, const void* k, const void* v, const unsigned char* mask, const int32_t* rowmap, void* out,
-                                  int32_t R, int32_t S, int32_t heads, int32_t head_dim, float scale, evk_stream_t stream);
+ * mask uint8 [R][S] or NULL; last_pos (device int64 scalar, or NULL): only positions <= *last_pos have been written --
+ * later ones are neither read nor attended (the causal mask of the incremental step).  Replaces the per-step state gather
+ * of caption_model.py:beam_step (`new_state[_][:, beam_ix]`, caption_model.py:74-86) on the K/V caches by a gather of the
+ * [R][S] index table.                                                                                                */
+int evk_decode_attention_indirect(const void* q, const void* k, const void* v, const unsigned char* mask, const int32_t* rowmap,
+                                  const int64_t* last_pos, void* out, int32_t R, int32_t S, int32_t heads, int32_t head_dim, float scale,
+                                  evk_stream_t stream);
 int evk_log_softmax_nll_fwd(const float* logits, float* logp, float* lse, const int64_t* target, const float* wmask, float* acc2,
                             int64_t rows, int32_t V, int32_t ld, int32_t ld_out, evk_stream_t stream);
 int evk_nll_bwd(const float* logits, const float* lse, const int64_t* target, const float* wmask, const float* gscale,

@@ -449,7 +449,15 @@ def test_decode_attention_matches_reference():
         H.check(H.lib.evk_decode_attention(H.ptr(q), H.ptr(kg), H.ptr(vg), H.ptr(mask) if mask is not None else None, H.ptr(ref_i), R, S,
                                            heads, 64, 1, C.c_float(0.125), H.stream()))
         H.check(H.lib.evk_decode_attention_indirect(H.ptr(q), H.ptr(k), H.ptr(v), H.ptr(mask) if mask is not None else None, H.ptr(rowmap),
-                                                    H.ptr(out_i), R, S, heads, 64, C.c_float(0.125), H.stream()))
+                                                    None, H.ptr(out_i), R, S, heads, 64, C.c_float(0.125), H.stream()))
+        assert torch.equal(out_i, ref_i)
+        # device-side step index instead of a mask: positions > last_pos are neither read nor attended
+        lp = torch.tensor([S // 2], device='cuda', dtype=torch.long)
+        causal = (torch.arange(S, device='cuda') <= lp).to(torch.uint8).unsqueeze(0).expand(R, S).contiguous()
+        H.check(H.lib.evk_decode_attention(H.ptr(q), H.ptr(kg), H.ptr(vg), H.ptr(causal), H.ptr(ref_i), R, S, heads, 64, 1, C.c_float(0.125),
+                                           H.stream()))
+        H.check(H.lib.evk_decode_attention_indirect(H.ptr(q), H.ptr(k), H.ptr(v), None, H.ptr(rowmap), H.ptr(lp), H.ptr(out_i), R, S, heads, 64,
+                                                    C.c_float(0.125), H.stream()))
         assert torch.equal(out_i, ref_i)
 
 
