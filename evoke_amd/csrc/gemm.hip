@@ -623,17 +623,19 @@ constexpr int SK_KC = 256, SK_TM = 128;      // SK_KC: the K granularity the lau
 template <int KC>
 __device__ __forceinline__ int sk_off(int row, int chunk) { return row * (KC * 2) + ((chunk ^ (row & 15)) << 4); }
 
-// KC = K-chunk depth (all loads of a chunk in flight at once), TN = output columns per block (16 or 32)
-template <int KC, int TN>
+// KC = K-chunk depth (all loads of a chunk in flight at once), TN = output columns per block (16 or 32), TM = rows per block
+// (128, or 64: these launches are bound by the LDS-fill bytes of ONE CU -- A panel TM x KC + B panel TN x KC at ~25 GB/s per CU,
+// gemm.hip use_big_tile() -- so for <= 256 rows half the panel on twice the CUs is faster)
+template <int KC, int TN, int TM>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmP p) {
   constexpr int CPR = KC / 8;                    // 16-byte chunks per row
-  constexpr int NA = SK_TM * CPR / 256, NB = TN * CPR / 256, NT = TN / 16;
+  constexpr int NA = TM * CPR / 256, NB = TN * CPR / 256, NT = TN / 16, MT = TM / 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* As = smem;                               // [128][KC] bf16, chunk index XOR (row & 15)
-  char* Bs = smem + SK_TM * KC * 2;              // [TN][KC]
+  char* As = smem;                               // [TM][KC] bf16, chunk index XOR (row & 15)
+  char* Bs = smem + TM * KC * 2;                 // [TN][KC]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int frow = lane & 15, fq = lane >> 4;
-  const int m0 = blockIdx.y * SK_TM, n0 = blockIdx.x * TN;
+  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
   uint4 ra[NA], rb[NB];
   auto load = [&](int k0) {
 #pragma unroll
@@ -655,11 +657,11 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmP p) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) { const int c = tid + 256 * i; *reinterpret_cast<uint4*>(Bs + sk_off<KC>(c / CPR, c % CPR)) = rb[i]; }
   };
-  f32x4 acc[NT][2];     // [n tile][m tile]; wave owns rows wave*32 .. +32
+  f32x4 acc[NT][MT];    // [n tile][m tile]; wave owns rows wave*(TM/4) .. +TM/4
 #pragma unroll
   for (int i = 0; i < NT; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   load(0);
   for (int k0 = 0; k0 < p.K; k0 += KC) {
     store();
@@ -667,22 +669,22 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmP p) {
     if (k0 + KC < p.K) load(k0 + KC);
 #pragma unroll
     for (int ks = 0; ks < KC / 32; ++ks) {
-      bf16x8 af[2], bfr[NT];
+      bf16x8 af[MT], bfr[NT];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(As + sk_off<KC>(wave * 32 + i * 16 + frow, ks * 4 + fq));
+      for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(As + sk_off<KC>(wave * (TM / 4) + i * 16 + frow, ks * 4 + fq));
 #pragma unroll
       for (int i = 0; i < NT; ++i) bfr[i] = *reinterpret_cast<const bf16x8*>(Bs + sk_off<KC>(i * 16 + frow, ks * 4 + fq));
 #pragma unroll
       for (int in = 0; in < NT; ++in)
 #pragma unroll
-        for (int im = 0; im < 2; ++im)
+        for (int im = 0; im < MT; ++im)
           acc[in][im] = EVK_MFMA_16x16x32(bfr[in], af[im], acc[in][im], 0, 0, 0);
     }
     __syncthreads();
   }
 #pragma unroll
-  for (int im = 0; im < 2; ++im) {
-    const int m = m0 + wave * 32 + im * 16 + frow;
+  for (int im = 0; im < MT; ++im) {
+    const int m = m0 + wave * (TM / 4) + im * 16 + frow;
     if (m >= p.M) continue;
 #pragma unroll
     for (int in = 0; in < NT; ++in) {
@@ -704,16 +706,16 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmP p) {
   }
 }
 
-template <int KC, int TN>
+template <int KC, int TN, int TM>
 int launch_skinny_cfg(const GemmP& p, hipStream_t s) {
-  constexpr int LDS = (SK_TM + TN) * KC * 2;
+  constexpr int LDS = (TM + TN) * KC * 2;
   static bool attr_done = false;
-  auto kern = gemm_skinny_kernel<KC, TN>;
+  auto kern = gemm_skinny_kernel<KC, TN, TM>;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_done = true;
   }
-  dim3 grid((unsigned)cdiv(p.N, TN), (unsigned)cdiv(p.M, SK_TM), 1);
+  dim3 grid((unsigned)cdiv(p.N, TN), (unsigned)cdiv(p.M, TM), 1);
   hipLaunchKernelGGL(kern, grid, dim3(NTHR), LDS, s, p);
   return evk_check_launch("gemm_skinny_kernel");
 }
@@ -722,8 +724,9 @@ int launch_skinny(const GemmP& p, hipStream_t s) {
   // <= 256 rows (relational memory, decode step): the whole K = 512 panel in flight at once and 16-column blocks (twice the
   // blocks) -- one memory round trip per 512 of K instead of two.  Larger M: 2x the LDS per block would halve the residency.
   static const int deep = [] { const char* e = getenv("EVK_SKINNY_DEEP"); return e ? atoi(e) : 1; }();
-  if (deep && p.K % 512 == 0 && p.M <= 256) return launch_skinny_cfg<512, 16>(p, s);
-  return launch_skinny_cfg<256, 32>(p, s);
+  static const int half = [] { const char* e = getenv("EVK_SKINNY_TM64"); return e ? atoi(e) : 1; }();
+  if (deep && p.K % 512 == 0 && p.M <= 256) return half ? launch_skinny_cfg<512, 16, 64>(p, s) : launch_skinny_cfg<512, 16, 128>(p, s);
+  return launch_skinny_cfg<256, 32, 128>(p, s);
 }
 
 // ------------------------------------------------------------------------------------------------
