@@ -78,7 +78,7 @@ def cpu_baseline(model, kind, res, L, Li, seconds_budget=25.0):
     ctx = O.Ctx(train=True, dropout=True)
     times = []
     t_all = time.time()
-    for it in range(4):
+    for it in range(7):            # 1 warm-up + up to 6 timed steps: ~10-15 s of CPU work, bounded by seconds_budget
         t0 = time.time()
         opt.zero_grad()
         if kind == 'finetune':
