@@ -53,8 +53,11 @@ def _build_one(lib, obj_dir, extra, verbose, force):
 
 def build(verbose=False, force=False):
     """Both libraries: bf16 storage (default) and fp16 storage (EVK_STORE=f16)."""
-    _build_one(LIB_F16, os.path.join(CSRC, 'obj_f16'), ['-DEVK_STORE_F16'], verbose, force)
-    return _build_one(LIB, OBJ, [], verbose, force)
+    with ThreadPoolExecutor(max_workers=2) as ex:       # the two libraries compile side by side (gemm.hip dominates both)
+        f16 = ex.submit(_build_one, LIB_F16, os.path.join(CSRC, 'obj_f16'), ['-DEVK_STORE_F16'], verbose, force)
+        lib = ex.submit(_build_one, LIB, OBJ, [], verbose, force)
+        f16.result()
+        return lib.result()
 
 
 if __name__ == '__main__':
