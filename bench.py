@@ -139,7 +139,7 @@ def bench_decode(a, rank, world, dev):
     print(json.dumps({
         'metric': 'decode tokens/sec (beam search, %d^2)' % a.res, 'value': toks / float(tt.item()), 'unit': 'tokens/s', 'n_gpus': world,
         'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * float(tt.item()) / a.steps, 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': os.environ.get('EVK_STORE', 'bf16').lower(), 'data': 'synthetic',
+        'vs_baseline': None, 'dtype': H.STORE, 'data': 'synthetic',
         'config': {'workload': 'EVOKE-%d inference: beam=%d, batch %d studies x %d views, max_seq_len %d (all steps run, as the reference), '
                                'incremental decoder state, visual extractor + fusion included, V=%d, random-init weights'
                                % (a.res, a.beam, B, a.views, L, V), 'parallelism': 'replicas x%d' % world,
@@ -194,7 +194,7 @@ def main():
         else:
             ret = model(batch['images'], batch['ids'], batch['masks'], batch['pids'])
         loss = ret['all_loss']
-        (loss / world).backward()
+        loss.backward()              # not pre-divided by world: all-reduce SUM, 1/world inside the optimizer kernel
         red.finish()
         opt.step()
         return loss.detach()
@@ -254,7 +254,7 @@ def main():
     out = {
         'metric': 'studies/sec (train step, 2-view %d^2)' % a.res, 'value': studies / dt, 'unit': 'studies/s', 'n_gpus': world,
         'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps, 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': os.environ.get('EVK_STORE', 'bf16').lower(), 'data': 'synthetic',
+        'vs_baseline': None, 'dtype': H.STORE, 'data': 'synthetic',
         'config': {'workload': 'EVOKE-%d two-view %s train step (fwd+bwd+allreduce+clip+RAdam), %d studies (%d images) per GPU, '
                                'L=%d, Li=%d, V=%d, random-init weights' % (a.res, kind, a.batch, a.batch * a.views, L, Li, V),
                    'parallelism': 'dp%d' % world, 'loss_last': float(losses[-1].item()),
@@ -266,13 +266,19 @@ def main():
         psteps = 1                                   # the extra, event-timed step
         alg_flops = (alg * 1e9 * a.batch * psteps) if alg else launched_flops
         ach = alg_flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        traffic = None          # HBM bytes of the family per step from the committed PMC passes of this very command
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_o_traffic.json')
-        if kind == 'finetune' and a.res == 384 and a.batch == 32 and os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get('gemm_family_hbm_bytes_per_step')
+        # HBM bytes of the family per step: rocprofv3 PMC passes of THIS command (tools/traffic_json.py), valid only while the
+        # committed file carries the fingerprint of the sources that are running; null otherwise (never a stale constant)
+        traffic, tsrc = None, None
+        from evoke_amd.build import source_fingerprint
+        for tname in sorted((f for f in os.listdir(os.path.join(REPO, 'profiles')) if f.endswith('traffic.json')), reverse=True):
+            tj = json.load(open(os.path.join(REPO, 'profiles', tname)))
+            if (tj.get('fingerprint') == source_fingerprint() and tj.get('workload') == [kind, a.res, a.batch, a.views]
+                    and tj.get('store') == H.STORE):
+                traffic, tsrc = tj.get('gemm_family_hbm_bytes_per_step'), 'profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per step)' % tname
+                break
         out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_kernel (MFMA GEMM / implicit-GEMM conv family)', 'achieved': ach,
                            'peak': MFMA_BF16_DENSE_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / MFMA_BF16_DENSE_PEAK_TFLOPS,
-                           'traffic': traffic, 'traffic_source': 'profiles/r01_o_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per step)' if traffic else None,
+                           'traffic': traffic, 'traffic_source': tsrc,
                            'launches_per_step': n / psteps, 'event_timed': '1 extra step after the timed region, single stream', 'avg_launch_us': 1e3 * ms / max(n, 1),
                            'gemm_ms_per_step': ms / psteps, 'launched_tflops': launched_flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
                            'family_ms_per_step': {k: v[0] / psteps for k, v in fam.items()}}

@@ -9,8 +9,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, 'obj')
-LIB = os.path.join(HERE, 'libevoke_hip.so')
-LIB_F16 = os.path.join(HERE, 'libevoke_hip_f16.so')      # same sources, -DEVK_STORE_F16 (fp16 storage: the parity mode)
+LIB = os.path.join(HERE, 'libevoke_hip.so')               # fp16 storage (the default: 1e-3 loss parity, dynamic loss scaling)
+LIB_BF16 = os.path.join(HERE, 'libevoke_hip_bf16.so')     # same sources, -DEVK_STORE_BF16 (EVK_STORE=bf16)
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function', '-ffp-contract=fast']
 
@@ -52,12 +52,26 @@ def _build_one(lib, obj_dir, extra, verbose, force):
 
 
 def build(verbose=False, force=False):
-    """Both libraries: bf16 storage (default) and fp16 storage (EVK_STORE=f16)."""
+    """Both libraries: fp16 storage (default) and bf16 storage (EVK_STORE=bf16)."""
     with ThreadPoolExecutor(max_workers=2) as ex:       # the two libraries compile side by side (gemm.hip dominates both)
-        f16 = ex.submit(_build_one, LIB_F16, os.path.join(CSRC, 'obj_f16'), ['-DEVK_STORE_F16'], verbose, force)
+        alt = ex.submit(_build_one, LIB_BF16, os.path.join(CSRC, 'obj_bf16'), ['-DEVK_STORE_BF16'], verbose, force)
         lib = ex.submit(_build_one, LIB, OBJ, [], verbose, force)
-        f16.result()
+        alt.result()
         return lib.result()
+
+
+def source_fingerprint():
+    """sha256 (16 hex digits) over the kernel sources, the C-ABI header and the host modules: profiles/*traffic.json is stamped
+    with it, and bench.py reports `roofline.traffic` only while the stamp matches the code that is running."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(('.hip', '.h'))]
+    files.append(os.path.join(os.path.dirname(HERE), 'include', 'evoke_hip.h'))
+    files += [os.path.join(HERE, f) for f in sorted(os.listdir(HERE)) if f.endswith('.py')]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
 
 
 if __name__ == '__main__':

@@ -199,6 +199,86 @@ __global__ __launch_bounds__(256) void optim_kernel(const OptP o) {
   }
 }
 
+// ---- dynamic loss scaling (fp16 storage): device-resident state, no host read-back ------------------------------------
+// state[0] = loss scale, [1] = consecutive good steps, [2] = non-finite gradient seen this step, [3] = skipped steps (total)
+__global__ __launch_bounds__(256) void grad_nonfinite_kernel(const float* __restrict__ g, long n, float* __restrict__ state) {
+  const long n4 = n >> 2;
+  bool bad = false;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const uint4 t = reinterpret_cast<const uint4*>(g)[i];          // exponent all ones <=> inf / NaN
+    bad |= ((t.x & 0x7f800000u) == 0x7f800000u) | ((t.y & 0x7f800000u) == 0x7f800000u) | ((t.z & 0x7f800000u) == 0x7f800000u) |
+           ((t.w & 0x7f800000u) == 0x7f800000u);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) bad |= (__float_as_uint(g[(n4 << 2) + threadIdx.x]) & 0x7f800000u) == 0x7f800000u;
+  if (__any(bad) && (threadIdx.x & 63) == 0) state[2] = 1.f;
+}
+
+__global__ void loss_scale_update_kernel(float* __restrict__ state, float growth, float backoff, int interval, float lo, float hi) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (state[2] != 0.f) {
+    state[0] = fmaxf(state[0] * backoff, lo);
+    state[1] = 0.f;
+    state[3] += 1.f;
+  } else {
+    const float good = state[1] + 1.f;
+    if (good >= (float)interval) { state[0] = fminf(state[0] * growth, hi); state[1] = 0.f; }
+    else state[1] = good;
+  }
+  state[2] = 0.f;
+}
+
+__global__ void optim_bump_kernel(int* __restrict__ steps, int count, const float* __restrict__ state) {
+  if (state && state[2] != 0.f) return;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) steps[i] += 1;
+}
+
+// optim_kernel with the step count, the loss scale and the skip decision read from device memory
+struct OptDyn { OptP o; const int* step; const float* state; float inv_world; };
+__global__ __launch_bounds__(256) void optim_dyn_kernel(const OptDyn d) {
+  if (d.state && d.state[2] != 0.f) return;            // global overflow skip: no element of any parameter moves
+  __shared__ float hp[4];
+  __shared__ int rect_on;
+  if (threadIdx.x == 0) {
+    const double step = (double)(d.step[0] + 1), beta1 = d.o.beta1, beta2 = d.o.beta2;
+    const double b1t = pow(beta1, step), b2t = pow(beta2, step);
+    hp[0] = (float)(1.0 - b1t);
+    hp[1] = (float)sqrt(1.0 - b2t);
+    hp[2] = 0.f;
+    rect_on = 0;
+    if (d.o.kind == 0) {
+      const double rho_inf = 2.0 / (1.0 - beta2) - 1.0;
+      const double rho_t = rho_inf - 2.0 * step * b2t / (1.0 - b2t);
+      rect_on = rho_t > 5.0;
+      if (rect_on) hp[2] = (float)sqrt((rho_t - 4.0) * (rho_t - 2.0) * rho_inf / ((rho_inf - 4.0) * (rho_inf - 2.0) * rho_t));
+    }
+    hp[3] = d.inv_world / (d.state ? d.state[0] : 1.f);
+  }
+  __syncthreads();
+  const OptP& o = d.o;
+  const float bc1 = hp[0], bc2_sqrt = hp[1], rect = hp[2], gscale = hp[3];
+  const int use_rect = rect_on;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < o.n; i += (long)gridDim.x * blockDim.x) {
+    float g = o.g[i] * gscale;
+    if (o.clip > 0.f) g = fminf(fmaxf(g, -o.clip), o.clip);
+    float w = o.p[i];
+    if (o.wd != 0.f) g += o.wd * w;
+    const float m = o.beta1 * o.m[i] + (1.f - o.beta1) * g;
+    const float v = o.beta2 * o.v[i] + (1.f - o.beta2) * g * g;
+    o.m[i] = m; o.v[i] = v;
+    if (o.kind == 0) {
+      const float mh = m / bc1;
+      if (use_rect) w -= o.lr * mh * rect * bc2_sqrt / (sqrtf(v) + o.eps);
+      else w -= o.lr * mh;
+    } else {
+      float vv = v;
+      if (o.vmax) { vv = fmaxf(o.vmax[i], v); o.vmax[i] = vv; }
+      w -= (o.lr / bc1) * m / (sqrtf(vv) / bc2_sqrt + o.eps);
+    }
+    o.p[i] = w;
+    if (o.shadow) o.shadow[i] = f2bf(w);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -304,6 +384,44 @@ int evk_optim_step_scaled(float* p, const float* g, float* m, float* v, float* v
   ProfScope ps(EVK_FAM_OPTIM, s);
   hipLaunchKernelGGL(optim_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, o);
   return evk_check_launch("optim_step");
+}
+
+int evk_optim_step_dyn(float* p, const float* g, float* m, float* v, float* vmax, void* shadow, int64_t n, int32_t kind, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, float clip, const int32_t* step_dev,
+                       const float* scale_state, float inv_world, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(p && g && m && v && n > 0 && step_dev && (kind == 0 || kind == 1) && inv_world > 0.f, "optim_step_dyn: bad args");
+  OptDyn d{{p, g, m, v, vmax, (bf16_t*)shadow, n, lr, beta1, beta2, eps, weight_decay, clip, 0.f, 0.f, 0.f, kind, 0, 1.f},
+           step_dev, scale_state, inv_world};
+  ProfScope ps(EVK_FAM_OPTIM, s);
+  hipLaunchKernelGGL(optim_dyn_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, d);
+  return evk_check_launch("optim_step_dyn");
+}
+
+int evk_optim_bump(int32_t* step_dev, int32_t count, const float* scale_state, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(step_dev && count > 0, "optim_bump: bad args");
+  ProfScope ps(EVK_FAM_OPTIM, s);
+  hipLaunchKernelGGL(optim_bump_kernel, dim3((int)cdiv(count, 256)), dim3(256), 0, s, step_dev, count, scale_state);
+  return evk_check_launch("optim_bump");
+}
+
+int evk_grad_nonfinite(const float* g, int64_t n, float* scale_state, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(g && n > 0 && scale_state && (reinterpret_cast<uintptr_t>(g) & 15) == 0, "grad_nonfinite: bad args");
+  ProfScope ps(EVK_FAM_OPTIM, s);
+  hipLaunchKernelGGL(grad_nonfinite_kernel, dim3(ew_blocks(n / 4 + 1)), dim3(256), 0, s, g, (long)n, scale_state);
+  return evk_check_launch("grad_nonfinite");
+}
+
+int evk_loss_scale_update(float* scale_state, float growth, float backoff, int32_t interval, float min_scale, float max_scale,
+                          evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(scale_state && growth >= 1.f && backoff > 0.f && backoff <= 1.f && interval > 0 && min_scale > 0.f && max_scale >= min_scale,
+              "loss_scale_update: bad args");
+  ProfScope ps(EVK_FAM_OPTIM, s);
+  hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(64), 0, s, scale_state, growth, backoff, interval, min_scale, max_scale);
+  return evk_check_launch("loss_scale_update");
 }
 
 }  // extern "C"

@@ -5,7 +5,8 @@ modules/trainer_v0401.py:28-29); what is built here follows SURVEY.md section 8e
   * studies shard across ranks (all views of a study stay on one rank); no collective on the forward data path
     except ONE exchange step for the contrastive negatives of Pretrain (autograd all-gather of the global image /
     text embeddings + 64-bit study-id hashes, variable rows per rank -> padded);
-  * gradient all-reduce (SUM of losses pre-scaled by 1/world == mean) on the FLAT f32 gradient buffers of
+  * gradient all-reduce (SUM; the 1/world of the mean is applied by the optimizer kernel together with the loss-scale
+    division, so the loss is NOT pre-divided and 16-bit activation gradients keep the full loss scale) on the FLAT f32 gradient buffers of
     evoke_amd.optim.FusedOptimizer: contiguous buckets, launched asynchronously from the backward as soon as every
     parameter of a bucket has its gradient (parameters are laid out in forward order, so the decoder / fusion /
     multi-view buckets reduce while the ResNet backward is still running); parameters that get no gradient in a step
@@ -56,7 +57,7 @@ def fnv1a64(s):
 class _AllGatherRows(torch.autograd.Function):
     """cat over ranks of x (rows_r, D) padded to the max row count.  Every rank then evaluates the SAME global loss on
     the gathered tensor, so d(loss)/d(x_local) is complete from the local slice alone; the backward multiplies it by
-    world so that the gradient all-reduce's mean (loss pre-scaled by 1/world) leaves the global term un-averaged."""
+    world so that the mean over ranks (all-reduce SUM, then 1/world in the optimizer) leaves the global term un-averaged."""
 
     @staticmethod
     def forward(ctx, x, counts):
@@ -131,6 +132,7 @@ class GradReducer:
         params = []
         for g, st in zip(opt.param_groups, opt.flat):
             params.append([(p, o, p.numel()) for p, o in zip(g['params'], st['offsets'])])
+        opt.world = world_size()          # the optimizer kernel divides the summed gradients by the rank count
         return cls(opt.flat_grads(), params, **kw)
 
     def begin(self, key='default'):

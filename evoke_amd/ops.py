@@ -18,26 +18,82 @@ from . import hip as H
 
 BF16, F32 = H.STORE_DTYPE, torch.float32      # BF16 = the 16-bit storage dtype of the loaded library (bf16, or fp16 under EVK_STORE=f16)
 
-# Static loss scale of the fp16-storage build (EVK_STORE=f16): FineTune / Pretrain return `all_loss` through scale_loss(), whose
-# backward multiplies the incoming gradient by LOSS_SCALE, so every 16-bit activation gradient of the step is 2^10 times
-# larger than its true value and stays in fp16's normal range; the f32 parameter gradients carry the same factor and
-# FusedOptimizer.step() divides it out before clipping (evk_optim_step_scaled).  The value of the loss is unchanged.  bf16
-# storage has fp32's exponent range and needs none (scale 1).  `p.grad` holds SCALED gradients while the scale is not 1.
-LOSS_SCALE = float(os.environ.get('EVK_LOSS_SCALE', '1024' if H.STORE == 'f16' else '1'))
+# Dynamic loss scale of the fp16-storage build (the default; EVK_STORE=bf16 has fp32's exponent range and runs with scale 1):
+# FineTune / Pretrain return `all_loss` through scale_loss(), whose backward multiplies the incoming gradient by the CURRENT
+# scale -- a device scalar, never read back by the host -- so every 16-bit activation gradient of the step stays in fp16's
+# normal range.  The f32 parameter gradients carry the same factor (`p.grad` holds SCALED gradients); FusedOptimizer.step()
+# looks for non-finite gradients after the all-reduce, skips the WHOLE step when it finds one, divides the scale out before
+# clipping otherwise, and backs the scale off / grows it (torch.cuda.amp.GradScaler's rule: x0.5 on overflow, x2 after
+# `interval` clean steps), all in device code (csrc/eltwise.hip).  The value of the loss is unchanged.
+LOSS_SCALE_INIT = float(os.environ.get('EVK_LOSS_SCALE', '1024' if H.STORE == 'f16' else '1'))
+LOSS_SCALE_DYNAMIC = H.STORE == 'f16' and os.environ.get('EVK_LOSS_SCALE_STATIC', '0') != '1'
+
+
+class LossScaler:
+    """state (device f32[4]): [0] scale, [1] consecutive good steps, [2] overflow seen this step, [3] skipped steps."""
+    GROWTH, BACKOFF, INTERVAL, MIN, MAX = 2.0, 0.5, int(os.environ.get('EVK_LOSS_SCALE_INTERVAL', '2000')), 1.0, 2.0 ** 24
+
+    def __init__(self, device):
+        self.state = torch.tensor([LOSS_SCALE_INIT, 0.0, 0.0, 0.0], dtype=torch.float32, device=device)
+
+    def check(self, flat_grad):
+        H.check(H.lib.evk_grad_nonfinite(H.ptr(flat_grad), flat_grad.numel(), H.ptr(self.state), H.stream()), 'grad_nonfinite')
+
+    def update(self):
+        if LOSS_SCALE_DYNAMIC:
+            H.check(H.lib.evk_loss_scale_update(H.ptr(self.state), self.GROWTH, self.BACKOFF, self.INTERVAL, self.MIN, self.MAX, H.stream()),
+                    'loss_scale_update')
+        else:
+            self.state[2:3].zero_()
+
+    def value(self):
+        """host read-back (synchronises): tests / checkpoints only"""
+        return float(self.state[0].item())
+
+    def skipped(self):
+        return int(self.state[3].item())
+
+
+_scalers = {}
+
+
+def loss_scaler(device=None):
+    """The per-device loss scaler, or None when the build needs none (bf16 storage with scale 1)."""
+    if LOSS_SCALE_INIT == 1.0 and not LOSS_SCALE_DYNAMIC:
+        return None
+    dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.type != 'cuda':
+        return None
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    sc = _scalers.get(key)
+    if sc is None:
+        sc = _scalers[key] = LossScaler(torch.device('cuda', key))
+    return sc
+
+
+def loss_scale_value(device=None):
+    """Current loss scale as a float (host sync; 1.0 when the build has no scaler)."""
+    sc = loss_scaler(device)
+    return sc.value() if sc is not None else 1.0
 
 
 class _ScaleGrad(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, scale):
+        ctx.save_for_backward(scale)
         return x.view_as(x)
 
     @staticmethod
     def backward(ctx, g):
-        return g * LOSS_SCALE
+        scale, = ctx.saved_tensors
+        return g * scale, None
 
 
 def scale_loss(loss):
-    return _ScaleGrad.apply(loss) if LOSS_SCALE != 1.0 and loss.requires_grad else loss
+    if not (torch.is_tensor(loss) and loss.requires_grad and loss.is_cuda):
+        return loss
+    sc = loss_scaler(loss.device)
+    return _ScaleGrad.apply(loss, sc.state[0]) if sc is not None else loss
 
 
 # ----------------------------------------------------------------------------------------------------

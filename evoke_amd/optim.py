@@ -50,7 +50,12 @@ class FusedOptimizer(torch.optim.Optimizer):
         self.steps = 0
         self.flat = []
         self._touched = set()
-        self._pstep = {}
+        # Per-parameter step counts live ON THE DEVICE (st['steps'], int32 per parameter): a step that the dynamic loss scaler
+        # skips (non-finite gradient anywhere) must not advance them and the host never reads the skip decision back.
+        # `_hist[id(p)]` is a host-side signature of the SET of optimizer steps the parameter took part in: parameters with
+        # equal signatures have equal device step counts and may share one fused launch.
+        self._hist = {}
+        self.world = 1              # ranks whose gradients the all-reduce SUMS into the flat buffers (set by GradReducer)
         ops.register_grad_callback(self._on_grad)
         for g in self.param_groups:
             ps = g['params']
@@ -73,7 +78,7 @@ class FusedOptimizer(torch.optim.Optimizer):
                 p.data = v
                 p.grad = _view_like(fg[o:o + n], p)
             st = dict(p=fp, g=fg, m=torch.zeros_like(fp), v=torch.zeros_like(fp), vmax=torch.zeros_like(fp) if self.amsgrad else None,
-                      shadow=sh, offsets=offs)
+                      shadow=sh, offsets=offs, steps=torch.zeros(len(ps), dtype=torch.int32, device=dev))
             self.flat.append(st)
             if sh is not None:
                 H.check(H.lib.evk_cast(H.ptr(fp), H.F32, H.ptr(sh), H.BF16, tot, H.stream()), 'cast')
@@ -90,8 +95,8 @@ class FusedOptimizer(torch.optim.Optimizer):
         state, groups, idx = {}, [], 0
         for g, st in zip(self.param_groups, self.flat):
             ids = []
-            for p, o in zip(g['params'], st['offsets']):
-                k = self._pstep.get(id(p), 0)
+            counts = st['steps'].cpu().tolist()          # checkpoint time: the one host read of the device step counts
+            for p, o, k in zip(g['params'], st['offsets'], counts):
                 if k > 0:
                     n = p.numel()
                     ent = {'step': torch.tensor(float(k)),
@@ -111,14 +116,15 @@ class FusedOptimizer(torch.optim.Optimizer):
     def load_state_dict(self, sd):
         if len(sd['param_groups']) != len(self.param_groups):
             raise ValueError('loaded state dict has a different number of parameter groups')
-        self._pstep = {}
+        self._hist = {}
         for g, st, lg in zip(self.param_groups, self.flat, sd['param_groups']):
+            counts = [0] * len(g['params'])
             if len(lg['params']) != len(g['params']):
                 raise ValueError("loaded state dict contains a parameter group that doesn't match the size of optimizer's group")
             for k, v in lg.items():
                 if k != 'params':
                     g[k] = v
-            for p, o, idx in zip(g['params'], st['offsets'], lg['params']):
+            for pi, (p, o, idx) in enumerate(zip(g['params'], st['offsets'], lg['params'])):
                 n = p.numel()
                 ent = sd['state'].get(idx)
                 for name, buf in (('exp_avg', st['m']), ('exp_avg_sq', st['v']), ('max_exp_avg_sq', st['vmax'])):
@@ -130,7 +136,9 @@ class FusedOptimizer(torch.optim.Optimizer):
                     else:
                         view.zero_()
                 if ent is not None:
-                    self._pstep[id(p)] = int(float(ent['step']))
+                    counts[pi] = int(float(ent['step']))
+                    self._hist[id(p)] = ('loaded', counts[pi])
+            st['steps'].copy_(torch.tensor(counts, dtype=torch.int32))
 
     def flat_grads(self):
         return [st['g'] for st in self.flat]
@@ -144,10 +152,18 @@ class FusedOptimizer(torch.optim.Optimizer):
     def step(self, closure=None):
         """torch.optim semantics: parameters that received no gradient this step are skipped (no weight decay, no
         step-count increment) -- e.g. the BERT pooler always, visual_self_atten_layers on indication batches.  Runs of
-        consecutive updated parameters with the same step count share one fused launch."""
+        consecutive updated parameters with the same step history share one fused launch.  fp16 storage: the gradients carry
+        the loss scale; a non-finite gradient anywhere (after the all-reduce, so every rank sees it) skips the whole step."""
         self.steps += 1
-        if self.flat and self.flat[0]['p'].is_cuda:
+        on_gpu = bool(self.flat) and self.flat[0]['p'].is_cuda
+        if on_gpu:
             ops.join_side_streams()
+        scaler = ops.loss_scaler(self.flat[0]['p'].device) if on_gpu else None
+        sstate = H.ptr(scaler.state) if scaler is not None else None
+        if scaler is not None:
+            for st in self.flat:
+                scaler.check(st['g'])
+        inv_world = 1.0 / float(self.world)
         for g, st in zip(self.param_groups, self.flat):
             b1, b2 = g['betas']
             ps, offs = g['params'], st['offsets']
@@ -157,21 +173,25 @@ class FusedOptimizer(torch.optim.Optimizer):
                 if id(p) not in self._touched:
                     cur = None
                     continue
-                k = self._pstep.get(id(p), 0) + 1
-                self._pstep[id(p)] = k
+                h = self._hist[id(p)] = hash((self._hist.get(id(p), 0), self.steps))
                 end = offs[i + 1] if i + 1 < len(ps) else total
-                if cur is not None and cur[2] == k and cur[1] == offs[i]:
+                if cur is not None and cur[2] == h and cur[1] == offs[i]:
                     cur[1] = end
+                    cur[4] += 1
                 else:
-                    cur = [offs[i], end, k]
+                    cur = [offs[i], end, h, i, 1]
                     runs.append(cur)
-            for a, b, k in runs:
+            for a, b, _, i0, cnt in runs:
                 es, eb = 4 * a, 2 * a
-                H.check(H.lib.evk_optim_step_scaled(st['p'].data_ptr() + es, st['g'].data_ptr() + es, st['m'].data_ptr() + es,
-                                                    st['v'].data_ptr() + es, (st['vmax'].data_ptr() + es) if st['vmax'] is not None else None,
-                                                    (st['shadow'].data_ptr() + eb) if st['shadow'] is not None else None, b - a, self.kind,
-                                                    float(g['lr']), b1, b2, g['eps'], g['weight_decay'], float(self.clip_value or 0.0), k,
-                                                    1.0 / ops.LOSS_SCALE, H.stream()), 'optim_step')
+                step_ptr = st['steps'].data_ptr() + 4 * i0
+                H.check(H.lib.evk_optim_step_dyn(st['p'].data_ptr() + es, st['g'].data_ptr() + es, st['m'].data_ptr() + es,
+                                                 st['v'].data_ptr() + es, (st['vmax'].data_ptr() + es) if st['vmax'] is not None else None,
+                                                 (st['shadow'].data_ptr() + eb) if st['shadow'] is not None else None, b - a, self.kind,
+                                                 float(g['lr']), b1, b2, g['eps'], g['weight_decay'], float(self.clip_value or 0.0), step_ptr,
+                                                 sstate, inv_world, H.stream()), 'optim_step')
+                H.check(H.lib.evk_optim_bump(step_ptr, cnt, sstate, H.stream()), 'optim_bump')
+        if scaler is not None:
+            scaler.update()
         self._touched.clear()
 
 

@@ -102,7 +102,7 @@ class Trainer:
                 self.reducer.begin(kind or 'pretrain')
             ret = self.model(images, batch[1].to(dev), batch[2].to(dev), batch[3])
         loss = ret['all_loss']
-        (loss / self.world if self.world > 1 else loss).backward()
+        loss.backward()              # never pre-divided by world: the reducer SUMS, the optimizer kernel applies 1/world
         if self.reducer is not None:
             self.reducer.finish()
         self.optimizer.step()                    # clip_grad_value_(0.1) is fused into the update kernel

@@ -75,10 +75,10 @@ typedef struct evk_gemm {
 } evk_gemm;
 
 int evk_version(void);
-/* 16-bit storage format this build of the library computes in: 0 = bf16 (libevoke_hip.so, the default and the training
- * format), 16 = IEEE fp16 (libevoke_hip_f16.so, built from the same sources with -DEVK_STORE_F16: the forward / evaluation
- * parity mode).  "bf16" in the comments of this header means "the library's 16-bit storage format".  The reference has no
- * counterpart: it computes in fp32 (torch CPU / CUDA default dtype). */
+/* 16-bit storage format this build of the library computes in: 16 = IEEE fp16 (libevoke_hip.so, the default: meets the
+ * 1e-3 loss parity, trains under the dynamic loss scale below), 0 = bf16 (libevoke_hip_bf16.so, built from the same sources
+ * with -DEVK_STORE_BF16).  "bf16" in the comments of this header means "the library's 16-bit storage format".  The reference
+ * has no counterpart: it computes in fp32 (torch CPU / CUDA default dtype). */
 int evk_storage_format(void);
 const char* evk_last_error(void);
 
@@ -277,6 +277,28 @@ int evk_optim_step(float* p, const float* g, float* m, float* v, float* vmax, vo
  * not finite are skipped for the step. */
 int evk_optim_step_scaled(float* p, const float* g, float* m, float* v, float* vmax, void* shadow, int64_t n, int32_t kind, float lr,
                           float beta1, float beta2, float eps, float weight_decay, float clip, int64_t step, float grad_scale,
+                          evk_stream_t stream);
+
+/* Dynamic loss scaling with a GLOBAL overflow skip, entirely on the device (no host read-back, HIP-graph capturable).  The
+ * reference trains in fp32 (modules/trainer_v0401.py:256-263, 426-435) and has none; torch.cuda.amp.GradScaler is the public
+ * counterpart (growth 2, backoff 0.5).  scale_state = float[4] in device memory: [0] loss scale, [1] consecutive good steps,
+ * [2] "a non-finite gradient was seen this step", [3] total skipped steps.
+ *   evk_grad_nonfinite     sets state[2] when any element of the flat f32 gradient buffer is inf / NaN (run it AFTER the
+ *                          gradient all-reduce: a sum carries every rank's inf / NaN, so all ranks take the same decision);
+ *   evk_optim_step_dyn     evk_optim_step with (a) the step count read from *step_dev (+1), (b) gradients multiplied by
+ *                          inv_world / state[0] (inv_world = 1 / ranks: the all-reduce sums, the loss is NOT pre-divided, so
+ *                          16-bit activation gradients keep the full loss scale on every rank), (c) no update at all when
+ *                          state[2] is set.  scale_state may be NULL (bf16 storage: scale 1, never skips);
+ *   evk_optim_bump         step_dev[0..count) += 1 unless state[2] is set (per-parameter step counts live on the device so
+ *                          that a skipped step does not advance them, as GradScaler.step skips optimizer.step);
+ *   evk_loss_scale_update  after the optimizer: overflow -> scale *= backoff (>= min_scale), good steps = 0, skipped += 1;
+ *                          else good steps += 1 and scale *= growth (<= max_scale) every `interval` good steps; clears [2]. */
+int evk_optim_step_dyn(float* p, const float* g, float* m, float* v, float* vmax, void* shadow, int64_t n, int32_t kind, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, float clip, const int32_t* step_dev,
+                       const float* scale_state, float inv_world, evk_stream_t stream);
+int evk_optim_bump(int32_t* step_dev, int32_t count, const float* scale_state, evk_stream_t stream);
+int evk_grad_nonfinite(const float* g, int64_t n, float* scale_state, evk_stream_t stream);
+int evk_loss_scale_update(float* scale_state, float growth, float backoff, int32_t interval, float min_scale, float max_scale,
                           evk_stream_t stream);
 
 /* ---- relational memory runner (rm.hip): RelationalMemory.forward / forward_step, encoder_decoder.py:274-300 ------

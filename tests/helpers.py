@@ -4,10 +4,10 @@ import os
 import numpy as np
 import torch
 
-# 16-bit storage dtype of the library under test: bf16 (default build) or fp16 (EVK_STORE=f16, evoke_amd/hip.py)
-F16_BUILD = os.environ.get('EVK_STORE', 'bf16').lower() == 'f16'
+# 16-bit storage dtype of the library under test: fp16 (the default build) or bf16 (EVK_STORE=bf16, evoke_amd/hip.py)
+F16_BUILD = os.environ.get('EVK_STORE', 'f16').lower() == 'f16'
 STORE_DTYPE = torch.float16 if F16_BUILD else torch.bfloat16
-# the fp16-storage build scales the LOSS (ops.LOSS_SCALE) inside FineTune / Pretrain; a unit test that back-propagates an
+# the fp16-storage build scales the LOSS (ops.LossScaler) inside FineTune / Pretrain; a unit test that back-propagates an
 # unscaled loss through single kernels sees gradients of ~1e-7 in fp16's subnormal range, so such legs run in bf16 only
 NO_F16_GRADS = 'fp16-storage build: this unit-level backward is not loss-scaled (gradients ~1e-7 underflow); checked in the bf16 build'
 

@@ -14,12 +14,12 @@ def _declared():
 
 
 def test_library_exports_every_declared_symbol():
-    """Both builds of the sources: bf16 storage (the default) and fp16 storage (EVK_STORE=f16, the parity mode)."""
+    """Both builds of the sources: fp16 storage (the default) and bf16 storage (EVK_STORE=bf16)."""
     from evoke_amd import build
     path = build.build()
     names = _declared()
     assert len(names) >= 10
-    for lib_path, fmt in ((path, 0), (build.LIB_F16, 16)):
+    for lib_path, fmt in ((path, 16), (build.LIB_BF16, 0)):
         lib = ctypes.CDLL(lib_path)
         missing = [n for n in names if not hasattr(lib, n)]
         assert not missing, (lib_path, missing)

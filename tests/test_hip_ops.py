@@ -231,35 +231,36 @@ def test_dropout_statistics_and_backward():
     assert float(z.float().min()) == 2.0 and float(z.float().max()) == 4.0
 
 
-@pytest.mark.skipif(F16_BUILD, reason=NO_F16_GRADS)
 def test_contrastive_losses_match_oracle():
     from evoke_amd import losses
+    from evoke_amd import ops
     from oracle import functional as O
+    sc = ops.loss_scale_value()          # fp16 storage: back-propagate under the model-level loss scale, compare grad / scale
     pid = np.array(['a', 'b', 'c', 'a', 'c', 'a'])
     g = rnd(6, 2048, seed=1)
     gd = g.cuda().requires_grad_(True)
     gr = g.clone().requires_grad_(True)
     l, lr_ = losses.multi_pos_contra_images(gd, pid, 0.5), O.multi_pos_contra_images(gr, pid, 0.5)
-    l.backward(); lr_.backward()
+    ops.scale_loss(l).backward(); lr_.backward()
     assert abs(l.item() - lr_.item()) < 2e-5, (l.item(), lr_.item())
-    close(gd.grad, gr.grad, 2e-3, 1e-6, 'multi_pos grad')
+    close(gd.grad / sc, gr.grad, 2e-3, 1e-6, 'multi_pos grad')
     assert tuple(losses.multi_pos_contra_images(gd, np.array(list('abcdef')), 0.5).shape) == (1,)
     v, t = rnd(3, 2048, seed=2), rnd(3, 2048, seed=3)
     vd, td = v.cuda().requires_grad_(True), t.cuda().requires_grad_(True)
     vr, tr = v.clone().requires_grad_(True), t.clone().requires_grad_(True)
     l, lr_ = losses.global_alignment(vd, td, pid, 0.5), O.global_alignment_loss(vr, tr, pid, 0.5)
-    l.backward(); lr_.backward()
+    ops.scale_loss(l).backward(); lr_.backward()
     assert abs(l.item() - lr_.item()) < 2e-5, (l.item(), lr_.item())
-    close(vd.grad, vr.grad, 2e-3, 1e-6, 'global grad v')
-    close(td.grad, tr.grad, 2e-3, 1e-6, 'global grad t')
+    close(vd.grad / sc, vr.grad, 2e-3, 1e-6, 'global grad v')
+    close(td.grad / sc, tr.grad, 2e-3, 1e-6, 'global grad t')
     p, tk = rnd(3, 49, 2048, seed=4), rnd(3, 9, 2048, seed=5)
     pd, tkd = p.cuda().requires_grad_(True), tk.cuda().requires_grad_(True)
     pr, tkr = p.clone().requires_grad_(True), tk.clone().requires_grad_(True)
     l, lr_ = losses.local_text_token_alignment(pd, tkd, 0.5), O.local_text_token_alignment_loss(pr, tkr, 0.5)
-    l.backward(); lr_.backward()
+    ops.scale_loss(l).backward(); lr_.backward()
     assert abs(l.item() - lr_.item()) < 2e-5, (l.item(), lr_.item())
-    close(pd.grad, pr.grad, 5e-3, 1e-7, 'local grad p')
-    close(tkd.grad, tkr.grad, 5e-3, 1e-7, 'local grad t')
+    close(pd.grad / sc, pr.grad, 5e-3, 1e-7, 'local grad p')
+    close(tkd.grad / sc, tkr.grad, 5e-3, 1e-7, 'local grad t')
 
 
 def test_relational_memory_step_matches_oracle():

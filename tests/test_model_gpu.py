@@ -1,19 +1,19 @@
 """GPU parity of the HIP engine's FineTune / Pretrain forward+backward against the golden fixtures that were
 produced by the IMPORTED REFERENCE (tests/golden/make_golden.py): same procedural weights (by state_dict key),
-same hashed inputs.  The engine computes with bf16 operands / bf16 activation storage / f32 accumulation, the
-reference in fp32; tolerances (measured values in DESIGN.md "Parity"):
+same hashed inputs.  The engine computes with 16-bit operands / 16-bit activation storage / f32 accumulation, the
+reference in fp32.  Tolerances of the DEFAULT build (fp16 storage, dynamic loss scale; measured values in DESIGN.md "Parity"):
 
-  eval mode (BN running statistics; errors do not amplify):
-     loss        |d| <= 5e-3        (measured 2.5e-4 .. 3.5e-3 on the synthetic random-weight cases)
-     activations reduced taps (sum, sum of squares, 61 samples / rms) <= 8e-2
-     gradients   energy (sum of squares) within 40 % and cosine of the 61-sample vector >= 0.5: a bf16 forward flips
-                 ~1 % of the ReLU gates per layer, so deep-network gradients are not point-wise reproducible
-  train mode (BN batch statistics): on RANDOM weights the 101-layer trunk amplifies the bf16 rounding of its
-     activations ~linearly in depth (0.85 relative at layer4 for ANY bf16-storage implementation, see
-     oracle/bf16_emulation.py), so activations / gradients cannot be compared with the fp32 reference point-wise:
-     loss        |d| <= 6e-2 vs the reference (the loss is insensitive; measured 1e-2 .. 4e-2)
-     trunk       HIP vs the CPU emulation of the same bf16 storage points: relative error <= 6e-2 at layer4
-     BN running statistics vs the reference <= 8e-2
+  eval mode (BN running statistics):
+     loss        |d| <= 1e-3        the north star's figure (measured 1.2e-4 .. 4.7e-4 on the golden cases)
+     activations reduced taps (sum, sum of squares, 61 samples / rms) <= 2e-2   (measured <= 7e-3)
+     gradients   energy (sum of squares) within 10 % and cosine of the 61-sample vector >= 0.95 (measured <= 6.6e-2, >= 0.979):
+                 a 16-bit forward flips a few ReLU gates per layer, so deep-network gradients are not point-wise reproducible
+  train mode (BN batch statistics):
+     loss        |d| <= 2e-3        (measured 8e-5 .. 4.4e-4)
+     BN running statistics vs the reference <= 2e-2
+The bf16-storage build of the same kernels (EVK_STORE=bf16) is run by the last test in a child interpreter with ITS tolerances:
+loss 5e-3 eval / 6e-2 train (bf16's 8-bit mantissa: a bias of the storage chain, amplified ~linearly in depth by train-mode BN on
+random weights, see oracle/bf16_emulation.py), activations 8e-2, gradients 40 % / 0.5.
 """
 import os
 
@@ -26,15 +26,12 @@ from tests.helpers import ARGS, GOLDEN, V, load_procedural, load_tokenizer
 
 pytestmark = pytest.mark.gpu
 
-# EVK_STORE=f16 (fp16 storage build of the same kernels): the north star's 1e-3 on the eval-mode loss.  Its backward runs under
-# the static loss scale ops.LOSS_SCALE (parameter gradients carry the factor until the optimizer divides it out).
-F16 = os.environ.get('EVK_STORE', 'bf16').lower() == 'f16'
+F16 = os.environ.get('EVK_STORE', 'f16').lower() == 'f16'      # the default build
 LOSS_TOL = 1e-3 if F16 else 5e-3
-LOSS_TOL_TRAIN = 2e-3 if F16 else 6e-2      # train-mode BN amplifies the storage rounding: fp16 storage measures <= 4.4e-4
-ACT_TOL = 8e-2
-GRAD_TOL = 0.4
-GRAD_COS = 0.5
-
+LOSS_TOL_TRAIN = 2e-3 if F16 else 6e-2
+ACT_TOL = 2e-2 if F16 else 8e-2
+GRAD_TOL = 0.10 if F16 else 0.4
+GRAD_COS = 0.95 if F16 else 0.5
 
 def _gold(name):
     return np.load(os.path.join(GOLDEN, name + '.npz'))
@@ -97,7 +94,7 @@ def test_finetune_matches_reference(name):
             for k in gold.files:
                 if k.startswith('eval/grad/'):
                     g = prm[k[len('eval/grad/'):]].grad
-                    if g is None or not _report_grad(k[10:], g / ops.LOSS_SCALE, gold[k]):
+                    if g is None or not _report_grad(k[10:], g / ops.loss_scale_value(), gold[k]):
                         bad.append(k)
         else:
             assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
@@ -146,7 +143,7 @@ def test_pretrain_matches_reference(name):
             for k in gold.files:
                 if k.startswith('eval/grad/'):
                     g = prm[k[len('eval/grad/'):]].grad
-                    if g is None or not _report_grad(k[10:], g / ops.LOSS_SCALE, gold[k]):
+                    if g is None or not _report_grad(k[10:], g / ops.loss_scale_value(), gold[k]):
                         bad.append(k)
         else:
             assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
@@ -180,9 +177,9 @@ def test_trunk_follows_bf16_emulation(train):
 
 @pytest.mark.parametrize('name', [n for n, c in CASES.items() if c['kind'] == 'beam'])
 def test_beam_search_matches_reference(name):
-    """Incremental device-side beam search vs the reference's full re-decode: token ids are compared exactly where the
-    two are numerically separable; a bf16 logit can flip a near-tie, so the assertion is on the score of the returned
-    beam (re-scored by the fp32 oracle) instead of demanding identical ids on every sample."""
+    """Incremental device-side beam search vs the reference's full re-decode.  Default (fp16-storage) build: the token ids
+    must be IDENTICAL to the reference's on every sample.  bf16-storage build only: a bf16 logit can flip a near-tie, so
+    there the assertion falls back to the score of the returned beam (re-scored by the fp32 oracle)."""
     from evoke_amd import ops
     from evoke_amd.model_pretrain_finetune import FineTune
     from oracle import beam as OB, functional as O, spec as S
@@ -204,6 +201,8 @@ def test_beam_search_matches_reference(name):
     print('   ref', want.tolist())
     assert seq.shape == want.shape and seq.dtype == torch.long
     assert texts == tok.decode_batch(seq.tolist()) or all(len(t) > 0 for t in texts)
+    if F16:
+        assert torch.equal(seq, want), 'beam search token ids differ from the reference'
     if not bool(same.all()):
         # score both sequences with the fp32 oracle (teacher forced): the engine's choice must be within bf16 noise of the reference's
         P = S.procedural_state(S.finetune_spec(V))
@@ -255,12 +254,12 @@ def test_distilgpt2_backend_matches_hf_fixture():
         bad.append('loss')
     if not _report('logits', lg[..., :V], gold['eval/tap/logits'], ACT_TOL):
         bad.append('logits')
-    loss.backward()
+    ops.scale_loss(loss).backward()          # the decoder is called directly here: apply the model-level loss scale by hand
     prm = dict(dec.named_parameters())
     for k in gold.files:
         if k.startswith('eval/grad/'):
             g = prm['decoder.encoder_decoder.decoder.' + k[len('eval/grad/'):]].grad
-            if g is None or not _report_grad(k[10:], g, gold[k]):
+            if g is None or not _report_grad(k[10:], g / ops.loss_scale_value(), gold[k]):
                 bad.append(k)
     with torch.no_grad():
         seq = dec(enc, None, stage='test').cpu()
@@ -270,6 +269,8 @@ def test_distilgpt2_backend_matches_hf_fixture():
     agree = sum(int(a.tolist() == b.tolist()) for a, b in zip(seq, want)) if seq.shape == want.shape else 0
     print('   identical sequences %d / %d' % (agree, len(want)))
     assert seq.dtype == torch.long and seq.shape[0] == 3 and bool((seq[:, 0] == V - 2).all())
+    if F16:
+        assert seq.shape == want.shape and torch.equal(seq, want), 'distilgpt2 beam generate differs from the HF fixture'
     ops.set_dropout_enabled(True)
     assert not bad, bad
 
@@ -366,14 +367,11 @@ def test_edge_geometries_match_oracle(name):
     assert np.isfinite(hip) and abs(hip - ref) <= LOSS_TOL, (hip, ref)
 
 
-@pytest.mark.skipif(F16, reason='already running in the fp16-storage build')
-def test_f16_storage_build_passes_the_gpu_suite_with_1e3_loss_parity():
-    """The fp16-storage build of the same kernels (EVK_STORE=f16 -> libevoke_hip_f16.so): the WHOLE GPU suite again in a
-    child interpreter (the storage format is fixed per process) -- every kernel family against its reference in fp16
-    storage, and the model against the reference's golden vectors with LOSS_TOL = 1e-3, the north star's figure (measured
-    1.2e-4 .. 4.7e-4 on the golden FineTune cases, <= 1e-5 on the Pretrain losses, 2.2e-4 at the realistic token count; beam
-    search token-exact), train-mode losses within 2e-3 (measured <= 4.4e-4; bf16: 6e-2), reduced gradients against the golden ones
-    under the static loss scale.  Only the unscaled unit-level contrastive-gradient check is skipped there (tests/helpers.py)."""
+@pytest.mark.skipif(not F16, reason='already running in the bf16-storage build')
+def test_bf16_storage_build_passes_the_gpu_suite():
+    """The bf16-storage build of the same kernels (EVK_STORE=bf16 -> libevoke_hip_bf16.so): the WHOLE GPU suite again in a child
+    interpreter (the storage format is fixed per process) with that build's tolerances (module docstring) -- every kernel family
+    against its reference in bf16 storage, unscaled gradients (the unit-level contrastive-gradient check runs only there)."""
     import gc
     import subprocess
     import sys
@@ -382,11 +380,10 @@ def test_f16_storage_build_passes_the_gpu_suite_with_1e3_loss_parity():
         del v[:]
     gc.collect()
     torch.cuda.empty_cache()
-    env = dict(os.environ, EVK_STORE='f16')
+    env = dict(os.environ, EVK_STORE='bf16')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests'), '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider',
-                        '--ignore', os.path.join(root, 'tests', 'test_distributed_gpu.py'), '--durations', '8'],
-                       env=env, capture_output=True, text=True, timeout=1500, cwd=root)
+                        '--durations', '8'], env=env, capture_output=True, text=True, timeout=1500, cwd=root)
     tail = '\n'.join((r.stdout + r.stderr).splitlines()[-30:])
     print(tail)
     assert r.returncode == 0, tail

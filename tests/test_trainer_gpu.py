@@ -44,7 +44,7 @@ def test_fused_optimizer_state_dict_round_trip(kind):
     def fstep(opt, ps, gs):
         opt.zero_grad()
         for p, g in zip(ps, gs):
-            ops.grad_buffer(p).add_(g.cuda() * ops.LOSS_SCALE)      # gradient buffers carry the loss scale (1 in the bf16 build)
+            ops.grad_buffer(p).add_(g.cuda() * ops.loss_scale_value())      # gradient buffers carry the loss scale (1 in the bf16 build)
             ops.grad_done(p)
         opt.step()
 
@@ -112,4 +112,85 @@ def test_trainer_finetune_steps_and_resume(tmp_path):
     log2b = tr2.train_epoch_finetune(None, batches(False, 2), epoch=2)
     # same weights + optimizer state + inputs (dropout 0): the resumed epoch reproduces the original one
     assert abs(log2b['train_loss'] - log2['train_loss']) <= 2e-2 * abs(log2['train_loss']), (log2b, log2)
+    ops.clear_grad_callbacks()
+
+
+def test_dynamic_loss_scale_skips_the_whole_step_on_overflow():
+    """Device-side dynamic loss scaling (csrc/eltwise.hip: evk_grad_nonfinite / evk_optim_step_dyn / evk_optim_bump /
+    evk_loss_scale_update) driven through the C ABI: a non-finite element anywhere in the flat gradient skips EVERY parameter of
+    the step, leaves the per-parameter step counts alone and halves the scale; clean steps follow torch.optim.RAdam fed the
+    unscaled, world-averaged gradients, and the scale doubles after `interval` clean steps."""
+    from evoke_amd import hip as H
+    n, world, scale0, interval = 4096, 4, 512.0, 3
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.randn(n, generator=g)
+    grads = [torch.randn(n, generator=g) * 0.05 for _ in range(6)]
+    ref = nn.Parameter(p0.clone().cuda())
+    ropt = torch.optim.RAdam([ref], lr=5e-3, weight_decay=1e-4)
+    p, m, v = p0.clone().cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    steps = torch.zeros(2, dtype=torch.int32).cuda()          # two "parameters" sharing the launch
+    state = torch.tensor([scale0, 0.0, 0.0, 0.0]).cuda()
+    scales, skipped_at = [], (1, 4)
+    for i, gr in enumerate(grads):
+        cur = float(state[0])
+        summed = (gr * world * cur).cuda()                     # what the all-reduce SUM of `world` scaled shard gradients holds
+        if i in skipped_at:
+            summed[n // 2] = float('inf') if i == 1 else float('nan')
+        before = p.clone()
+        H.check(H.lib.evk_grad_nonfinite(H.ptr(summed), n, H.ptr(state), H.stream()))
+        H.check(H.lib.evk_optim_step_dyn(H.ptr(p), H.ptr(summed), H.ptr(m), H.ptr(v), None, None, n, 0, 5e-3, 0.9, 0.999, 1e-8, 1e-4, 0.1,
+                                         H.ptr(steps), H.ptr(state), 1.0 / world, H.stream()))
+        H.check(H.lib.evk_optim_bump(H.ptr(steps), 2, H.ptr(state), H.stream()))
+        H.check(H.lib.evk_loss_scale_update(H.ptr(state), 2.0, 0.5, interval, 1.0, 65536.0, H.stream()))
+        if i in skipped_at:
+            assert torch.equal(p, before), 'a skipped step moved parameters'
+        else:
+            ref.grad = gr.cuda().clamp(-0.1, 0.1)
+            ropt.step()
+        scales.append(float(state[0]))
+    assert steps.tolist() == [4, 4] and float(state[3]) == 2.0 and float(state[2]) == 0.0
+    # 512 -> ok 512 -> inf 256 -> ok, ok (2 good) -> nan 128 -> ok (1 good)
+    assert scales == [512.0, 256.0, 256.0, 256.0, 128.0, 128.0], scales
+    assert torch.allclose(p, ref.detach(), rtol=2e-5, atol=2e-6)
+    # growth: `interval` clean steps double the scale
+    for _ in range(interval):
+        H.check(H.lib.evk_loss_scale_update(H.ptr(state), 2.0, 0.5, interval, 1.0, 65536.0, H.stream()))
+    assert float(state[0]) == 256.0, float(state[0])
+
+
+def test_fused_optimizer_overflow_skip_keeps_the_torch_trajectory():
+    """FusedOptimizer.step() with an overflowed gradient in ONE parameter: no parameter of any group moves, state_dict step counts
+    do not advance, and the following clean steps continue on torch.optim.RAdam's trajectory (fp16-storage build only: the
+    bf16 build has no scaler)."""
+    from evoke_amd import ops, optim
+    if ops.loss_scaler() is None:
+        pytest.skip('bf16-storage build: no loss scaler')
+    init = _params(3)
+    grads = [[torch.randn(*q.shape, generator=torch.Generator().manual_seed(31 * s + i)) * 0.05 for i, q in enumerate(init)] for s in range(3)]
+    ref = [nn.Parameter(q.clone().cuda()) for q in init]
+    ropt = torch.optim.RAdam(ref, lr=5e-3)
+    mine = [nn.Parameter(q.clone().cuda()) for q in init]
+    fo = optim.FusedOptimizer([(5e-3, [('p%d' % i, q) for i, q in enumerate(mine)])], kind='RAdam', clip_value=0.1)
+    sc0 = ops.loss_scale_value()
+    for s in range(3):
+        for attempt in range(2 if s == 1 else 1):                # step 1 is first tried with an overflow, then repeated clean
+            fo.zero_grad()
+            for i, (q, gq) in enumerate(zip(mine, grads[s])):
+                gsc = gq.cuda() * ops.loss_scale_value()
+                if s == 1 and attempt == 0 and i == 2:
+                    gsc.view(-1)[5] = float('inf')
+                ops.grad_buffer(q).add_(gsc)
+                ops.grad_done(q)
+            before = [q.detach().clone() for q in mine]
+            fo.step()
+            if s == 1 and attempt == 0:
+                assert all(torch.equal(a, b.detach()) for a, b in zip(before, mine))
+                assert ops.loss_scale_value() == sc0 * 0.5
+        for q, gq in zip(ref, grads[s]):
+            q.grad = gq.cuda().clamp(-0.1, 0.1)
+        ropt.step()
+    assert [int(e['step']) for e in fo.state_dict()['state'].values()] == [3, 3, 3, 3]
+    for a, b in zip(mine, ref):
+        assert torch.allclose(a.detach().cpu(), b.detach().cpu(), rtol=2e-5, atol=2e-6)
+    ops.loss_scaler().state.copy_(torch.tensor([sc0, 0.0, 0.0, 0.0]))          # leave the process-wide scaler as found
     ops.clear_grad_callbacks()

@@ -1,8 +1,12 @@
 """profiles/*_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --steps 1 --warmup 1 --no-prof
---no-cpu-baseline`: usage traffic_json.py fetch.csv write.csv steps > out.json  (FETCH doubled on gfx950, KB -> bytes)."""
+--no-cpu-baseline`: usage traffic_json.py fetch.csv write.csv steps > out.json  (FETCH doubled on gfx950, KB -> bytes).
+The file is stamped with evoke_amd.build.source_fingerprint(): bench.py reports it as `roofline.traffic` only while it matches."""
 import json
+import os
 import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from traffic_agg import load
+from evoke_amd.build import source_fingerprint
 
 fe, cnt = load(sys.argv[1], 2.0)
 wr, _ = load(sys.argv[2], 1.0)
@@ -10,6 +14,7 @@ steps = float(sys.argv[3])
 fam = lambda n: n.startswith('void gemm_') or n.startswith('splitk_reduce')
 names = sorted(set(fe) | set(wr), key=lambda n: -(fe.get(n, 0) + wr.get(n, 0)))
 out = {
+    'fingerprint': source_fingerprint(), 'workload': ['finetune', 384, 32, 2], 'store': os.environ.get('EVK_STORE', 'f16').lower(),
     'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), python bench.py --steps 1 --warmup 1 '
               '--no-prof --no-cpu-baseline (finetune 384^2, 32 studies); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies '
               '128-B requests at 64 B); KB -> bytes x1024; divided by the %g steps of the run (includes one-off initialisation)' % steps,

@@ -28,5 +28,5 @@ for it in range(steps):
     opt.step()
     if it % 10 == 0 or it == steps - 1:
         out.append((it, float(ret['all_loss'])))
-print('store=%s loss_scale=%g  ' % (H.STORE, ops.LOSS_SCALE) + '  '.join('%d:%.4f' % t for t in out))
+print('store=%s loss_scale=%g  ' % (H.STORE, ops.loss_scale_value()) + '  '.join('%d:%.4f' % t for t in out))
 assert all(x == x for _, x in out) and out[-1][1] < out[0][1], 'loss did not decrease'
