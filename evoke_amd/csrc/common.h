@@ -34,6 +34,14 @@ __device__ __forceinline__ float hi_bf(uint32_t v) { return __uint_as_float(v & 
 #endif
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
 
+// Dropout seeds are kernel arguments, i.e. frozen when a launch sequence is captured in a HIP graph.  Every seeded kernel adds
+// the device-resident "seed epoch" (evk_set_seed_epoch: one uint64 the host advances once per training step, by a device op
+// that is part of the captured step) so that a replayed graph draws fresh masks while forward and backward of ONE step agree.
+const unsigned long long* evk_seed_epoch_ptr();
+__device__ __forceinline__ unsigned long long evk_mix_seed(unsigned long long seed, const unsigned long long* epoch) {
+  return epoch ? seed + epoch[0] * 0xD6E8FEB86659FD93ULL : seed;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -60,7 +60,9 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const bf16_t* __restrict__
 }
 
 __global__ __launch_bounds__(256) void dropout_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ resid,
-                                                      bf16_t* __restrict__ y, long n, float p, unsigned long long seed) {
+                                                      bf16_t* __restrict__ y, long n, float p, unsigned long long seed0,
+                                                      const unsigned long long* __restrict__ epoch) {
+  const unsigned long long seed = evk_mix_seed(seed0, epoch);
   const float sc = 1.f / (1.f - p);
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const bool keep = (hash32(seed * 0x9E3779B97F4A7C15ULL + (uint64_t)i) >> 8) * (1.f / 16777216.f) >= p;
@@ -311,7 +313,7 @@ int evk_dropout(const void* x, const void* resid, void* y, int64_t n, float p, u
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   EVK_REQUIRE(x && y && n > 0 && p >= 0.f && p < 1.f, "dropout: bad args");
   ProfScope ps(EVK_FAM_ELTWISE, s);
-  hipLaunchKernelGGL(dropout_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)resid, (bf16_t*)y, (long)n, p, (unsigned long long)seed);
+  hipLaunchKernelGGL(dropout_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)resid, (bf16_t*)y, (long)n, p, (unsigned long long)seed, evk_seed_epoch_ptr());
   return evk_check_launch("dropout");
 }
 

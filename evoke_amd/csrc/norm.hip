@@ -195,7 +195,7 @@ struct SmP {
   const float* s; void* p_out; void* pd_out;   // P (pre-dropout) and P' (post-dropout, may alias when p_drop == 0)
   const unsigned char* mask;                   // 1 = keep; index = zo*mBo + q*mQ + col (mQ = 0 for key masks)
   long rows; int Tq, S, ld_in, ld_out, heads; long mBo; int mQ; int causal;
-  float p_drop; unsigned long long seed; int p_f32;
+  float p_drop; unsigned long long seed; int p_f32; const unsigned long long* epoch;
 };
 constexpr int SMC = 16;  // columns per lane -> S <= 1024
 
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const SmP p) {
       const long o = row * p.ld_out + col;
       if (p.p_f32) reinterpret_cast<float*>(p.p_out)[o] = pr; else reinterpret_cast<bf16_t*>(p.p_out)[o] = f2bf(pr);
       if (p.p_drop > 0.f) {
-        const float pd = keep_elem(p.seed, (uint64_t)o, p.p_drop) ? pr * sc : 0.f;
+        const float pd = keep_elem(evk_mix_seed(p.seed, p.epoch), (uint64_t)o, p.p_drop) ? pr * sc : 0.f;
         if (p.p_f32) reinterpret_cast<float*>(p.pd_out)[o] = pd; else reinterpret_cast<bf16_t*>(p.pd_out)[o] = f2bf(pd);
       }
     }
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const SmP p) {
 
 struct SmBP {
   const void* dp; const void* pr; void* ds;  // dP' (f32 or bf16), P (pre-dropout), dS out (same dtype as P)
-  long rows; int S, ld_dp, ld, dp_f32; float p_drop; unsigned long long seed; float alpha; int p_f32;
+  long rows; int S, ld_dp, ld, dp_f32; float p_drop; unsigned long long seed; float alpha; int p_f32; const unsigned long long* epoch;
 };
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const SmBP p) {
   const int lane = threadIdx.x & 63;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const SmBP p) {
     if (col < p.S) {
       float g = p.dp_f32 ? reinterpret_cast<const float*>(p.dp)[row * p.ld_dp + col]
                          : bf2f(reinterpret_cast<const bf16_t*>(p.dp)[row * p.ld_dp + col]);
-      if (p.p_drop > 0.f) g = keep_elem(p.seed, (uint64_t)row * p.ld + col, p.p_drop) ? g * sc : 0.f;
+      if (p.p_drop > 0.f) g = keep_elem(evk_mix_seed(p.seed, p.epoch), (uint64_t)row * p.ld + col, p.p_drop) ? g * sc : 0.f;
       pv[c] = p.p_f32 ? reinterpret_cast<const float*>(p.pr)[row * p.ld + col] : bf2f(reinterpret_cast<const bf16_t*>(p.pr)[row * p.ld + col]);
       d[c] = g;
       dot += g * pv[c];
@@ -561,7 +561,7 @@ int evk_softmax_fwd(const float* scores, void* p_out, void* pdrop_out, int p_dty
   EVK_REQUIRE(S <= ld_in && S <= ld_out && ld_out <= 64 * SMC, "softmax_fwd: S=%d ld_out=%d (max %d)", S, ld_out, 64 * SMC);
   EVK_REQUIRE(p_drop == 0.f || pdrop_out, "softmax_fwd: dropout needs a second output");
   SmP p{scores, p_out, pdrop_out ? pdrop_out : p_out, mask, batch * heads * Tq, Tq, S, ld_in, ld_out, heads, mask_batch_stride,
-        mask_q_stride, causal, p_drop, seed, p_dtype == EVK_F32};
+        mask_q_stride, causal, p_drop, seed, p_dtype == EVK_F32, evk_seed_epoch_ptr()};
   ProfScope ps(EVK_FAM_NORM, s);
   hipLaunchKernelGGL(softmax_fwd_kernel, dim3(row_blocks(p.rows)), dim3(256), 0, s, p);
   return evk_check_launch("softmax_fwd");
@@ -571,7 +571,7 @@ int evk_softmax_bwd(const void* dp, int dp_dtype, int32_t ld_dp, const void* pro
                     float alpha, float p_drop, uint64_t seed, evk_stream_t stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   EVK_REQUIRE(dp && probs && ds && rows > 0 && S > 0 && S <= ld && ld <= 64 * SMC && S <= ld_dp, "softmax_bwd: bad args");
-  SmBP p{dp, probs, ds, rows, S, ld_dp, ld, dp_dtype == EVK_F32, p_drop, seed, alpha, p_dtype == EVK_F32};
+  SmBP p{dp, probs, ds, rows, S, ld_dp, ld, dp_dtype == EVK_F32, p_drop, seed, alpha, p_dtype == EVK_F32, evk_seed_epoch_ptr()};
   ProfScope ps(EVK_FAM_NORM, s);
   hipLaunchKernelGGL(softmax_bwd_kernel, dim3(row_blocks(rows)), dim3(256), 0, s, p);
   return evk_check_launch("softmax_bwd");

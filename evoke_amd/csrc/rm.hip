@@ -35,6 +35,7 @@ struct AttP {
   float* P; bf16_t* a; float p_drop; unsigned long long seed;
   // backward
   const bf16_t* da; bf16_t* dqkv; bf16_t* dxk; bf16_t* dxv;
+  const unsigned long long* epoch;
 };
 
 __device__ __forceinline__ void load_qkv(const AttP& p, int b, int h, int l, float (&q)[S_][2], float (&k)[KEYS][2], float (&v)[KEYS][2]) {
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) void rm_attn_fwd_kernel(const AttP p) {
     float o0 = 0.f, o1 = 0.f;
 #pragma unroll
     for (int j = 0; j < KEYS; ++j) {
-      const float w = pr[i][j] * keep_scale(p.seed, ((uint64_t)(b * HEADS + h) * S_ + i) * KEYS + j, p.p_drop);
+      const float w = pr[i][j] * keep_scale(evk_mix_seed(p.seed, p.epoch), ((uint64_t)(b * HEADS + h) * S_ + i) * KEYS + j, p.p_drop);
       o0 += w * v[j][0]; o1 += w * v[j][1];
     }
     *reinterpret_cast<uint32_t*>(p.a + (long)(b * S_ + i) * D_ + h * DH + 2 * l) = pack2bf(o0, o1);
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void rm_attn_bwd_kernel(const AttP p) {
 #pragma unroll
     for (int j = 0; j < KEYS; ++j) {
       pr[j] = p.P[((long)(b * HEADS + h) * S_ + i) * KEYS + j];
-      ks[j] = keep_scale(p.seed, ((uint64_t)(b * HEADS + h) * S_ + i) * KEYS + j, p.p_drop);
+      ks[j] = keep_scale(evk_mix_seed(p.seed, p.epoch), ((uint64_t)(b * HEADS + h) * S_ + i) * KEYS + j, p.p_drop);
       dp[j] = half_sum(da[i][0] * v[j][0] + da[i][1] * v[j][1]) * ks[j];      // d/dP (through the dropout scale)
       dv[j][0] += pr[j] * ks[j] * da[i][0]; dv[j][1] += pr[j] * ks[j] * da[i][1];
       dot += dp[j] * pr[j];
@@ -289,7 +290,7 @@ int evk_rm_forward(const void* xk, const void* xv, const void* gw, const void* m
     bf16_t* qkv = w.qkv + (long)t * R * 1536;
     if (int e = gemm(m, Wqkv, qkv, (int)R, 1536, D_, EVK_B_PLAIN, D_, bqkv, nullptr, EVK_ACT_NONE, stream)) return e;
     AttP ap{qkv, (const bf16_t*)xk + (long)t * D_, (const bf16_t*)xv + (long)t * D_, (long)L * D_, w.P + (long)t * B * HEADS * S_ * KEYS,
-            w.a + t * RD, p_drop, (unsigned long long)(seed + 0x51ED27ULL * (uint64_t)(t + 1)), nullptr, nullptr, nullptr, nullptr};
+            w.a + t * RD, p_drop, (unsigned long long)(seed + 0x51ED27ULL * (uint64_t)(t + 1)), nullptr, nullptr, nullptr, nullptr, evk_seed_epoch_ptr()};
     {
       ProfScope ps(EVK_FAM_NORM, s);
       hipLaunchKernelGGL(rm_attn_fwd_kernel, dim3(B), dim3(256), 0, s, ap);
@@ -358,7 +359,7 @@ int evk_rm_backward(const void* dout, const void* xk, const void* xv, const void
     bf16_t* dqkv = w.dqkv + (long)t * R * 1536;
     AttP ap{w.qkv + (long)t * R * 1536, (const bf16_t*)xk + (long)t * D_, (const bf16_t*)xv + (long)t * D_, (long)L * D_,
             w.P + (long)t * B * HEADS * S_ * KEYS, nullptr, p_drop, (unsigned long long)(seed + 0x51ED27ULL * (uint64_t)(t + 1)), w.t_da, dqkv,
-            (bf16_t*)dxk + (long)t * D_, (bf16_t*)dxv + (long)t * D_};
+            (bf16_t*)dxk + (long)t * D_, (bf16_t*)dxv + (long)t * D_, evk_seed_epoch_ptr()};
     {
       ProfScope ps(EVK_FAM_NORM, s);
       hipLaunchKernelGGL(rm_attn_bwd_kernel, dim3(B), dim3(256), 0, s, ap);

@@ -56,9 +56,17 @@ void evk_prof_end(int family, hipStream_t s, double flops) {
   g_open = nullptr;
 }
 
+static const unsigned long long* g_seed_epoch = nullptr;
+const unsigned long long* evk_seed_epoch_ptr() { return g_seed_epoch; }
+
 extern "C" {
 
-int evk_version(void) { return 100; }
+int evk_set_seed_epoch(const uint64_t* epoch_dev) {
+  g_seed_epoch = reinterpret_cast<const unsigned long long*>(epoch_dev);
+  return EVK_OK;
+}
+
+int evk_version(void) { return 101; }
 int evk_storage_format(void) {
 #ifdef EVK_STORE_F16
   return 16;

@@ -81,6 +81,11 @@ int evk_version(void);
  * has no counterpart: it computes in fp32 (torch CPU / CUDA default dtype). */
 int evk_storage_format(void);
 const char* evk_last_error(void);
+/* Seed epoch of every dropout-drawing kernel (evk_dropout, evk_softmax_fwd/bwd, evk_attention_fwd/bwd, the relational-memory
+ * attention): a device uint64 the caller owns and advances once per training step with a device-side op; each kernel adds
+ * epoch * odd-constant to its seed argument, so a HIP graph of a whole step draws fresh masks at every replay although its
+ * kernel arguments are frozen (nn.Dropout's RNG state in the reference: torch's global generator).  NULL (default) = off. */
+int evk_set_seed_epoch(const uint64_t* epoch_dev);
 
 /* ---- profiling hooks used by bench.py: HIP-event timing of every launch of a kernel family ---------- */
 enum evk_family { EVK_FAM_GEMM = 0, EVK_FAM_NORM = 1, EVK_FAM_ELTWISE = 2, EVK_FAM_REDUCE = 3, EVK_FAM_OPTIM = 4,
