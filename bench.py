@@ -159,6 +159,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--dump-launches', default='', help='write one CSV row per profiled launch (GEMM shapes + ms) to this path')
     ap.add_argument('--no-prof', action='store_true', help='disable the in-library HIP-event timing of kernel families')
+    ap.add_argument('--no-side-streams', action='store_true', help='issue the whole step on one stream (experiment)')
+    ap.add_argument('--graph', type=int, default=-1, help='1: capture the whole training step in a HIP graph, 0: eager launches, -1: default')
     a = ap.parse_args()
 
     from evoke_amd import distributed as D
@@ -186,7 +188,8 @@ def main():
     red = D.GradReducer.for_optimizer(opt)
     batch = synth_batch(kind, a.batch, a.views, a.res, L, Li, dev, 1000 + rank)
 
-    def step():
+    def step_eager():
+        ops.advance_seed_epoch()
         opt.zero_grad()
         red.begin(kind)
         if kind == 'finetune':
@@ -199,6 +202,16 @@ def main():
         opt.step()
         return loss.detach()
 
+    # Step replay (evoke_amd/graph.py + csrc/replay.hip): the step is stream-captured once and its launch sequence re-issued from
+    # C++ -- host issue time 33 -> 12 ms per step (measured, profiles/r02_b_*), but with all work queued at once the side lanes
+    # (weight gradients, relational memory) compete with the critical path and the GPU-side step grows from 57.8 to 64 ms, so it
+    # stays opt-in (--graph 1) until the lanes carry the capture's stream priorities.
+    use_graph = a.graph if a.graph >= 0 else 0
+    step = step_eager
+    if use_graph:
+        from evoke_amd.graph import StepGraph
+        step = StepGraph(step_eager, warmup=2, make_on_replay=opt.replay_hook)
+
     def barrier():
         if world > 1:
             torch.distributed.barrier()
@@ -209,7 +222,8 @@ def main():
     main_stream = torch.cuda.Stream(device=dev, priority=-1) if os.environ.get('EVK_MAIN_PRIO', '1') == '1' else torch.cuda.current_stream()
     main_stream.wait_stream(torch.cuda.current_stream())
     torch.cuda.set_stream(main_stream)
-    for _ in range(a.warmup):
+    n_warm = max(a.warmup, 3) if use_graph else a.warmup          # capture happens on the 3rd call: keep it out of the timed steps
+    for _ in range(n_warm):
         step()
     barrier()
     t0 = time.perf_counter()
@@ -219,6 +233,16 @@ def main():
     host_dt = time.perf_counter() - t0
     barrier()
     dt = time.perf_counter() - t0
+    # host cost of ISSUING one step, measured from an idle GPU (inside the timed loop the launch queue is full whenever the GPU is
+    # the bottleneck, so the loop's host time mostly measures the GPU): two more steps, each issued after a full synchronisation
+    issue = []
+    for _ in range(2):
+        barrier()
+        t1 = time.perf_counter()
+        step()
+        issue.append(time.perf_counter() - t1)
+    barrier()
+    host_issue_ms = 1e3 * min(issue)
     fam, launched_flops = ({}, 0.0)
     if not a.no_prof:
         # Per-kernel durations for the roofline: ONE more step of the same workload right after the timed region, with a
@@ -236,7 +260,7 @@ def main():
         cyc_per_ms = 20_000_000 / max(e0.elapsed_time(e1), 1e-3)
         torch.cuda._sleep(int(cyc_per_ms * min(400.0, 1.5e3 * dt / a.steps + 30.0)))
         H.prof_enable(True)
-        step()
+        step_eager()
         barrier()
         ops.SIDE_STREAMS_ENABLED[0] = True
         if a.dump_launches:
@@ -253,12 +277,14 @@ def main():
     studies = a.batch * world * a.steps
     out = {
         'metric': 'studies/sec (train step, 2-view %d^2)' % a.res, 'value': studies / dt, 'unit': 'studies/s', 'n_gpus': world,
-        'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps, 'higher_is_better': True, 'scaling': 'weak',
+        'steps': a.steps, 'warmup': n_warm, 'ms_per_step': 1e3 * dt / a.steps, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': H.STORE, 'data': 'synthetic',
         'config': {'workload': 'EVOKE-%d two-view %s train step (fwd+bwd+allreduce+clip+RAdam), %d studies (%d images) per GPU, '
                                'L=%d, Li=%d, V=%d, random-init weights' % (a.res, kind, a.batch, a.batch * a.views, L, Li, V),
                    'parallelism': 'dp%d' % world, 'loss_last': float(losses[-1].item()),
-                   'host_launch_ms_per_step': 1e3 * host_dt / a.steps},
+                   'host_launch_ms_per_step': host_issue_ms, 'host_loop_ms_per_step': 1e3 * host_dt / a.steps,
+                   'step_graph': bool(use_graph and getattr(step, 'graph', None) is not None),
+                   'step_replay_plan': getattr(step, 'info', None)},
     }
     if fam:
         ms, n = fam['gemm']

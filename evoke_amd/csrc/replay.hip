@@ -1,0 +1,317 @@
+// replay.hip -- step replayer: re-issues the launch sequence of a stream-CAPTURED training step from C++.
+//
+// A training step of the engine is ~5k kernel launches on four HIP streams, issued from Python at ~10 us each (50 ms of host
+// time per 58 ms step).  Capturing the step in a HIP graph records exactly what has to run (our kernels, torch's glue kernels,
+// autograd's accumulation adds, memcpy / memset nodes, cross-stream dependencies), but hipGraphLaunch on ROCm 7.2 spends
+// 7-12 us of HOST time per node (measured: 75 ms per replay of the 6.2k-node step graph, 43 ms with the step forced onto one
+// stream) -- slower than the Python loop it replaces.  So the graph is used as a RECORDING only: this file walks the captured
+// hipGraph_t once (nodes, edges, kernel / memcpy / memset parameters), splits it into chains ("lanes" = HIP streams: a node
+// continues the lane of a predecessor when it can, which recovers the capture's stream structure), and replays it with plain
+// hipLaunchKernel / hipMemcpyAsync / hipMemsetAsync calls in topological order -- ~3.5 us per launch, cross-lane edges as
+// hipEventRecord / hipStreamWaitEvent pairs.  The kernel argument blocks stay owned by the hipGraph_t, which the caller keeps
+// alive for the life of the plan.  The reference has no counterpart (its step is eager PyTorch, modules/trainer_v0401.py:426-435).
+#include <stdlib.h>
+#include <algorithm>
+#include <queue>
+#include <unordered_map>
+#include <vector>
+#include "common.h"
+
+namespace {
+
+struct RNode {
+  int type = 3;                 // 0 kernel, 1 memcpy (1-D), 2 memset, 3 nothing to issue
+  void* func = nullptr; bool module_fn = false;
+  dim3 grid, block; unsigned shmem = 0; void** args = nullptr; void** extra = nullptr;
+  void* dst = nullptr; const void* src = nullptr; size_t bytes = 0; hipMemcpyKind kind = hipMemcpyDefault;
+  hipMemsetParams ms{};
+  hipGraphExec_t exec = nullptr;  // type 4: a one-node graph holding a memcpy / memset node this file does not decode itself
+  int lane = 0;
+  std::vector<int> waits;       // events to wait for before issuing
+  int record = -1;              // event to record after issuing
+};
+
+struct Plan {
+  std::vector<RNode> nodes;                 // in issue order
+  std::vector<hipStream_t> lanes;           // lanes[0] is the caller's stream at run time
+  std::vector<hipEvent_t> events;
+  int begin_event = -1;
+  std::vector<int> tail_events;             // events recorded at the end of the side lanes, joined by lane 0
+  size_t n_kernels = 0, n_copies = 0, n_sets = 0, n_cross = 0, n_sub = 0;
+  std::vector<hipGraph_t> subgraphs;
+};
+
+int new_event(Plan* p) {
+  hipEvent_t e;
+  if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return -1;
+  p->events.push_back(e);
+  return (int)p->events.size() - 1;
+}
+
+// a clone of `graph` reduced to the one node `nd`, instantiated: the fallback for node flavours whose parameters the public
+// query does not return faithfully (e.g. the 2-D device copies torch issues for strided slices)
+hipGraphExec_t isolate_node(Plan* p, hipGraph_t graph, hipGraphNode_t nd) {
+  hipGraph_t c = nullptr;
+  if (hipGraphClone(&c, graph) != hipSuccess) return nullptr;
+  hipGraphNode_t keep = nullptr;
+  if (hipGraphNodeFindInClone(&keep, nd, c) != hipSuccess) { (void)hipGraphDestroy(c); return nullptr; }
+  size_t m = 0;
+  if (hipGraphGetNodes(c, nullptr, &m) != hipSuccess) { (void)hipGraphDestroy(c); return nullptr; }
+  std::vector<hipGraphNode_t> all(m);
+  if (hipGraphGetNodes(c, all.data(), &m) != hipSuccess) { (void)hipGraphDestroy(c); return nullptr; }
+  for (hipGraphNode_t x : all)
+    if (x != keep && hipGraphDestroyNode(x) != hipSuccess) { (void)hipGraphDestroy(c); return nullptr; }
+  hipGraphExec_t ex = nullptr;
+  if (hipGraphInstantiate(&ex, c, nullptr, nullptr, 0) != hipSuccess) { (void)hipGraphDestroy(c); return nullptr; }
+  p->subgraphs.push_back(c);
+  ++p->n_sub;
+  return ex;
+}
+
+}  // namespace
+
+extern "C" {
+
+/* Builds a replay plan from a captured (not necessarily instantiated) hipGraph_t.  Returns NULL on failure (evk_last_error). */
+void* evk_replay_build(void* graph_handle, int32_t max_lanes) {
+  hipGraph_t graph = reinterpret_cast<hipGraph_t>(graph_handle);
+  if (!graph || max_lanes < 1) { evk_set_error("replay_build: bad args"); return nullptr; }
+  size_t n = 0, ne = 0;
+  if (hipGraphGetNodes(graph, nullptr, &n) != hipSuccess || n == 0) { evk_set_error("replay_build: hipGraphGetNodes failed / empty graph"); return nullptr; }
+  std::vector<hipGraphNode_t> nodes(n);
+  if (hipGraphGetNodes(graph, nodes.data(), &n) != hipSuccess) { evk_set_error("replay_build: hipGraphGetNodes failed"); return nullptr; }
+  if (hipGraphGetEdges(graph, nullptr, nullptr, &ne) != hipSuccess) { evk_set_error("replay_build: hipGraphGetEdges failed"); return nullptr; }
+  std::vector<hipGraphNode_t> ef(ne), et(ne);
+  if (ne && hipGraphGetEdges(graph, ef.data(), et.data(), &ne) != hipSuccess) { evk_set_error("replay_build: hipGraphGetEdges failed"); return nullptr; }
+  std::unordered_map<hipGraphNode_t, int> id;
+  id.reserve(n * 2);
+  for (size_t i = 0; i < n; ++i) id[nodes[i]] = (int)i;
+  std::vector<std::vector<int>> succ(n), pred(n);
+  for (size_t e = 0; e < ne; ++e) {
+    auto a = id.find(ef[e]), b = id.find(et[e]);
+    if (a == id.end() || b == id.end()) { evk_set_error("replay_build: edge references an unknown node"); return nullptr; }
+    succ[a->second].push_back(b->second);
+    pred[b->second].push_back(a->second);
+  }
+  // topological order, creation order as the priority (the capture's own issue order is one valid schedule)
+  std::vector<int> indeg(n), order;
+  order.reserve(n);
+  std::priority_queue<int, std::vector<int>, std::greater<int>> ready;
+  for (size_t i = 0; i < n; ++i) { indeg[i] = (int)pred[i].size(); if (!indeg[i]) ready.push((int)i); }
+  while (!ready.empty()) {
+    const int v = ready.top(); ready.pop();
+    order.push_back(v);
+    for (int s : succ[v]) if (--indeg[s] == 0) ready.push(s);
+  }
+  if (order.size() != n) { evk_set_error("replay_build: the graph has a cycle"); return nullptr; }
+
+  Plan* p = new Plan();
+  p->nodes.resize(n);
+  std::vector<int> pos(n);                    // node id -> index in issue order
+  for (size_t k = 0; k < n; ++k) pos[order[k]] = (int)k;
+  // node parameters
+  for (size_t k = 0; k < n; ++k) {
+    RNode& r = p->nodes[k];
+    hipGraphNode_t nd = nodes[order[k]];
+    hipGraphNodeType ty;
+    if (hipGraphNodeGetType(nd, &ty) != hipSuccess) { evk_set_error("replay_build: hipGraphNodeGetType failed"); delete p; return nullptr; }
+    if (ty == hipGraphNodeTypeKernel) {
+      hipKernelNodeParams kp{};
+      if (hipGraphKernelNodeGetParams(nd, &kp) != hipSuccess) { evk_set_error("replay_build: hipGraphKernelNodeGetParams failed"); delete p; return nullptr; }
+      r.type = 0; r.func = kp.func; r.grid = kp.gridDim; r.block = kp.blockDim; r.shmem = kp.sharedMemBytes; r.args = kp.kernelParams; r.extra = kp.extra;
+      hipFuncAttributes fa;
+      r.module_fn = hipFuncGetAttributes(&fa, kp.func) != hipSuccess;      // not a host-side kernel symbol: a hipFunction_t
+      (void)hipGetLastError();
+      ++p->n_kernels;
+    } else if (ty == hipGraphNodeTypeMemcpy) {
+      hipMemcpy3DParms mp{};
+      if (hipGraphMemcpyNodeGetParams(nd, &mp) != hipSuccess) { evk_set_error("replay_build: hipGraphMemcpyNodeGetParams failed"); delete p; return nullptr; }
+      if (mp.srcArray || mp.dstArray || mp.extent.height > 1 || mp.extent.depth > 1) {
+        r.exec = isolate_node(p, graph, nd);
+        if (!r.exec) { evk_set_error("replay_build: could not isolate memcpy node %zu", k); delete p; return nullptr; }
+        r.type = 4;
+        continue;
+      }
+      r.type = 1;
+      r.dst = (char*)mp.dstPtr.ptr + mp.dstPos.x; r.src = (const char*)mp.srcPtr.ptr + mp.srcPos.x; r.bytes = mp.extent.width; r.kind = mp.kind;
+      ++p->n_copies;
+    } else if (ty == hipGraphNodeTypeMemset) {
+      if (hipGraphMemsetNodeGetParams(nd, &r.ms) != hipSuccess) { evk_set_error("replay_build: hipGraphMemsetNodeGetParams failed"); delete p; return nullptr; }
+      if (r.ms.height > 1 || (r.ms.elementSize != 1 && r.ms.elementSize != 2 && r.ms.elementSize != 4)) {
+        r.exec = isolate_node(p, graph, nd);
+        if (!r.exec) { evk_set_error("replay_build: could not isolate memset node %zu", k); delete p; return nullptr; }
+        r.type = 4;
+        continue;
+      }
+      r.type = 2;
+      ++p->n_sets;
+    } else if (ty == hipGraphNodeTypeEmpty || ty == hipGraphNodeTypeEventRecord || ty == hipGraphNodeTypeWaitEvent) {
+      r.type = 3;
+    } else {
+      evk_set_error("replay_build: unsupported node type %d", (int)ty);
+      delete p;
+      return nullptr;
+    }
+  }
+  // Lanes = a MINIMUM PATH COVER of the dependency DAG (maximum bipartite matching between "node as predecessor" and "node as
+  // successor" along the edges): every chain follows real edges only, so putting a chain on one stream adds no false
+  // dependency, and the cover needs no more chains than the capture had streams (main, weight gradients, relational memory,
+  // text encoder, copies -- the capture's own streams are one valid cover).  Local rules do not recover them: at a fork the
+  // side branch may be issued before the forking stream continues (side.wait(main); launch side; launch main) or long after
+  // (autograd records an event when a node finishes and the consumer's stream waits for it when it runs); "first successor
+  // continues the lane" puts weight-gradient GEMM i and data-gradient GEMM i+2 on one lane and serialises the step (75 ms
+  // instead of 57), "last successor continues" breaks the main stream into 13 chains.
+  std::vector<int> nxt(n, -1), prv(n, -1);       // in issue indices
+  std::vector<std::vector<int>> sk(n);          // successors in issue indices, ascending
+  for (size_t k = 0; k < n; ++k) { for (int sc : succ[order[k]]) sk[k].push_back(pos[sc]); std::sort(sk[k].begin(), sk[k].end()); }
+  for (size_t k = 0; k < n; ++k)                // greedy start: the earliest free successor
+    for (int sc : sk[k]) if (prv[sc] < 0) { nxt[k] = sc; prv[sc] = (int)k; break; }
+  {
+    std::vector<int> seen(n, -1);
+    // Kuhn's augmenting paths, iterative (chains are thousands of nodes long)
+    for (size_t root = 0; root < n; ++root) {
+      if (nxt[root] >= 0 || sk[root].empty()) continue;
+      std::vector<std::pair<int, size_t>> st;     // (left node, next successor slot to try)
+      std::vector<int> via;                       // right node through which each stacked left node was reached
+      st.push_back({(int)root, 0});
+      via.push_back(-1);
+      bool found = false;
+      while (!st.empty() && !found) {
+        auto& top = st.back();
+        const int u = top.first;
+        if (top.second >= sk[u].size()) { st.pop_back(); via.pop_back(); continue; }
+        const int v = sk[u][top.second++];
+        if (seen[v] == (int)root) continue;
+        seen[v] = (int)root;
+        if (prv[v] < 0) {                         // free right node: flip the path
+          int right = v;
+          for (int i = (int)st.size() - 1; i >= 0; --i) {
+            const int left = st[i].first;
+            const int old_right = nxt[left];
+            nxt[left] = right; prv[right] = left;
+            right = old_right;                    // the right node this left node gives up goes to the previous left node
+            (void)via;
+          }
+          found = true;
+        } else {
+          st.push_back({prv[v], 0});
+          via.push_back(v);
+        }
+      }
+    }
+  }
+  std::vector<int> lane_tail;                 // per lane: issue index of its last node
+  for (size_t k = 0; k < n; ++k) {
+    RNode& r = p->nodes[k];
+    const std::vector<int>& pr = pred[order[k]];
+    int lane = -1;
+    if (prv[k] >= 0) lane = p->nodes[prv[k]].lane;
+    if (lane < 0) {
+      if (lane_tail.empty()) { lane = 0; lane_tail.push_back(-1); }
+      else if ((int)lane_tail.size() < max_lanes) { lane = (int)lane_tail.size(); lane_tail.push_back(-1); }
+      else {
+        for (size_t l = 1; l < lane_tail.size(); ++l)            // out of lanes: re-use one whose chain has ended
+          if (lane_tail[l] >= 0 && nxt[lane_tail[l]] < 0) { lane = (int)l; break; }
+        if (lane < 0) lane = 0;
+      }
+    }
+    r.lane = lane;
+    for (int q : pr) {
+      const int qi = pos[q];
+      RNode& rq = p->nodes[qi];
+      if (rq.lane == lane && qi <= lane_tail[lane]) continue;    // ordered by the lane itself
+      if (rq.record < 0) { rq.record = new_event(p); if (rq.record < 0) { evk_set_error("replay_build: hipEventCreate failed"); delete p; return nullptr; } }
+      r.waits.push_back(rq.record);
+      ++p->n_cross;
+    }
+    lane_tail[lane] = (int)k;
+  }
+  if (getenv("EVK_REPLAY_DEBUG")) {
+    std::vector<int> cnt(lane_tail.size(), 0);
+    for (RNode& r : p->nodes) ++cnt[r.lane];
+    for (size_t l = 0; l < cnt.size(); ++l) {
+      fprintf(stderr, "[replay] lane %zu: %d nodes;", l, cnt[l]);
+      int shown = 0;
+      for (size_t k = 0; k < n && shown < 4; ++k)
+        if (p->nodes[k].lane == (int)l && p->nodes[k].type == 0) { const char* nm = hipKernelNameRefByPtr(p->nodes[k].func, nullptr); fprintf(stderr, " [%zu]%.48s", k, nm ? nm : "?"); ++shown; }
+      fprintf(stderr, "\n");
+    }
+  }
+  p->lanes.assign(lane_tail.size(), nullptr);
+  for (size_t l = 1; l < p->lanes.size(); ++l)
+    if (hipStreamCreateWithFlags(&p->lanes[l], hipStreamNonBlocking) != hipSuccess) { evk_set_error("replay_build: hipStreamCreate failed"); delete p; return nullptr; }
+  p->begin_event = new_event(p);
+  for (size_t l = 1; l < p->lanes.size(); ++l) {
+    const int e = new_event(p);
+    if (e < 0 || p->begin_event < 0) { evk_set_error("replay_build: hipEventCreate failed"); delete p; return nullptr; }
+    p->tail_events.push_back(e);
+  }
+  return p;
+}
+
+/* nodes / kernels / memcpys / memsets / lanes / cross-lane edges / isolated one-node sub-graphs of a plan */
+int evk_replay_info(void* plan, int64_t* out6) {
+  Plan* p = reinterpret_cast<Plan*>(plan);
+  EVK_REQUIRE(p && out6, "replay_info: bad args");
+  out6[0] = (int64_t)p->nodes.size(); out6[1] = (int64_t)p->n_kernels; out6[2] = (int64_t)p->n_copies; out6[3] = (int64_t)p->n_sets;
+  out6[4] = (int64_t)p->lanes.size(); out6[5] = (int64_t)p->n_cross; out6[6] = (int64_t)p->n_sub;
+  return EVK_OK;
+}
+
+/* Issues the recorded step: lane 0 = `stream` (everything is ordered after what is already queued there, and `stream` waits
+ * for every lane at the end), the other lanes are streams the plan owns. */
+int evk_replay_run(void* plan, evk_stream_t stream) {
+  Plan* p = reinterpret_cast<Plan*>(plan);
+  EVK_REQUIRE(p, "replay_run: null plan");
+  hipStream_t s0 = reinterpret_cast<hipStream_t>(stream);
+  p->lanes[0] = s0;
+  if (p->lanes.size() > 1) {
+    if (hipEventRecord(p->events[p->begin_event], s0) != hipSuccess) { evk_set_error("replay_run: hipEventRecord failed"); return EVK_ELAUNCH; }
+    for (size_t l = 1; l < p->lanes.size(); ++l) (void)hipStreamWaitEvent(p->lanes[l], p->events[p->begin_event], 0);
+  }
+  for (RNode& r : p->nodes) {
+    hipStream_t s = p->lanes[r.lane];
+    for (int e : r.waits) (void)hipStreamWaitEvent(s, p->events[e], 0);
+    hipError_t err = hipSuccess;
+    switch (r.type) {
+      case 0:
+        if (r.module_fn)
+          err = hipModuleLaunchKernel(reinterpret_cast<hipFunction_t>(r.func), r.grid.x, r.grid.y, r.grid.z, r.block.x, r.block.y, r.block.z, r.shmem, s, r.args, r.extra);
+        else
+          err = hipLaunchKernel(r.func, r.grid, r.block, r.args, r.shmem, s);
+        break;
+      case 1: err = hipMemcpyAsync(r.dst, r.src, r.bytes, r.kind, s); break;
+      case 2:
+        if (r.ms.elementSize == 4) err = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(r.ms.dst), (int)r.ms.value, r.ms.width, s);
+        else if (r.ms.elementSize == 2) err = hipMemsetD16Async(reinterpret_cast<hipDeviceptr_t>(r.ms.dst), (unsigned short)r.ms.value, r.ms.width, s);
+        else err = hipMemsetAsync(r.ms.dst, (int)r.ms.value, r.ms.width, s);
+        break;
+      case 4: err = hipGraphLaunch(r.exec, s); break;
+      default: break;
+    }
+    if (err != hipSuccess) {
+      evk_set_error("replay_run: node %ld (type %d, lane %d of %zu, %zu waits) failed: %s", (long)(&r - p->nodes.data()), r.type, r.lane, p->lanes.size(),
+                    r.waits.size(), hipGetErrorString(err));
+      return EVK_ELAUNCH;
+    }
+    if (r.record >= 0) (void)hipEventRecord(p->events[r.record], s);
+  }
+  for (size_t l = 1; l < p->lanes.size(); ++l) {
+    (void)hipEventRecord(p->events[p->tail_events[l - 1]], p->lanes[l]);
+    (void)hipStreamWaitEvent(s0, p->events[p->tail_events[l - 1]], 0);
+  }
+  return evk_check_launch("replay_run");
+}
+
+int evk_replay_destroy(void* plan) {
+  Plan* p = reinterpret_cast<Plan*>(plan);
+  if (!p) return EVK_OK;
+  for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
+  for (RNode& r : p->nodes) if (r.exec) (void)hipGraphExecDestroy(r.exec);
+  for (hipGraph_t g : p->subgraphs) (void)hipGraphDestroy(g);
+  for (size_t l = 1; l < p->lanes.size(); ++l) if (p->lanes[l]) (void)hipStreamDestroy(p->lanes[l]);
+  delete p;
+  return EVK_OK;
+}
+
+}  // extern "C"

@@ -247,7 +247,7 @@ def multi_pos_contra_images(global_image_embed, patient_ids, temp, gather=None):
     np.fill_diagonal(labels, 0.0)
     idx = np.nonzero(labels.sum(1) != 0)[0]
     if len(idx) == 0:
-        return torch.tensor([0.0], requires_grad=True, device=global_image_embed.device)
+        return torch.zeros(1, device=global_image_embed.device, requires_grad=True)      # no host->device copy (graph-capturable)
     labels = labels[idx][:, idx]
     labels = labels / labels.sum(1, keepdims=True)
     t = ops.upload(labels, g.device)

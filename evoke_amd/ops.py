@@ -174,16 +174,23 @@ def side_stream(name, device=None):
 _main_stream = {}
 
 
+def _capturing(st):
+    with torch.cuda.stream(st):
+        return torch.cuda.is_current_stream_capturing()
+
+
 def join_side_streams(into=None, skip=None):
     """Make `into` (default: the current stream) wait for everything queued on the side streams and on the main stream
     (called before the optimizer / gradient all-reduce, because parameter gradients are accumulated in place from those
-    streams).  `skip` names a side stream to leave out."""
+    streams).  `skip` names a side stream to leave out.  While a step is being captured in a HIP graph only the streams that
+    have joined the capture are waited for (an idle side stream has nothing queued and is not part of the graph)."""
     cur = torch.cuda.current_stream() if into is None else into
+    cap = _capturing(cur)
     for (name, dev), st in _side_streams.items():
-        if dev == cur.device.index and st != cur and name != skip:
+        if dev == cur.device.index and st != cur and name != skip and (not cap or _capturing(st)):
             cur.wait_stream(st)
     main = _main_stream.get(cur.device.index)
-    if main is not None and main != cur:
+    if main is not None and main != cur and (not cap or _capturing(main)):
         cur.wait_stream(main)
 
 
@@ -205,6 +212,13 @@ class _Uploader:
         arr = np.ascontiguousarray(arr)
         nb = arr.nbytes
         tdt = torch.from_numpy(arr[:0].reshape(-1)).dtype
+        if nb and torch.cuda.is_current_stream_capturing():
+            # HIP-graph capture of a whole step (evoke_amd/graph.py): the copy becomes a memcpy node that re-reads ITS OWN pinned
+            # staging buffer at every replay, so the buffer is dedicated to the graph (kept alive by the capture's owner) and no
+            # event of the ring is synchronised while the stream is capturing
+            stage = torch.from_numpy(arr.reshape(-1).view(np.uint8).copy()).pin_memory()
+            CAPTURE_KEEPALIVE.append(stage)
+            return stage.to(self.device, non_blocking=True).view(tdt).view(arr.shape)
         if nb > self.bufs[0].numel() or nb == 0:
             return torch.from_numpy(arr).to(self.device)          # oversize / empty: plain (blocking) path
         k = self.i % len(self.bufs)
@@ -225,6 +239,7 @@ class _Uploader:
 
 
 _uploaders = {}
+CAPTURE_KEEPALIVE = []          # pinned staging buffers referenced by memcpy nodes of captured step graphs
 
 
 def upload(arr, device):
@@ -257,8 +272,9 @@ _wgrad_join_queued = [False]
 def _wgrad_join_callback():
     _wgrad_join_queued[0] = False
     cur = torch.cuda.current_stream()
+    cap = _capturing(cur)
     for (name, dev), st in _side_streams.items():
-        if name == 'wgrad' and dev == cur.device.index:
+        if name == 'wgrad' and dev == cur.device.index and (not cap or _capturing(st)):
             cur.wait_stream(st)
 
 
@@ -547,6 +563,21 @@ def set_dropout_enabled(on):
 def next_seed():
     _seed_state[0] = (_seed_state[0] * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
     return _seed_state[0]
+
+
+_seed_epoch = {}
+
+
+def advance_seed_epoch(device=None):
+    """Device-side dropout epoch (evk_set_seed_epoch): call once at the start of every training step.  The increment is a
+    device op, so a captured step graph advances it at every replay and its frozen seed arguments still draw fresh masks."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    ep = _seed_epoch.get(dev)
+    if ep is None:
+        ep = _seed_epoch[dev] = torch.zeros(1, dtype=torch.int64, device=torch.device('cuda', dev))
+        H.check(H.lib.evk_set_seed_epoch(H.ptr(ep)), 'set_seed_epoch')
+    ep.add_(1)
+    return ep
 
 
 def manual_seed(s):

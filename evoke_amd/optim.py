@@ -56,6 +56,7 @@ class FusedOptimizer(torch.optim.Optimizer):
         # equal signatures have equal device step counts and may share one fused launch.
         self._hist = {}
         self.world = 1              # ranks whose gradients the all-reduce SUMS into the flat buffers (set by GradReducer)
+        self._last_touched = []
         ops.register_grad_callback(self._on_grad)
         for g in self.param_groups:
             ps = g['params']
@@ -192,7 +193,20 @@ class FusedOptimizer(torch.optim.Optimizer):
                 H.check(H.lib.evk_optim_bump(step_ptr, cnt, sstate, H.stream()), 'optim_bump')
         if scaler is not None:
             scaler.update()
+        self._last_touched = [p for g in self.param_groups for p in g['params'] if id(p) in self._touched]
         self._touched.clear()
+
+    def replay_hook(self):
+        """Host bookkeeping of a step that was just captured in a HIP graph (evoke_amd/graph.py): the returned function is called
+        after every replay and folds the replayed step into the step-history signatures of the parameters it updated (their
+        device step counts advanced inside the graph), so that later eager steps still merge only parameters with equal counts."""
+        touched = list(self._last_touched)
+
+        def hook():
+            self.steps += 1
+            for p in touched:
+                self._hist[id(p)] = hash((self._hist.get(id(p), 0), self.steps))
+        return hook
 
 
 def build_two_stage_optimizer(args, model, clip_value=0.1):

@@ -48,6 +48,10 @@ class Trainer:
         self.not_improved = 0
         self.checkpoint_dir = os.path.join(args.get('result_dir', '.'), 'checkpoint')
         self.world = D.world_size()
+        # engine-namespaced key (the reference has no counterpart): capture each batch structure's whole step once and replay its
+        # launch sequence from C++ (evoke_amd/graph.py); opt-in, see bench.py
+        self.step_graphs = bool(args.get('evk_step_graphs', False))
+        self._graphs = {}
         if args.get('resume'):
             self.resume_checkpoint(args['resume'])
         if args.get('load'):
@@ -81,12 +85,58 @@ class Trainer:
         return invalid
 
     # ------------------------------------------------------------------ one optimizer step
+    MAX_STEP_GRAPHS = 8
+
+    def _graphed_step(self, batch, kind):
+        """train_step through evoke_amd.graph.StepGraph: one captured HIP graph per batch STRUCTURE (tensor shapes + multi-view
+        grouping of patient_ids + step kind), inputs copied into that structure's static device buffers before every call.  A
+        structure runs eagerly until it has been seen `warmup` times; at most MAX_STEP_GRAPHS structures are kept (LRU)."""
+        from . import ops
+        from .graph import StepGraph, structure_key
+        dev = next(self.model.parameters()).device
+        tens = [batch[0], batch[1], batch[2]] + [batch[i] for i in (4, 5) if len(batch) > i]
+        key = structure_key(tens, batch[3], extra=(kind, self.model.training))
+        ent = self._graphs.pop(key, None)
+        if ent is None:
+            static = [torch.empty(t.shape, dtype=t.dtype, device=dev) for t in tens]
+            pids = list(batch[3])
+            model, opt, red, task = self.model, self.optimizer, self.reducer, self.task
+
+            def fn():
+                ops.advance_seed_epoch()
+                opt.zero_grad()
+                if red is not None:
+                    red.begin(kind)
+                if task == 'finetune':
+                    ret = model(static[0], static[1], static[2], pids, *static[3:5], mode='train')
+                else:
+                    ret = model(static[0], static[1], static[2], pids)
+                ret['all_loss'].backward()
+                if red is not None:
+                    red.finish()
+                opt.step()
+                return {k: v.detach() for k, v in ret.items() if torch.is_tensor(v)}
+            ent = (static, StepGraph(fn, warmup=2, make_on_replay=getattr(opt, 'replay_hook', None)))
+            while len(self._graphs) >= self.MAX_STEP_GRAPHS:
+                self._graphs.pop(next(iter(self._graphs)))
+        self._graphs[key] = ent                     # most recently used last
+        static, sg = ent
+        for dst, src in zip(static, tens):
+            dst.copy_(src, non_blocking=True)
+        return sg()
+
     def train_step(self, batch, kind=None):
         """batch: the loader tuple without the leading image ids -- pretrain (images, radgraph_ids, radgraph_masks,
         patient_ids); finetune (images, input_ids, attention_masks, patient_ids[, inc_ids, inc_masks]).
         Returns the model's loss dict (device tensors, detached)."""
         dev = next(self.model.parameters()).device
+        if self.step_graphs and dev.type == 'cuda' and hasattr(self.optimizer, 'replay_hook') and D.world_size() == 1:
+            k = kind or (('inc' if len(batch) >= 6 else 'no_inc') if self.task == 'finetune' else 'pretrain')
+            return self._graphed_step(batch, k)
         images = batch[0].to(dev, non_blocking=True)
+        from . import ops
+        if dev.type == 'cuda':
+            ops.advance_seed_epoch()
         self.optimizer.zero_grad()
         if self.task == 'finetune':
             has_inc = len(batch) >= 6

@@ -94,6 +94,19 @@ int evk_prof_enable(int on);                     /* records a hipEvent pair arou
 int evk_prof_collect(double* ms_per_family, int64_t* launches_per_family, double* flops_gemm); /* syncs+resets */
 int evk_prof_dump_to(const char* path);          /* next evk_prof_collect also writes one CSV row per launch (shape-tagged GEMMs) */
 
+/* ---- step replayer (replay.hip): the launch sequence of a stream-captured training step re-issued from C++ ------------
+ * The reference's step is eager PyTorch (modules/trainer_v0401.py:426-435: zero_grad, forward, backward, clip, step).  Here the
+ * step is captured ONCE per batch structure with hipStreamBeginCapture (through torch.cuda.graph), and the resulting hipGraph_t
+ * is only a recording: evk_replay_build walks its nodes / edges / kernel parameters and evk_replay_run re-issues them with plain
+ * hipLaunchKernel calls on a few streams (hipGraphLaunch itself costs 7-12 us of host time per node on ROCm 7.2).  The caller
+ * keeps the hipGraph_t alive for the life of the plan (kernel argument blocks are owned by it).
+ *   evk_replay_info: out6[0..6] = {nodes, kernels, memcpys, memsets, lanes (streams), cross-lane edges, nodes replayed as isolated
+ *   one-node graphs (copy flavours whose parameters the public query does not return faithfully)}.                        */
+void* evk_replay_build(void* hip_graph, int32_t max_lanes);
+int evk_replay_info(void* plan, int64_t* out6);
+int evk_replay_run(void* plan, evk_stream_t stream);
+int evk_replay_destroy(void* plan);
+
 /* ---- GEMM / implicit-GEMM family (MFMA) -------------------------------------------------------------
  * replaces: nn.Linear / torch.matmul (encoder_decoder.py:20-28,192-214; bert_model.py:262-341;
  * utils_v0511.py:263-278), nn.Conv1d k=1 (utils_v0511.py:135-147), nn.Conv2d of the ResNet-101 trunk

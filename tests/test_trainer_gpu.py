@@ -194,3 +194,52 @@ def test_fused_optimizer_overflow_skip_keeps_the_torch_trajectory():
         assert torch.allclose(a.detach().cpu(), b.detach().cpu(), rtol=2e-5, atol=2e-6)
     ops.loss_scaler().state.copy_(torch.tensor([sc0, 0.0, 0.0, 0.0]))          # leave the process-wide scaler as found
     ops.clear_grad_callbacks()
+
+
+@pytest.mark.parametrize('task', ['finetune', 'pretrain'])
+def test_step_graph_replays_the_eager_trajectory(task):
+    """Whole-step HIP-graph capture (evoke_amd/graph.py) through Trainer.train_step: six optimizer steps on batches of ONE
+    structure (different data each step) -- two eager warm-up calls, the capture, three replays -- follow the same loss sequence
+    and end at the same parameters as six eager steps of an identically initialised model (dropout off; the only
+    non-determinism left is the summation order of f32 atomics)."""
+    from evoke_amd import distributed as D, ops, optim
+    from evoke_amd.model_pretrain_finetune import FineTune, Pretrain
+    from evoke_amd.trainer import Trainer
+    from tests.helpers import ARGS, V, load_tokenizer
+    args = dict(ARGS, task=task, pt_lr=5e-5, ft_lr=5e-4, optim='RAdam', weight_decay=5e-5, amsgrad=True)
+    ops.set_dropout_enabled(False)
+
+    def batch(i):
+        g = torch.Generator().manual_seed(11 * i + 1)
+        ids = torch.randint(5, V - 2, (2, 12), generator=g)
+        ids[:, 0] = V - 2 if task == 'finetune' else 1
+        b = [torch.randn(3, 3, 224, 224, generator=g), ids, torch.ones(2, 12, dtype=torch.long), ['q%d_s0' % i, 'q%d_s1' % i, 'q%d_s0' % i]]
+        if task == 'finetune':
+            inc = torch.randint(5, V - 2, (2, 6), generator=g)
+            inc[:, 0] = 1
+            b += [inc, torch.ones(2, 6, dtype=torch.long)]
+        return tuple(b)
+
+    def run(graphs):
+        ops.clear_grad_callbacks()
+        torch.manual_seed(5)
+        m = (FineTune if task == 'finetune' else Pretrain)(args, load_tokenizer(), 'mimic_cxr').cuda().train()
+        o = optim.build_two_stage_optimizer(args, m, clip_value=0.1)
+        tr = Trainer(m, o, dict(args, evk_step_graphs=graphs), reducer=D.GradReducer.for_optimizer(o), task=task, log=lambda s: None)
+        losses = [float(tr.train_step(batch(i))['all_loss'].reshape(-1)[0]) for i in range(6)]
+        torch.cuda.synchronize()
+        captured = [sg.graph is not None for _, sg in tr._graphs.values()]
+        steps = [int(e['step']) for e in o.state_dict()['state'].values()]
+        return losses, [st['p'].detach().clone() for st in o.flat], captured, steps
+
+    l_e, p_e, cap_e, steps_e = run(False)
+    l_g, p_g, cap_g, steps_g = run(True)
+    ops.clear_grad_callbacks()
+    ops.set_dropout_enabled(True)
+    print('\n[step graph %s] eager %s\n                   graph %s' % (task, ['%.5f' % v for v in l_e], ['%.5f' % v for v in l_g]))
+    assert cap_e == [] and cap_g == [True], (cap_e, cap_g)
+    assert steps_e == steps_g and max(steps_g) == 6
+    for a, b in zip(l_e, l_g):
+        assert abs(a - b) <= 2e-4 * max(1.0, abs(a)), (l_e, l_g)
+    for a, b in zip(p_e, p_g):
+        assert torch.allclose(a, b, rtol=1e-3, atol=2e-5), float((a - b).abs().max())
