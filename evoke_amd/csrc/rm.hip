@@ -9,6 +9,7 @@
 // while everything that does not depend on the recurrence is hoisted out of the loop by the caller (x_t.Wk, x_t.Wv and
 // W(x_t) for all t are three ordinary batched GEMMs) and all weight gradients are ONE K = L*B*slots GEMM per weight
 // after the loop (the per-token operands are saved contiguously in the workspace).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -190,6 +191,18 @@ __global__ __launch_bounds__(256) void rm_combine_kernel(const bf16_t* __restric
   }
 }
 
+// Measured on MI355X (FineTune 384^2, 32 samples, L = 100; profiles/r02_c_rm_persistent_kernel_stats.csv): persistent forward
+// 15.1 ms + backward 12.5 ms against 5.5 + 5.8 ms of kernel time for the per-token launch sequence -- every workgroup has to
+// pull the 4 MB of weights through ITS OWN vector L1 once per token, and one CU's L1 miss queue sustains ~27 GB/s (the same
+// fill bound the tile GEMMs sit on): 4 MB / 27 GB/s = 150 us per token.  The launch sequence spreads each
+// GEMM's weights over 32 CUs instead.  So the persistent kernels are OPT-IN (EVK_RM_PERSIST=1 / evk_rm_set_persistent(1)): they
+// cut 2000 launches (~10 ms of host time per step) to 2 and are the right trade when the host is the bottleneck.
+int g_rm_persist = -1;           // -1: EVK_RM_PERSIST (default off); 0 / 1: evk_rm_set_persistent
+inline bool rm_use_persistent(int L) {
+  if (g_rm_persist < 0) { const char* e = getenv("EVK_RM_PERSIST"); g_rm_persist = e ? (atoi(e) != 0) : 0; }
+  return g_rm_persist != 0 && L >= 8;
+}
+
 inline int ew_blocks(long work) { long b = cdiv(work, 256); return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b)); }
 
 int gemm(const void* A, const void* B, void* C, int M, int N, int K, int b_mode, long ldb, const float* bias, const void* resid, int act,
@@ -224,6 +237,9 @@ struct Ws {
 }  // namespace
 
 extern "C" {
+
+/* 1: walks of >= 8 tokens run as ONE persistent launch per direction; 0 (default): always the per-token launch path */
+int evk_rm_set_persistent(int32_t on) { g_rm_persist = on ? 1 : 0; return EVK_OK; }
 
 /* bytes of workspace for evk_rm_forward(save=1) + evk_rm_backward */
 int64_t evk_rm_ws_bytes(int32_t B, int32_t L) {
@@ -262,6 +278,360 @@ Ws carve(void* ws, int B, int L) {
   return w;
 }
 
+
+// ====================================================================================================
+// Persistent recurrence kernels: ONE launch walks all L tokens (forward) / all L tokens backwards (BPTT).
+//
+// One workgroup per SAMPLE (256 threads = 4 waves); the 3 x 512 memory of the sample lives in LDS for the whole walk, every
+// intermediate of a token goes LDS -> LDS (and, 16-bit rounded at the same points as the per-token launch path above, to the
+// workspace the backward / the weight-gradient GEMMs read).  No workgroup ever waits for another one (no grid barrier, no
+// residency requirement), so the kernel cannot dead-lock whatever else shares the GPU.
+// The seven weight matrices (4 MB of 16-bit operands) do not fit one CU's LDS + registers: each workgroup STREAMS them from
+// L2 / Infinity Cache once per token straight into MFMA A-operand registers (row-major [out][in] rows are K-contiguous = the
+// A fragment of v_mfma_f32_16x16x32: lane -> weight row l&15, 8 consecutive k at 8*(l>>4); 16-byte loads, two row blocks in
+// flight per wave), the 3 activation rows are the B operand (columns 3..15 of the tile are don't-care).  All workgroups walk
+// the same weights in the same order at the same pace, so a line fetched by one is an L2 hit for the other samples of its XCD.
+// Bound: weight bytes per token per CU (4 MB at the CU's fill rate), not MFMA (4096 MFMAs per token per CU ~ 7 us).
+// ====================================================================================================
+constexpr int LS = 520;          // LDS row stride (16-bit elements) of a 512-wide activation row: rows land 16 B apart mod 256 B
+
+struct PersistW {                // forward weights (row-major [out][in]) / backward: the TRANSPOSED weights
+  const bf16_t *Wqkv, *Wo, *W0, *W2, *U;
+  const float *bqkv, *bo, *b0, *b2, *bU;
+};
+struct PersistP {
+  PersistW w;
+  const bf16_t *xk, *xv, *gw, *m0;      // (B, L, 512) x2, (B, L, 1024), (B, 3, 512)
+  bf16_t *out, *m_last;                 // (B, L, 1536), (B, 3, 512) or null
+  Ws ws; int B, L; float p_drop; unsigned long long seed; const unsigned long long* epoch;
+  // backward only
+  const bf16_t* dout; bf16_t *dxk, *dxv, *dgw;
+};
+
+__device__ __forceinline__ bf16x8 ld_frag(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+
+// out rows [16*rb, 16*rb+16) for the wave's row blocks rb = wave, wave+4, ... < nblocks of W[N][512*KCH] times the 3
+// activation rows in `in` (LDS, row stride `lsi`).  Work unit = (row block, 512-wide K chunk); the A fragments of unit u+1 are
+// in flight while unit u multiplies (two register sets, ping-pong).  KCH == 1: the B fragments are loaded once; otherwise they
+// are re-read from LDS per unit (the accumulators of all row blocks of a wave would not fit beside two A sets).
+// epi(rb, acc): lane holds D[row 4*(l>>4)+j][col l&15], useful for col < 3.
+template <int KCH, class Epi>
+__device__ __forceinline__ void mvgen(const bf16_t* __restrict__ W, int nblocks, const bf16_t* in, int lsi, int wave, int lane, Epi epi) {
+  constexpr int ktot = 512 * KCH;
+  const int col = lane & 15, kq = lane >> 4;
+  const bf16_t* brow = in + (col % 3) * lsi + kq * 8;
+  const bf16_t* wl = W + (long)col * ktot + kq * 8;
+  const int nbw = nblocks > wave ? (nblocks - wave + 3) / 4 : 0;
+  const int units = nbw * KCH;
+  if (units == 0) return;
+  bf16x8 b[16], a0[16], a1[16];
+  if (KCH == 1) {
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) b[ks] = ld_frag(brow + ks * 32);
+  }
+  auto load = [&](bf16x8 (&a)[16], int u) {
+    const int rb = wave + 4 * (u / KCH), c = u % KCH;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) a[ks] = ld_frag(wl + (long)rb * 16 * ktot + c * 512 + ks * 32);
+  };
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  auto mul = [&](bf16x8 (&a)[16], int u) {
+    const int rb = wave + 4 * (u / KCH), c = u % KCH;
+    if (KCH > 1) {
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) b[ks] = ld_frag(brow + c * 512 + ks * 32);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) acc = EVK_MFMA_16x16x32(a[ks], b[ks], acc, 0, 0, 0);
+    if (c == KCH - 1) { epi(rb, acc); acc = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  };
+  load(a0, 0);
+  for (int u = 0; u < units; u += 2) {
+    if (u + 1 < units) load(a1, u + 1);
+    mul(a0, u);
+    if (u + 1 >= units) break;
+    if (u + 2 < units) load(a0, u + 2);
+    mul(a1, u + 1);
+  }
+}
+
+__device__ __forceinline__ void st4(bf16_t* p, float v0, float v1, float v2, float v3) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(pack2bf(v0, v1), pack2bf(v2, v3));
+}
+
+__global__ __launch_bounds__(256) void rm_persist_fwd_kernel(const PersistP p) {
+  __shared__ __attribute__((aligned(16))) bf16_t sm[3 * LS], stm[3 * LS], sqkv[3 * (1536 + 8)], sgu[3 * (1024 + 8)], sa[3 * LS], snm1[3 * LS], sh1[3 * LS],
+      sh2[3 * LS];
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int col = lane & 15, kq = lane >> 4;
+  const Ws& w = p.ws;
+  const long R = w.R, RD = R * D_;
+  const long row0 = (long)b * S_;                       // first of the sample's 3 rows in the [R][*] workspace arrays
+  // m_0, tanh(m_0)
+  for (int i = tid; i < S_ * D_; i += 256) {
+    const int s = i / D_, c = i - s * D_;
+    const bf16_t v = p.m0[(row0 + s) * D_ + c];
+    const bf16_t tv = f2bf(tanhf(bf2f(v)));
+    sm[s * LS + c] = v; stm[s * LS + c] = tv;
+    w.m[(row0 + s) * D_ + c] = v; w.tm[(row0 + s) * D_ + c] = tv;
+  }
+  __syncthreads();
+  for (int t = 0; t < p.L; ++t) {
+    // ---- qkv = m.Wqkv^T + bqkv (96 row blocks), gu = tanh(m).U^T + bU (64 row blocks)
+    bf16_t* qkv_g = w.qkv + ((long)t * R + row0) * 1536;
+    mvgen<1>(p.w.Wqkv, 96, sm, LS, wave, lane, [&](int rb, const f32x4& acc) {
+      if (col < 3) {
+        const int o = rb * 16 + kq * 4;
+        const float4 bb = *reinterpret_cast<const float4*>(p.w.bqkv + o);
+        st4(sqkv + col * 1544 + o, acc[0] + bb.x, acc[1] + bb.y, acc[2] + bb.z, acc[3] + bb.w);
+        st4(qkv_g + (long)col * 1536 + o, acc[0] + bb.x, acc[1] + bb.y, acc[2] + bb.z, acc[3] + bb.w);
+      }
+    });
+    mvgen<1>(p.w.U, 64, stm, LS, wave, lane, [&](int rb, const f32x4& acc) {
+      if (col < 3) {
+        const int o = rb * 16 + kq * 4;
+        const float4 bb = *reinterpret_cast<const float4*>(p.w.bU + o);
+        st4(sgu + col * 1032 + o, acc[0] + bb.x, acc[1] + bb.y, acc[2] + bb.z, acc[3] + bb.w);
+      }
+    });
+    __syncthreads();
+    // ---- attention of the 3 slots over [3 slots; x_t]: thread -> head h = tid>>5, dims 2l, 2l+1
+    {
+      const int h = tid >> 5, l = tid & 31, c = h * DH + 2 * l;
+      float q[S_][2], k[KEYS][2], v[KEYS][2];
+#pragma unroll
+      for (int i = 0; i < S_; ++i) {
+        const uint32_t a = *reinterpret_cast<const uint32_t*>(sqkv + i * 1544 + c), kk = *reinterpret_cast<const uint32_t*>(sqkv + i * 1544 + 512 + c),
+                       vv = *reinterpret_cast<const uint32_t*>(sqkv + i * 1544 + 1024 + c);
+        q[i][0] = lo_bf(a); q[i][1] = hi_bf(a); k[i][0] = lo_bf(kk); k[i][1] = hi_bf(kk); v[i][0] = lo_bf(vv); v[i][1] = hi_bf(vv);
+      }
+      const uint32_t kk = *reinterpret_cast<const uint32_t*>(p.xk + ((long)b * p.L + t) * D_ + c);
+      const uint32_t vv = *reinterpret_cast<const uint32_t*>(p.xv + ((long)b * p.L + t) * D_ + c);
+      k[3][0] = lo_bf(kk); k[3][1] = hi_bf(kk); v[3][0] = lo_bf(vv); v[3][1] = hi_bf(vv);
+      const unsigned long long seed = evk_mix_seed(p.seed + 0x51ED27ULL * (uint64_t)(t + 1), p.epoch);
+      float* Pt = w.P + (long)t * p.B * HEADS * S_ * KEYS;
+#pragma unroll
+      for (int i = 0; i < S_; ++i) {
+        float sc[KEYS], mx = -INFINITY, sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < KEYS; ++j) { sc[j] = half_sum(q[i][0] * k[j][0] + q[i][1] * k[j][1]) * 0.125f; mx = fmaxf(mx, sc[j]); }
+#pragma unroll
+        for (int j = 0; j < KEYS; ++j) { sc[j] = __expf(sc[j] - mx); sum += sc[j]; }
+        float o0 = 0.f, o1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < KEYS; ++j) {
+          const float pr = sc[j] / sum;
+          if (l == 0) Pt[((long)(b * HEADS + h) * S_ + i) * KEYS + j] = pr;
+          const float wgt = pr * keep_scale(seed, ((uint64_t)(b * HEADS + h) * S_ + i) * KEYS + j, p.p_drop);
+          o0 += wgt * v[j][0]; o1 += wgt * v[j][1];
+        }
+        const uint32_t pk = pack2bf(o0, o1);
+        *reinterpret_cast<uint32_t*>(sa + i * LS + c) = pk;
+        *reinterpret_cast<uint32_t*>(w.a + (long)t * RD + (row0 + i) * D_ + c) = pk;
+      }
+    }
+    __syncthreads();
+    // ---- nm1 = a.Wo^T + bo + m
+    mvgen<1>(p.w.Wo, 32, sa, LS, wave, lane, [&](int rb, const f32x4& acc) {
+      if (col < 3) {
+        const int o = rb * 16 + kq * 4;
+        const float4 bb = *reinterpret_cast<const float4*>(p.w.bo + o);
+        const uint2 mm = *reinterpret_cast<const uint2*>(sm + col * LS + o);
+        const float r0 = acc[0] + bb.x + lo_bf(mm.x), r1 = acc[1] + bb.y + hi_bf(mm.x), r2 = acc[2] + bb.z + lo_bf(mm.y), r3 = acc[3] + bb.w + hi_bf(mm.y);
+        st4(snm1 + col * LS + o, r0, r1, r2, r3);
+        st4(w.nm1 + (long)t * RD + (row0 + col) * D_ + o, r0, r1, r2, r3);
+      }
+    });
+    __syncthreads();
+    // ---- h1 = relu(nm1.W0^T + b0) ; h2 = relu(h1.W2^T + b2)
+    mvgen<1>(p.w.W0, 32, snm1, LS, wave, lane, [&](int rb, const f32x4& acc) {
+      if (col < 3) {
+        const int o = rb * 16 + kq * 4;
+        const float4 bb = *reinterpret_cast<const float4*>(p.w.b0 + o);
+        const float r0 = fmaxf(acc[0] + bb.x, 0.f), r1 = fmaxf(acc[1] + bb.y, 0.f), r2 = fmaxf(acc[2] + bb.z, 0.f), r3 = fmaxf(acc[3] + bb.w, 0.f);
+        st4(sh1 + col * LS + o, r0, r1, r2, r3);
+        st4(w.h1 + (long)t * RD + (row0 + col) * D_ + o, r0, r1, r2, r3);
+      }
+    });
+    __syncthreads();
+    mvgen<1>(p.w.W2, 32, sh1, LS, wave, lane, [&](int rb, const f32x4& acc) {
+      if (col < 3) {
+        const int o = rb * 16 + kq * 4;
+        const float4 bb = *reinterpret_cast<const float4*>(p.w.b2 + o);
+        const float r0 = fmaxf(acc[0] + bb.x, 0.f), r1 = fmaxf(acc[1] + bb.y, 0.f), r2 = fmaxf(acc[2] + bb.z, 0.f), r3 = fmaxf(acc[3] + bb.w, 0.f);
+        st4(sh2 + col * LS + o, r0, r1, r2, r3);
+        st4(w.h2 + (long)t * RD + (row0 + col) * D_ + o, r0, r1, r2, r3);
+      }
+    });
+    __syncthreads();
+    // ---- gates
+    const bf16_t* gwt = p.gw + ((long)b * p.L + t) * 2 * D_;
+    for (int i = tid; i < S_ * D_; i += 256) {
+      const int s = i / D_, c = i - s * D_;
+      const float ig = bf2f(gwt[c]) + bf2f(sgu[s * 1032 + c]);
+      const float fg = bf2f(gwt[D_ + c]) + bf2f(sgu[s * 1032 + D_ + c]);
+      const float si = 1.f / (1.f + __expf(-ig)), sf = 1.f / (1.f + __expf(-fg));
+      const float tn = tanhf(bf2f(snm1[s * LS + c]) + bf2f(sh2[s * LS + c]));
+      const bf16_t nx = f2bf(si * tn + sf * bf2f(sm[s * LS + c]));
+      const bf16_t tnx = f2bf(tanhf(bf2f(nx)));
+      const long e = (row0 + s) * D_ + c;
+      w.si[(long)t * RD + e] = f2bf(si); w.sf[(long)t * RD + e] = f2bf(sf); w.tnm[(long)t * RD + e] = f2bf(tn);
+      w.m[(long)(t + 1) * RD + e] = nx; w.tm[(long)(t + 1) * RD + e] = tnx;
+      p.out[((long)b * p.L + t) * S_ * D_ + s * D_ + c] = nx;
+      sm[s * LS + c] = nx; stm[s * LS + c] = tnx;
+    }
+    __syncthreads();
+  }
+  if (p.m_last)
+    for (int i = tid; i < S_ * D_; i += 256) { const int s = i / D_, c = i - s * D_; p.m_last[(row0 + s) * D_ + c] = sm[s * LS + c]; }
+}
+
+// BPTT: p.w holds the TRANSPOSED weights (Wqkv -> [512][1536], U -> [512][1024], Wo / W0 / W2 -> [512][512]).
+__global__ __launch_bounds__(256) void rm_persist_bwd_kernel(const PersistP p) {
+  __shared__ __attribute__((aligned(16))) bf16_t sdg[3 * (1024 + 8)], sdqkv[3 * (1536 + 8)], sA[3 * LS], sB[3 * LS], sdnm2[3 * LS], sdnm1[3 * LS];
+  __shared__ float scarry[3 * D_], sdmd[3 * D_], sdtm[3 * D_];
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int col = lane & 15, kq = lane >> 4;
+  const Ws& w = p.ws;
+  const long R = w.R, RD = R * D_;
+  const long row0 = (long)b * S_;
+  for (int i = tid; i < S_ * D_; i += 256) scarry[i] = 0.f;
+  __syncthreads();
+  for (int t = p.L - 1; t >= 0; --t) {
+    // ---- gate backward (elementwise): dnext = dout + carry
+    for (int i = tid; i < D_; i += 256) {
+      float gi = 0.f, gf = 0.f;
+#pragma unroll
+      for (int s = 0; s < S_; ++s) {
+        const long e = (row0 + s) * D_ + i;
+        float g = bf2f(p.dout[((long)b * p.L + t) * S_ * D_ + s * D_ + i]);
+        if (t != p.L - 1) g += bf2f(f2bf(scarry[s * D_ + i]));          // the launch path hands the carry over as a 16-bit tensor
+        const float si = bf2f(w.si[(long)t * RD + e]), sf = bf2f(w.sf[(long)t * RD + e]), tn = bf2f(w.tnm[(long)t * RD + e]);
+        const bf16_t dnm2 = f2bf(g * si * (1.f - tn * tn));
+        sdnm2[s * LS + i] = dnm2;
+        sdmd[s * D_ + i] = bf2f(f2bf(g * sf));
+        const float di = g * tn * si * (1.f - si), df = g * bf2f(w.m[(long)t * RD + e]) * sf * (1.f - sf);
+        const bf16_t hdi = f2bf(di), hdf = f2bf(df);
+        sdg[s * 1032 + i] = hdi; sdg[s * 1032 + D_ + i] = hdf;
+        w.dgs[((long)t * R + row0 + s) * 2 * D_ + i] = hdi;
+        w.dgs[((long)t * R + row0 + s) * 2 * D_ + D_ + i] = hdf;
+        gi += di; gf += df;
+        // dh2 = dnm2 * (h2 > 0)
+        const bf16_t dh2 = bf2f(w.h2[(long)t * RD + e]) > 0.f ? dnm2 : (bf16_t)0;
+        sA[s * LS + i] = dh2;
+        w.dh2s[(long)t * RD + e] = dh2;
+      }
+      p.dgw[((long)b * p.L + t) * 2 * D_ + i] = f2bf(gi);
+      p.dgw[((long)b * p.L + t) * 2 * D_ + D_ + i] = f2bf(gf);
+    }
+    __syncthreads();
+    // ---- dtm = dgates . U  (K = 1024)   and   t1 = dh2 . W2 -> dh1 = t1 * (h1 > 0)
+    mvgen<2>(p.w.U, 32, sdg, 1032, wave, lane, [&](int rb, const f32x4& acc) {
+      if (col < 3) {
+        const int o = rb * 16 + kq * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sdtm[col * D_ + o + j] = bf2f(f2bf(acc[j]));
+      }
+    });
+    mvgen<1>(p.w.W2, 32, sA, LS, wave, lane, [&](int rb, const f32x4& acc) {
+      if (col < 3) {
+        const int o = rb * 16 + kq * 4;
+        const uint2 hh = *reinterpret_cast<const uint2*>(w.h1 + (long)t * RD + (row0 + col) * D_ + o);
+        // the launch path rounds t1 to 16 bits before the mask
+        const float r0 = lo_bf(hh.x) > 0.f ? bf2f(f2bf(acc[0])) : 0.f, r1 = hi_bf(hh.x) > 0.f ? bf2f(f2bf(acc[1])) : 0.f;
+        const float r2 = lo_bf(hh.y) > 0.f ? bf2f(f2bf(acc[2])) : 0.f, r3 = hi_bf(hh.y) > 0.f ? bf2f(f2bf(acc[3])) : 0.f;
+        st4(sB + col * LS + o, r0, r1, r2, r3);
+        st4(w.dh1s + (long)t * RD + (row0 + col) * D_ + o, r0, r1, r2, r3);
+      }
+    });
+    __syncthreads();
+    // ---- dnm1 = dh1 . W0 + dnm2
+    mvgen<1>(p.w.W0, 32, sB, LS, wave, lane, [&](int rb, const f32x4& acc) {
+      if (col < 3) {
+        const int o = rb * 16 + kq * 4;
+        const uint2 dd = *reinterpret_cast<const uint2*>(sdnm2 + col * LS + o);
+        const float r0 = acc[0] + lo_bf(dd.x), r1 = acc[1] + hi_bf(dd.x), r2 = acc[2] + lo_bf(dd.y), r3 = acc[3] + hi_bf(dd.y);
+        st4(sdnm1 + col * LS + o, r0, r1, r2, r3);
+        st4(w.dnm2s + (long)t * RD + (row0 + col) * D_ + o, r0, r1, r2, r3);
+      }
+    });
+    __syncthreads();
+    // ---- da = dnm1 . Wo
+    mvgen<1>(p.w.Wo, 32, sdnm1, LS, wave, lane, [&](int rb, const f32x4& acc) {
+      if (col < 3) st4(sA + col * LS + rb * 16 + kq * 4, acc[0], acc[1], acc[2], acc[3]);
+    });
+    __syncthreads();
+    // ---- attention backward
+    {
+      const int h = tid >> 5, l = tid & 31, c = h * DH + 2 * l;
+      const bf16_t* qkv_g = w.qkv + ((long)t * R + row0) * 1536;
+      float q[S_][2], k[KEYS][2], v[KEYS][2], da[S_][2];
+#pragma unroll
+      for (int i = 0; i < S_; ++i) {
+        const bf16_t* r = qkv_g + (long)i * 1536 + c;
+        const uint32_t a = *reinterpret_cast<const uint32_t*>(r), kk = *reinterpret_cast<const uint32_t*>(r + 512), vv = *reinterpret_cast<const uint32_t*>(r + 1024);
+        q[i][0] = lo_bf(a); q[i][1] = hi_bf(a); k[i][0] = lo_bf(kk); k[i][1] = hi_bf(kk); v[i][0] = lo_bf(vv); v[i][1] = hi_bf(vv);
+        const uint32_t dd = *reinterpret_cast<const uint32_t*>(sA + i * LS + c);
+        da[i][0] = lo_bf(dd); da[i][1] = hi_bf(dd);
+      }
+      const uint32_t kk = *reinterpret_cast<const uint32_t*>(p.xk + ((long)b * p.L + t) * D_ + c);
+      const uint32_t vv = *reinterpret_cast<const uint32_t*>(p.xv + ((long)b * p.L + t) * D_ + c);
+      k[3][0] = lo_bf(kk); k[3][1] = hi_bf(kk); v[3][0] = lo_bf(vv); v[3][1] = hi_bf(vv);
+      const unsigned long long seed = evk_mix_seed(p.seed + 0x51ED27ULL * (uint64_t)(t + 1), p.epoch);
+      const float* Pt = w.P + (long)t * p.B * HEADS * S_ * KEYS;
+      float dq[S_][2] = {}, dk[KEYS][2] = {}, dv[KEYS][2] = {};
+#pragma unroll
+      for (int i = 0; i < S_; ++i) {
+        float pr[KEYS], dp[KEYS], dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < KEYS; ++j) {
+          pr[j] = Pt[((long)(b * HEADS + h) * S_ + i) * KEYS + j];
+          const float ks = keep_scale(seed, ((uint64_t)(b * HEADS + h) * S_ + i) * KEYS + j, p.p_drop);
+          dp[j] = half_sum(da[i][0] * v[j][0] + da[i][1] * v[j][1]) * ks;
+          dv[j][0] += pr[j] * ks * da[i][0]; dv[j][1] += pr[j] * ks * da[i][1];
+          dot += dp[j] * pr[j];
+        }
+#pragma unroll
+        for (int j = 0; j < KEYS; ++j) {
+          const float ds = pr[j] * (dp[j] - dot) * 0.125f;
+          dq[i][0] += ds * k[j][0]; dq[i][1] += ds * k[j][1];
+          dk[j][0] += ds * q[i][0]; dk[j][1] += ds * q[i][1];
+        }
+      }
+      bf16_t* dq_g = w.dqkv + ((long)t * R + row0) * 1536;
+#pragma unroll
+      for (int i = 0; i < S_; ++i) {
+        const uint32_t a = pack2bf(dq[i][0], dq[i][1]), kk2 = pack2bf(dk[i][0], dk[i][1]), vv2 = pack2bf(dv[i][0], dv[i][1]);
+        *reinterpret_cast<uint32_t*>(sdqkv + i * 1544 + c) = a;
+        *reinterpret_cast<uint32_t*>(sdqkv + i * 1544 + 512 + c) = kk2;
+        *reinterpret_cast<uint32_t*>(sdqkv + i * 1544 + 1024 + c) = vv2;
+        *reinterpret_cast<uint32_t*>(dq_g + (long)i * 1536 + c) = a;
+        *reinterpret_cast<uint32_t*>(dq_g + (long)i * 1536 + 512 + c) = kk2;
+        *reinterpret_cast<uint32_t*>(dq_g + (long)i * 1536 + 1024 + c) = vv2;
+      }
+      *reinterpret_cast<uint32_t*>(p.dxk + ((long)b * p.L + t) * D_ + c) = pack2bf(dk[3][0], dk[3][1]);
+      *reinterpret_cast<uint32_t*>(p.dxv + ((long)b * p.L + t) * D_ + c) = pack2bf(dv[3][0], dv[3][1]);
+    }
+    __syncthreads();
+    // ---- carry = (dqkv . Wqkv + dnm1) + dmd + dtm * (1 - tm^2)
+    mvgen<3>(p.w.Wqkv, 32, sdqkv, 1544, wave, lane, [&](int rb, const f32x4& acc) {
+      if (col < 3) {
+        const int o = rb * 16 + kq * 4;
+        const uint2 dd = *reinterpret_cast<const uint2*>(sdnm1 + col * LS + o);
+        const uint2 tt = *reinterpret_cast<const uint2*>(w.tm + (long)t * RD + (row0 + col) * D_ + o);
+        const float dn[4] = {lo_bf(dd.x), hi_bf(dd.x), lo_bf(dd.y), hi_bf(dd.y)};
+        const float tm[4] = {lo_bf(tt.x), hi_bf(tt.x), lo_bf(tt.y), hi_bf(tt.y)};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float dmp = bf2f(f2bf(acc[j] + dn[j]));
+          scarry[col * D_ + o + j] = dmp + sdmd[col * D_ + o + j] + sdtm[col * D_ + o + j] * (1.f - tm[j] * tm[j]);
+        }
+      }
+    });
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -282,6 +652,17 @@ int evk_rm_forward(const void* xk, const void* xv, const void* gw, const void* m
   EVK_REQUIRE(ws_bytes >= evk_rm_ws_bytes(B, L), "rm_forward: workspace too small");
   Ws w = carve(ws, B, L);
   const long R = w.R, RD = R * D_;
+  if (rm_use_persistent(L)) {
+    // training-length walks: one persistent launch (one workgroup per sample); decode (L = 1, hundreds of hypotheses) keeps
+    // the per-token launch path below, where a weight tile is shared by all rows
+    PersistP pp{};
+    pp.w = PersistW{(const bf16_t*)Wqkv, (const bf16_t*)Wo, (const bf16_t*)W0, (const bf16_t*)W2, (const bf16_t*)U, bqkv, bo, b0, b2, bU};
+    pp.xk = (const bf16_t*)xk; pp.xv = (const bf16_t*)xv; pp.gw = (const bf16_t*)gw; pp.m0 = (const bf16_t*)m0;
+    pp.out = (bf16_t*)out; pp.m_last = (bf16_t*)m_last; pp.ws = w; pp.B = B; pp.L = L; pp.p_drop = p_drop; pp.seed = seed; pp.epoch = evk_seed_epoch_ptr();
+    ProfScope ps(EVK_FAM_GEMM, s, 2.0 * 3 * 4096.0 * 512.0 * B * L);
+    hipLaunchKernelGGL(rm_persist_fwd_kernel, dim3(B), dim3(256), 0, s, pp);
+    return evk_check_launch("rm_forward (persistent)");
+  }
   if (hipMemcpyAsync(w.m, m0, RD * 2, hipMemcpyDeviceToDevice, s) != hipSuccess) { evk_set_error("rm_forward: memcpy failed"); return EVK_ELAUNCH; }
   if (int e = evk_act_fwd(w.m, w.tm, RD, EVK_ACT_TANH, stream)) return e;   // tm[0] = tanh(m0)
   for (int t = 0; t < L; ++t) {
@@ -330,7 +711,17 @@ int evk_rm_backward(const void* dout, const void* xk, const void* xv, const void
   Ws w = carve(ws, B, L);
   const long R = w.R, RD = R * D_;
   const bf16_t* carry = nullptr;
-  for (int t = L - 1; t >= 0; --t) {
+  const bool persistent = rm_use_persistent(L);
+  if (persistent) {
+    PersistP pp{};
+    pp.w = PersistW{(const bf16_t*)Wqkvt, (const bf16_t*)Wot, (const bf16_t*)W0t, (const bf16_t*)W2t, (const bf16_t*)Ut, nullptr, nullptr, nullptr, nullptr, nullptr};
+    pp.xk = (const bf16_t*)xk; pp.xv = (const bf16_t*)xv; pp.ws = w; pp.B = B; pp.L = L; pp.p_drop = p_drop; pp.seed = seed; pp.epoch = evk_seed_epoch_ptr();
+    pp.dout = (const bf16_t*)dout; pp.dxk = (bf16_t*)dxk; pp.dxv = (bf16_t*)dxv; pp.dgw = (bf16_t*)dgw;
+    ProfScope ps(EVK_FAM_GEMM, s, 2.0 * 3 * 4096.0 * 512.0 * B * L);
+    hipLaunchKernelGGL(rm_persist_bwd_kernel, dim3(B), dim3(256), 0, s, pp);
+    if (int e = evk_check_launch("rm_backward (persistent)")) return e;
+  }
+  for (int t = L - 1; t >= 0 && !persistent; --t) {
     bf16_t* dgs = w.dgs + (long)t * R * 2 * D_;
     bf16_t* dnm2 = w.dnm2s + t * RD;            // becomes dnm1 (stack) below
     GateBP gb{(const bf16_t*)dout + (long)t * S_ * D_, (long)L * S_ * D_, carry, w.si + t * RD, w.sf + t * RD, w.tnm + t * RD, w.m + t * RD,

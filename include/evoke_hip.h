@@ -325,6 +325,12 @@ int evk_loss_scale_update(float* scale_state, float growth, float backoff, int32
  *   xk, xv (B,L,512) = x_t.Wk^T + bk / x_t.Wv^T + bv,  gw (B,L,1024) = W(x_t): hoisted out of the recurrence by the caller.
  *   Wqkv [1536][512] = [attn.linears.0; .1; .2] bf16, biases f32.  out (B,L,1536) bf16; m_last (B,3,512) optional.   */
 int64_t evk_rm_ws_bytes(int32_t B, int32_t L);
+/* evk_rm_set_persistent(1) (or EVK_RM_PERSIST=1): walks of L >= 8 tokens run as ONE persistent kernel per direction -- one
+ * workgroup per sample, the sample's memory in LDS for all L tokens, the 4 MB of weights streamed from L2 into MFMA operand
+ * registers once per token, no inter-workgroup synchronisation (cannot dead-lock).  2000 launches per training step become 2,
+ * but each CU then pulls all weights through its own L1 (~27 GB/s per CU): 15 + 12.5 ms against 5.5 + 5.8 ms for the default
+ * per-token launch sequence, which therefore stays the default; shorter walks (decode, L = 1) always use it. */
+int evk_rm_set_persistent(int32_t on);
 int evk_rm_forward(const void* xk, const void* xv, const void* gw, const void* m0, const void* Wqkv, const float* bqkv, const void* Wo,
                    const float* bo, const void* W0, const float* b0, const void* W2, const float* b2, const void* U, const float* bU,
                    void* out, void* m_last, void* ws, int64_t ws_bytes, int32_t B, int32_t L, float p_drop, uint64_t seed,

@@ -263,28 +263,71 @@ def test_contrastive_losses_match_oracle():
     close(tkd.grad / sc, tkr.grad, 5e-3, 1e-7, 'local grad t')
 
 
-def test_relational_memory_step_matches_oracle():
-    from evoke_amd import ops
+@pytest.mark.parametrize('B,L,persistent', [(2, 5, 1), (3, 12, 0), (3, 12, 1), (2, 100, 1)])
+def test_relational_memory_step_matches_oracle(B, L, persistent):
+    """RelationalMemory.forward (encoder_decoder.py:263-300) + BPTT against the fp32 oracle: the per-token launch sequence
+    (L < 8 or persistent off) and the persistent one-launch-per-direction kernels (csrc/rm.hip), up to max_seq_len = 100 tokens."""
+    from evoke_amd import hip as H, ops
     from evoke_amd.layers import RelationalMemory
     from oracle import functional as O
     ops.set_dropout_enabled(False)
+    H.check(H.lib.evk_rm_set_persistent(persistent))
+    torch.manual_seed(3)
     rm = RelationalMemory(3, 512, 8).cuda().train()
     P = {'text_decoder.model.rm.' + k: v.detach().cpu().to(BF).float() if v.dim() > 1 else v.detach().cpu().clone()
          for k, v in rm.state_dict().items()}
     for k in P:
         P[k].requires_grad_(True)
-    emb = rnd(2, 5, 512, seed=1)
+    emb = rnd(B, L, 512, seed=1)
     ed = leaf(emb)
     out = rm(ed)
-    out.float().sum().backward()
+    gsc = 1.0 / L                                   # keep the summed gradient O(1) for long walks
+    (out.float().sum() * gsc).backward()
     er = ref(emb)
     cfg = dict(rm_num_slots=3, rm_d_model=512, rm_num_heads=8)
     outr = O.rm_forward(P, er, cfg, O.Ctx(train=True))
-    outr.sum().backward()
+    (outr.sum() * gsc).backward()
     ops.set_dropout_enabled(True)
+    H.check(H.lib.evk_rm_set_persistent(0))
     close(out, outr, 3e-2, 3e-2, 'rm out')
     close(ed.grad, er.grad, 8e-2, 8e-2, 'rm demb')
     close(rm.W.weight.grad, P['text_decoder.model.rm.W.weight'].grad, 8e-2, 8e-2, 'rm dW')
+    # the other recurrence weights by relative norm (a 16-bit forward flips a few ReLU gates of the memory MLP: point-wise
+    # differences on single elements, energy-wise small)
+    from tests.helpers import rel_err
+    for what, got, key in (('dU', rm.U.weight.grad, 'U.weight'), ('dWq', rm.attn.linears[0].weight.grad, 'attn.linears.0.weight'),
+                           ('dWo', rm.attn.linears[3].weight.grad, 'attn.linears.3.weight'), ('dW0', rm.mlp[0].weight.grad, 'mlp.0.weight'),
+                           ('dW2', rm.mlp[2].weight.grad, 'mlp.2.weight')):
+        e = rel_err(got, P['text_decoder.model.rm.' + key].grad)
+        print('   rm %-4s rel-norm err %.2e' % (what, e))
+        assert e <= 5e-2, (what, e)
+
+
+def test_relational_memory_persistent_kernels_match_the_launch_sequence():
+    """The persistent kernels round every intermediate to 16 bits at the same points as the per-token launch path, so the two
+    differ only by the f32 summation order inside the GEMMs: outputs and input gradients agree to a few 16-bit ulps, with the
+    dropout of the memory attention ON (both draw the same stateless-hash masks)."""
+    from evoke_amd import hip as H, ops
+    from evoke_amd.layers import RelationalMemory
+    torch.manual_seed(4)
+    rm = RelationalMemory(3, 512, 8).cuda().train()
+    emb = rnd(4, 24, 512, seed=2)
+    res = []
+    for persistent in (0, 1):
+        H.check(H.lib.evk_rm_set_persistent(persistent))
+        ops.manual_seed(99)
+        for prm in rm.parameters():
+            prm.grad = None
+        ed = leaf(emb)
+        out = rm(ed)
+        (out.float() * rnd(4, 24, 1536, seed=5).cuda()).sum().backward()
+        res.append((out.detach().float().cpu(), ed.grad.detach().float().cpu(), rm.mlp[2].weight.grad.detach().cpu().clone(),
+                    rm.attn.linears[1].weight.grad.detach().cpu().clone()))
+    H.check(H.lib.evk_rm_set_persistent(0))
+    for a, b, what in zip(res[0], res[1], ('out', 'demb', 'dW2', 'dWk')):
+        err = float((a - b).abs().max() / (a.abs().max() + 1e-12))
+        print('   persistent vs launch path %-5s rel max err %.2e' % (what, err))
+        assert err < 2e-2, (what, err)
 
 
 def test_optim_step_matches_torch():
