@@ -666,6 +666,58 @@ def layernorm(x, gamma, beta, eps=1e-5, mode=0, dgam=None, dbet=None):
 # ----------------------------------------------------------------------------------------------------
 # multi-head attention core on projected q/k/v ([B,T,H*dh] / [B,S,H*dh] bf16, heads interleaved)
 # ----------------------------------------------------------------------------------------------------
+FUSED_ATTENTION = [os.environ.get('EVK_FUSED_ATTENTION', '1') == '1']
+
+
+class _FusedAttention(torch.autograd.Function):
+    """ONE kernel each way (csrc/attn.hip): the 32 x S score tile of a workgroup stays in LDS, softmax by wavefront shuffles,
+    K / V tiles staged through LDS; P (16-bit) is the only intermediate in HBM.  dK / dV are two K-strided batched GEMMs."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask, heads, scale, causal, p_drop, seed):
+        B, T, HD = q.shape
+        S = k.shape[1]
+        dh = HD // heads
+        Sp = _pad8(S)
+        dev = q.device
+        P = _e(B, heads, T, Sp, device=dev)
+        Pd = _e(B, heads, T, Sp, device=dev) if p_drop > 0 else None
+        out = _e(B, T, HD, device=dev)
+        mb = mq = 0
+        if mask is not None:
+            assert mask.dtype == torch.uint8 and mask.is_contiguous()
+            if mask.dim() == 2:
+                mb, mq = mask.shape[1], 0
+            else:
+                mb, mq = mask.shape[1] * mask.shape[2], mask.shape[2]
+        H.check(H.lib.evk_attention_fwd(H.ptr(q), H.ptr(k), H.ptr(v), H.ptr(out), H.ptr(P), H.ptr(Pd), H.ptr(mask), mb, mq, int(causal), B, heads,
+                                        T, S, dh, C.c_float(scale), C.c_float(p_drop), C.c_uint64(seed), H.stream()), 'attention_fwd')
+        ctx.save_for_backward(q, k, v, P, Pd if Pd is not None else P)
+        ctx.cfg = (B, T, S, Sp, HD, heads, dh, scale, p_drop, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, P, Pv = ctx.saved_tensors
+        B, T, S, Sp, HD, heads, dh, scale, p_drop, seed = ctx.cfg
+        dev = q.device
+        dout = dout.contiguous()
+        dS = _e(B, heads, T, Sp, device=dev)
+        dQ = _e(B, T, HD, device=dev)
+        H.check(H.lib.evk_attention_bwd(H.ptr(dout), H.ptr(k), H.ptr(v), H.ptr(P), H.ptr(dS), H.ptr(dQ), B, heads, T, S, dh, C.c_float(scale),
+                                        C.c_float(p_drop), C.c_uint64(seed), H.stream()), 'attention_bwd')
+        dV = dK = None
+        if ctx.needs_input_grad[2]:          # dV = P'^T . dO
+            dV = _e(B, S, HD, device=dev)
+            gemm(Pv, dout, dV, S, dh, T, a_mode=H.A_KSTR, b_mode=H.B_KSTR, lda=Sp, ldb=HD, ldc=HD, batch=(B, heads),
+                 sA=(heads * T * Sp, T * Sp), sB=(T * HD, dh), sC=(S * HD, dh))
+        if ctx.needs_input_grad[1]:          # dK = dS^T . Q   (dS carries the 1/sqrt(d) factor)
+            dK = _e(B, S, HD, device=dev)
+            gemm(dS, q, dK, S, dh, T, a_mode=H.A_KSTR, b_mode=H.B_KSTR, lda=Sp, ldb=HD, ldc=HD, batch=(B, heads),
+                 sA=(heads * T * Sp, T * Sp), sB=(T * HD, dh), sC=(S * HD, dh))
+        return dQ, dK, dV, None, None, None, None, None, None
+
+
 class _Attention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, mask, heads, scale, causal, p_drop, seed):
@@ -740,6 +792,8 @@ def attention(q, k, v, heads, mask=None, causal=False, p_drop=0.0, training=Fals
     if scale is None:
         scale = 1.0 / math.sqrt(dh)
     p = float(p_drop) if (training and DROPOUT_ENABLED[0]) else 0.0
+    if FUSED_ATTENTION[0] and H.lib.evk_attention_supported(k.shape[1], dh):
+        return _FusedAttention.apply(q, k, v, mask, heads, float(scale), causal, p, next_seed() if p > 0 else 0)
     return _Attention.apply(q, k, v, mask, heads, float(scale), causal, p, next_seed() if p > 0 else 0)
 
 

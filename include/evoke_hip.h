@@ -297,6 +297,24 @@ int evk_optim_step_scaled(float* p, const float* g, float* m, float* v, float* v
                           float beta1, float beta2, float eps, float weight_decay, float clip, int64_t step, float grad_scale,
                           evk_stream_t stream);
 
+/* ---- fused attention core (attn.hip): softmax(alpha * Q.K^T [masked]) [dropout] . V per head, forward and backward ----------
+ * replaces `attention` (modules/encoder_decoder.py:20-28), BertSelfAttention's matmul/softmax/dropout/matmul
+ * (models/language_encoder/bert_model.py:262-341), ScaledDotProductAttention's core (modules/utils_v0511.py:263-278) and HF
+ * GPT2Attention._attn of the distilgpt2 backend.  q [B][T][heads*dh], k / v [B][S][heads*dh] (heads interleaved in the feature
+ * dimension), out [B][T][heads*dh], all in the library's 16-bit storage format; dh a multiple of 64, S <= 640
+ * (evk_attention_supported).  The f32 score tile of 32 query rows lives in LDS only.
+ *   fwd: probs [B][heads][T][pad8(S)] receives the pre-dropout probabilities (the backward's input), probs_dropped the
+ *        post-dropout ones (required iff p_drop > 0; dropout = stateless hash of (seed + epoch, element index)); mask uint8, 1 =
+ *        attend: key mask (mask_q_stride 0, mask_batch_stride = S) or per-query mask (mask_q_stride = S, batch stride T*S).
+ *   bwd: dq = dS.K with dS = P * (dropout'(dO.V^T) - rowsum) * scale; ds [B][heads][T][pad8(S)] (16-bit) is written for the
+ *        caller's dK = dS^T.Q product, dV = P'^T.dO uses probs_dropped -- both are K-strided batched evk_gemm launches.     */
+int evk_attention_supported(int32_t S, int32_t dh);
+int evk_attention_fwd(const void* q, const void* k, const void* v, void* out, void* probs, void* probs_dropped, const unsigned char* mask,
+                      int64_t mask_batch_stride, int32_t mask_q_stride, int32_t causal, int64_t B, int32_t heads, int32_t T, int32_t S,
+                      int32_t dh, float scale, float p_drop, uint64_t seed, evk_stream_t stream);
+int evk_attention_bwd(const void* dout, const void* k, const void* v, const void* probs, void* ds, void* dq, int64_t B, int32_t heads,
+                      int32_t T, int32_t S, int32_t dh, float scale, float p_drop, uint64_t seed, evk_stream_t stream);
+
 /* Dynamic loss scaling with a GLOBAL overflow skip, entirely on the device (no host read-back, HIP-graph capturable).  The
  * reference trains in fp32 (modules/trainer_v0401.py:256-263, 426-435) and has none; torch.cuda.amp.GradScaler is the public
  * counterpart (growth 2, backoff 0.5).  scale_state = float[4] in device memory: [0] loss scale, [1] consecutive good steps,

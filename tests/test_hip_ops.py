@@ -96,14 +96,20 @@ def test_linear_fwd_bwd(act):
 
 
 @pytest.mark.parametrize('cfg', [dict(B=3, T=37, S=50, Hh=12, dh=64, mask='key'), dict(B=2, T=20, S=20, Hh=8, dh=64, mask='causal'),
-                                 dict(B=2, T=145, S=290, Hh=8, dh=256, mask=None), dict(B=4, T=3, S=4, Hh=8, dh=64, mask=None)])
+                                 dict(B=2, T=145, S=290, Hh=8, dh=256, mask=None), dict(B=4, T=3, S=4, Hh=8, dh=64, mask=None),
+                                 dict(B=2, T=145, S=435, Hh=8, dh=2048, mask=None),          # multi-view fusion: 3 siblings, 2048-wide heads
+                                 dict(B=2, T=100, S=100, Hh=8, dh=64, mask='causal'),        # decoder self-attention at max_seq_len
+                                 dict(B=3, T=33, S=70, Hh=4, dh=64, mask='full')])           # per-query mask [B, T, S]
 def test_attention(cfg):
     from evoke_amd import ops
     B, T, S, Hh, dh = cfg['B'], cfg['T'], cfg['S'], cfg['Hh'], cfg['dh']
     q, k, v = rnd(B, T, Hh * dh, seed=1), rnd(B, S, Hh * dh, seed=2), rnd(B, S, Hh * dh, seed=3)
     do = rnd(B, T, Hh * dh, seed=4)
     mask = None
-    if cfg['mask']:
+    if cfg['mask'] == 'full':
+        mask = (torch.rand(B, T, S, generator=torch.Generator().manual_seed(9)) > 0.3).to(torch.uint8)
+        mask[:, :, 0] = 1
+    elif cfg['mask']:
         mask = torch.ones(B, S, dtype=torch.uint8)
         for i in range(B):
             mask[i, S - 3 * i:] = 0
@@ -113,7 +119,7 @@ def test_attention(cfg):
     qr, kr, vr = ref(q), ref(k), ref(v)
     sc = torch.einsum('bthd,bshd->bhts', qr.view(B, T, Hh, dh), kr.view(B, S, Hh, dh)) / math.sqrt(dh)
     if mask is not None:
-        sc = sc.masked_fill(mask[:, None, None, :] == 0, -1e9)
+        sc = sc.masked_fill((mask[:, None, :, :] if mask.dim() == 3 else mask[:, None, None, :]) == 0, -1e9)
     if cfg['mask'] == 'causal':
         sc = sc.masked_fill(torch.tril(torch.ones(T, S)) == 0, -1e9)
     orf = torch.einsum('bhts,bshd->bthd', torch.softmax(sc, -1), vr.view(B, S, Hh, dh)).reshape(B, T, Hh * dh)
@@ -122,6 +128,37 @@ def test_attention(cfg):
     close(qd.grad, qr.grad, 3e-2, 3e-2, 'dq')
     close(kd.grad, kr.grad, 3e-2, 3e-2, 'dk')
     close(vd.grad, vr.grad, 3e-2, 3e-2, 'dv')
+
+
+def test_fused_attention_dropout_through_the_c_abi():
+    """evk_attention_fwd / evk_attention_bwd (csrc/attn.hip) called directly with attention dropout 0.1: the post-dropout
+    probabilities the kernel writes define the keep mask; output, dQ and dS are then checked against the f32 formulas with THAT
+    mask, and the same seed must reproduce the same mask in the backward (stateless hash + seed epoch)."""
+    import ctypes as C
+    from evoke_amd import hip as H
+    B, T, S, Hh, dh, p = 2, 45, 77, 4, 64, 0.1
+    Sp = (S + 7) // 8 * 8
+    q, k, v, do = (rnd(B, n, Hh * dh, seed=i).to(BF).cuda() for i, n in ((1, T), (2, S), (3, S), (4, T)))
+    out, dq = torch.empty_like(q), torch.empty_like(q)
+    P, Pd, dS = (torch.zeros(B, Hh, T, Sp, dtype=BF, device='cuda') for _ in range(3))
+    scale, seed = 1.0 / math.sqrt(dh), 1234567
+    H.check(H.lib.evk_attention_fwd(H.ptr(q), H.ptr(k), H.ptr(v), H.ptr(out), H.ptr(P), H.ptr(Pd), None, 0, 0, 0, B, Hh, T, S, dh,
+                                    C.c_float(scale), C.c_float(p), C.c_uint64(seed), H.stream()))
+    H.check(H.lib.evk_attention_bwd(H.ptr(do), H.ptr(k), H.ptr(v), H.ptr(P), H.ptr(dS), H.ptr(dq), B, Hh, T, S, dh, C.c_float(scale),
+                                    C.c_float(p), C.c_uint64(seed), H.stream()))
+    qf, kf, vf, dof = (t.float().cpu().view(B, -1, Hh, dh) for t in (q, k, v, do))
+    Pf, Pdf = P.float().cpu()[..., :S], Pd.float().cpu()[..., :S]
+    pr = torch.softmax(torch.einsum('bthd,bshd->bhts', qf, kf) * scale, -1)
+    keep = (Pdf != 0).float()
+    frac = float(keep.mean())
+    assert abs(frac - (1 - p)) < 0.02, frac
+    close(Pf, pr, 1e-2, 1e-3, 'P')
+    close(Pdf, pr * keep / (1 - p), 1e-2, 1e-3, 'P dropped')
+    close(out.view(B, T, Hh, dh), torch.einsum('bhts,bshd->bthd', Pdf, vf), 1e-2, 1e-2, 'out')
+    dP = torch.einsum('bthd,bshd->bhts', dof, vf) * keep / (1 - p)
+    dSr = Pf * (dP - (dP * Pf).sum(-1, keepdim=True)) * scale
+    close(dS.float().cpu()[..., :S], dSr, 2e-2, 2e-3, 'dS')
+    close(dq.view(B, T, Hh, dh), torch.einsum('bhts,bshd->bthd', dS.float().cpu()[..., :S], kf), 1e-2, 1e-2, 'dQ')
 
 
 @pytest.mark.parametrize('C_,relu,res', [(64, True, False), (256, True, True), (2048, False, False)])
@@ -289,12 +326,17 @@ def test_relational_memory_step_matches_oracle(B, L, persistent):
     (outr.sum() * gsc).backward()
     ops.set_dropout_enabled(True)
     H.check(H.lib.evk_rm_set_persistent(0))
-    close(out, outr, 3e-2, 3e-2, 'rm out')
-    close(ed.grad, er.grad, 8e-2, 8e-2, 'rm demb')
-    close(rm.W.weight.grad, P['text_decoder.model.rm.W.weight'].grad, 8e-2, 8e-2, 'rm dW')
+    from tests.helpers import rel_err
+    if L <= 20:
+        close(out, outr, 3e-2, 3e-2, 'rm out')
+        close(ed.grad, er.grad, 8e-2, 8e-2, 'rm demb')
+        close(rm.W.weight.grad, P['text_decoder.model.rm.W.weight'].grad, 8e-2, 8e-2, 'rm dW')
+    else:       # 100 recurrent tokens in 16-bit storage: single elements drift (measured max 0.11 at rel-norm 2.6e-3): compare by norm
+        e_out, e_emb, e_w = rel_err(out, outr), rel_err(ed.grad, er.grad), rel_err(rm.W.weight.grad, P['text_decoder.model.rm.W.weight'].grad)
+        print('   rm L=%d rel-norm err: out %.2e demb %.2e dW %.2e' % (L, e_out, e_emb, e_w))
+        assert e_out <= 1e-2 and e_emb <= 5e-2 and e_w <= 5e-2, (e_out, e_emb, e_w)
     # the other recurrence weights by relative norm (a 16-bit forward flips a few ReLU gates of the memory MLP: point-wise
     # differences on single elements, energy-wise small)
-    from tests.helpers import rel_err
     for what, got, key in (('dU', rm.U.weight.grad, 'U.weight'), ('dWq', rm.attn.linears[0].weight.grad, 'attn.linears.0.weight'),
                            ('dWo', rm.attn.linears[3].weight.grad, 'attn.linears.3.weight'), ('dW0', rm.mlp[0].weight.grad, 'mlp.0.weight'),
                            ('dW2', rm.mlp[2].weight.grad, 'mlp.2.weight')):
