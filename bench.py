@@ -98,33 +98,37 @@ def cpu_baseline(model, kind, res, L, Li, seconds_budget=25.0):
                        'median of %d steps after 1 warm-up' % (kind, B, res, res, max(1, len(times) - 1)))
 
 
-def bench_decode(a, rank, world, dev):
-    """BASELINE.json configs[4]: EVOKE-384 inference, beam search (default beam 4), bs 64, max_seq_len 100, replicas only.
-    One step = the whole FineTune.forward(mode='inference') of one batch (visual extractor + fusion + beam search); every
-    hypothesis is extended for all max_seq_len steps as in the reference (finished beams keep running with -1000), so
-    tokens = batch x max_seq_len per step."""
-    from evoke_amd import hip as H, ops
-    from evoke_amd.model_pretrain_finetune import FineTune
+def decode_record(model, a, rank, world, dev, with_cpu):
+    """BASELINE.json configs[4]: EVOKE-384 inference, beam search (default beam 4), bs 64 studies x 2 views, max_seq_len 100,
+    replicas only.  One step = the whole FineTune.forward(mode='inference') of one batch (visual extractor + fusion + beam search);
+    every hypothesis is extended for all max_seq_len steps as in the reference (finished beams keep running with -1000), so
+    tokens = batch x max_seq_len per step.  Returns the record dict (rank 0) or None.
+    roofline: the per-token decode step (one HIP-graph replay: ~100 kernels) against HBM -- achieved = ALGORITHMIC bytes of one
+    step (the decoder-step weights once + per hypothesis the self-attention cache up to t, the cross-attention
+    K/V of the 144 patches and the 1536-wide memory row, in 16-bit) / measured step time (HIP events around the replays)."""
+    from evoke_amd import decode as DEC, hip as H, metrics
     from tests.helpers import load_tokenizer
-    torch.manual_seed(9233)
-    args = make_args('test')
-    args['beam_size'] = a.beam
-    B = a.batch if a.batch != 32 else 64
-    model = FineTune(args, load_tokenizer(), 'mimic_cxr').to(dev).eval()
-    b = synth_batch('finetune', B, a.views, a.res, 100, 30, dev, 1000 + rank)
+    beam, B, L = a.beam, a.decode_batch, 100
+    model.eval()
+    model.args['beam_size'], model.args['max_seq_len'] = beam, L
+    b = synth_batch('finetune', B, a.views, a.res, L, 30, dev, 2000 + rank)
 
-    def step():
+    def step(bb=b):
         with torch.no_grad():
-            return model(b['images'], b['ids'], b['masks'], b['pids'], b['inc'], b['inc_masks'], mode='inference')[1]
+            return model(bb['images'], bb['ids'], bb['masks'], bb['pids'], bb['inc'], bb['inc_masks'], mode='inference')[1]
 
-    for _ in range(a.warmup):
+    for _ in range(max(1, min(a.warmup, 2))):
         step()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
+    n = max(2, min(a.steps, 4))
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    step_ms = []
+    for _ in range(n):
         seq = step()
+        ev0, ev1, cnt = DEC.stats['step_events']
+        step_ms.append((ev0, ev1, cnt))
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -133,17 +137,77 @@ def bench_decode(a, rank, world, dev):
     if world > 1:
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
     if rank != 0:
-        return
-    L = args['max_seq_len']
-    toks = B * L * a.steps * world
-    print(json.dumps({
-        'metric': 'decode tokens/sec (beam search, %d^2)' % a.res, 'value': toks / float(tt.item()), 'unit': 'tokens/s', 'n_gpus': world,
-        'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * float(tt.item()) / a.steps, 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': H.STORE, 'data': 'synthetic',
+        return None
+    dt = float(tt.item())
+    per_step_ms = sum(e0.elapsed_time(e1) for e0, e1, c in step_ms) / max(1, sum(c for _, _, c in step_ms))
+    td = model.text_decoder
+    w_params = sum(p.numel() for m in (td.model.decoder, td.model.rm, td.logit) for p in m.parameters())
+    R = B * beam
+    t_mean = (L - 1) / 2.0
+    state_bytes = (t_mean * 3 * 2 * 512 + 144 * 3 * 2 * 512 + 1536) * 2.0
+    alg_bytes = 2.0 * w_params + R * state_bytes
+    ach = alg_bytes / (per_step_ms * 1e-3) / 1e9
+    rec = {
+        'metric': 'decode tokens/sec (beam search, %d^2)' % a.res, 'value': B * L * n * world / dt, 'unit': 'tokens/s', 'steps': n,
+        'ms_per_batch': 1e3 * dt / n, 'higher_is_better': True, 'dtype': H.STORE,
         'config': {'workload': 'EVOKE-%d inference: beam=%d, batch %d studies x %d views, max_seq_len %d (all steps run, as the reference), '
                                'incremental decoder state, visual extractor + fusion included, V=%d, random-init weights'
-                               % (a.res, a.beam, B, a.views, L, V), 'parallelism': 'replicas x%d' % world,
-                   'mean_generated_len': float((seq != 0).sum(1).float().mean().item())}}))
+                               % (a.res, beam, B, a.views, L, V), 'parallelism': 'replicas x%d' % world,
+                   'mean_generated_len': float((seq != 0).sum(1).float().mean().item()), 'hip_graph_step': DEC.stats.get('graph'),
+                   'fused_beam_bookkeeping': DEC.stats.get('fused_bookkeeping')},
+        'roofline': {'bound': 'hbm', 'kernel': 'per-token decode step (HIP graph: RM step, 3 decoder layers, logits, log-softmax, beam step)',
+                     'achieved': ach, 'peak': 8000.0, 'unit': 'GB/s', 'frac': ach / 8000.0, 'traffic': None,
+                     'algorithmic_bytes_per_step': alg_bytes, 'step_ms': per_step_ms, 'hypotheses': R,
+                     'note': 'the step is launch-latency bound (~100 dependent kernels of a few us), not bandwidth bound'},
+    }
+    if with_cpu:
+        try:
+            rec['cpu_baseline'], rec['parity'] = decode_cpu_baseline(model, a, dev, beam, L)
+        except Exception as e:          # noqa: BLE001
+            rec['cpu_baseline'] = {'value': None, 'unit': 'tokens/s', 'cores': os.cpu_count(), 'kind': 'port', 'sample': 'failed: %r' % (e,)}
+    return rec
+
+
+def decode_cpu_baseline(model, a, dev, beam, L):
+    """The CPU oracle's generation (oracle/beam.py: full-prefix re-decode per step, as the reference) on a bounded sample -- 2
+    studies x 2 views -- and, on the SAME inputs and weights, the engine's sequences: token agreement + BLEU-4 of the engine's
+    reports against the oracle's (evoke_amd/metrics.py)."""
+    from evoke_amd import metrics
+    from oracle import beam as OB, functional as O
+    from tests.helpers import load_tokenizer
+    threads = max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get('EVK_CPU_THREADS', '16'))))
+    torch.set_num_threads(threads)
+    Bc = 2
+    b = synth_batch('finetune', Bc, a.views, a.res, L, 30, 'cpu', 11)
+    with torch.no_grad():
+        hip_seq = model(b['images'].to(dev), b['ids'].to(dev), b['masks'].to(dev), b['pids'], b['inc'], b['inc_masks'], mode='inference')[1].cpu()
+    P = {k: (v.detach().float() if v.is_floating_point() else v.detach()).cpu() for k, v in model.state_dict().items() if not k.endswith('position_ids')}
+    cfg = dict(O.DEFAULT_CFG, max_seq_len=L, beam_size=beam)
+    t0 = time.time()
+    with torch.no_grad():
+        x, m = O.finetune_encoder_states(P, b['images'], b['pids'], Bc, b['inc'], b['inc_masks'], cfg, O.Ctx())
+        ref_seq = OB.beam_search(P, x, m, cfg, V - 2, V - 1)
+    dt = time.time() - t0
+    tok = load_tokenizer()
+    same_seq, same_tok = metrics.token_agreement(hip_seq.tolist(), ref_seq.tolist())
+    bl = metrics.bleu(OB.decode_texts(tok, ref_seq), OB.decode_texts(tok, hip_seq))
+    base = dict(value=Bc * L / dt, unit='tokens/s', cores=threads, kind='port',
+                sample='oracle beam search (full-prefix re-decode per step, as the reference) incl. encoder, beam %d, %d studies x %d views %dx%d, '
+                       '%d steps, one run of %.1f s' % (beam, Bc, a.views, a.res, a.res, L, dt))
+    par = dict(identical_sequences=same_seq, token_agreement=same_tok, bleu4_vs_oracle=bl[3], studies=Bc,
+               note='engine vs CPU oracle on the same inputs and (random-init) weights')
+    return base, par
+
+
+def bench_decode(a, rank, world, dev):
+    from evoke_amd.model_pretrain_finetune import FineTune
+    from tests.helpers import load_tokenizer
+    torch.manual_seed(9233)
+    model = FineTune(make_args('test'), load_tokenizer(), 'mimic_cxr').to(dev).eval()
+    rec = decode_record(model, a, rank, world, dev, with_cpu=(world == 1 and not a.no_cpu_baseline))
+    if rank == 0:
+        rec.update(n_gpus=world, warmup=a.warmup, scaling='weak', vs_baseline=None, data='synthetic', ms_per_step=rec['ms_per_batch'])
+        print(json.dumps(rec))
 
 
 def main():
@@ -153,6 +217,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='finetune', choices=['finetune', 'pretrain', 'decode'])
     ap.add_argument('--beam', type=int, default=4)
+    ap.add_argument('--decode-batch', type=int, default=64, help='studies per GPU of the decode workload (BASELINE config 5: 64)')
+    ap.add_argument('--no-decode', action='store_true', help='skip the decode sub-record of the default line')
     ap.add_argument('--res', type=int, default=384)
     ap.add_argument('--batch', type=int, default=32, help='studies per GPU')
     ap.add_argument('--views', type=int, default=2)
@@ -272,6 +338,16 @@ def main():
     if world > 1:
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
     dt = float(tt.item())
+    # BASELINE.json's metric is two numbers: the train-step studies/s above and decode tokens/s (config 5) -- measured on the same
+    # model object right after the timed training region (every rank: replicas)
+    dec_rec = None
+    if kind == 'finetune' and not a.no_decode:
+        torch.cuda.set_stream(torch.cuda.default_stream(dev))
+        try:
+            dec_rec = decode_record(model, a, rank, world, dev, with_cpu=(world == 1 and not a.no_cpu_baseline))
+        except Exception as e:          # noqa: BLE001 -- the training measurement must still be reported
+            dec_rec = {'metric': 'decode tokens/sec', 'value': None, 'error': repr(e)}
+        model.train()
     if rank != 0:
         return
     studies = a.batch * world * a.steps
@@ -308,6 +384,8 @@ def main():
                            'launches_per_step': n / psteps, 'event_timed': '1 extra step after the timed region, single stream', 'avg_launch_us': 1e3 * ms / max(n, 1),
                            'gemm_ms_per_step': ms / psteps, 'launched_tflops': launched_flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
                            'family_ms_per_step': {k: v[0] / psteps for k, v in fam.items()}}
+    if kind == 'finetune' and not a.no_decode and dec_rec is not None:
+        out['decode'] = dec_rec
     if world == 1 and not a.no_cpu_baseline:
         try:
             out['cpu_baseline'] = cpu_baseline(model, kind, a.res, L, Li)

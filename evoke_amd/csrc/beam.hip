@@ -1,0 +1,143 @@
+// beam.hip -- one kernel per generated token for ALL the beam bookkeeping of CaptionModel.beam_search / beam_step
+// (modules/caption_model.py:51-106: candidate scores = running sum + log-prob, flat descending sort over beam x (V+1), top-beam,
+// state / sequence reorder; :174-189: beams that emit [EOS] -- or every beam at the last position -- are recorded as finished
+// with p = running sum and get -1000 on their running sum; modules/att_model.py:133-135: the best finished beam wins).
+// The reference does this with a per-sample Python loop and .item() syncs; the first engine with ~15 torch glue ops per token
+// inside the captured decode step (gather / where / max / index_copy kernels).  Here: one workgroup per sample --
+//   1. every thread keeps the top-`beam` of its strided share of the beam x (V+1) candidates, `beam` rounds of a block arg-max
+//      (ties -> lowest flat index, i.e. torch.sort(descending=True)'s order on distinct scores) pick the winners;
+//   2. the sample's old sequences, cache row tables and relational-memory rows are staged in LDS and rewritten IN PLACE in the
+//      winners' order (a sample's hypotheses only permute among themselves), the new token goes to position *pos;
+//   3. finished-beam tracking and the -1000 penalty, the next step's input tokens.
+#include "common.h"
+
+namespace {
+
+constexpr int KMAX = 8;
+
+struct BeamP {
+  const float* logp; int ld;          // [B*beam][ld] f32 log-probs of the step, V1 valid columns
+  int V1, beam, max_len, eos, force_end;
+  const long long* pos;               // device scalar: position being written
+  float* beam_sum;                    // [B][beam] running sums (in / out)
+  long long* beam_seq;                // [B][beam][max_len] (in place)
+  float* best_p; long long* best_seq; // [B], [B][max_len]
+  long long* words;                   // [B*beam] out: tokens fed to the next decoder step
+  bf16_t* mem; int mem_row;           // relational-memory state [B*beam][mem_row] (in place) or null
+  int* anc; int anc_cols;             // cache row table [B*beam][anc_cols] (in place) or null
+};
+
+__global__ __launch_bounds__(256) void beam_step_kernel(const BeamP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float s_val[4]; __shared__ int s_idx[4];
+  __shared__ float win_v[KMAX]; __shared__ int win_i[KMAX];
+  __shared__ int s_best;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int beam = p.beam, n = beam * p.V1;
+  // ---- 1. top-`beam` candidates
+  float bv[KMAX]; int bi[KMAX];
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j) { bv[j] = -INFINITY; bi[j] = 0x7fffffff; }
+  for (int c = tid; c < n; c += 256) {
+    const int src = c / p.V1, w = c - src * p.V1;
+    float v = p.beam_sum[b * beam + src] + p.logp[(long)(b * beam + src) * p.ld + w];
+    int id = c;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j)
+      if (j < beam && (v > bv[j] || (v == bv[j] && id < bi[j]))) { const float tv = bv[j]; const int ti = bi[j]; bv[j] = v; bi[j] = id; v = tv; id = ti; }
+  }
+  for (int r = 0; r < beam; ++r) {
+    float best = bv[0]; int bid = bi[0];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bid, o, 64);
+      if (ov > best || (ov == best && oi < bid)) { best = ov; bid = oi; }
+    }
+    if (lane == 0) { s_val[wave] = best; s_idx[wave] = bid; }
+    __syncthreads();
+    if (tid == 0) {
+      float fv = s_val[0]; int fi = s_idx[0];
+      for (int w = 1; w < 4; ++w) if (s_val[w] > fv || (s_val[w] == fv && s_idx[w] < fi)) { fv = s_val[w]; fi = s_idx[w]; }
+      win_v[r] = fv; win_i[r] = fi;
+    }
+    __syncthreads();
+    if (bi[0] == win_i[r]) {            // the owner pops its head
+#pragma unroll
+      for (int j = 0; j + 1 < KMAX; ++j) { bv[j] = bv[j + 1]; bi[j] = bi[j + 1]; }
+      bv[KMAX - 1] = -INFINITY; bi[KMAX - 1] = 0x7fffffff;
+    }
+  }
+  // ---- 2. stage the sample's rows, rewrite them in the winners' order
+  const long pos = p.pos[0];
+  long long* seq = p.beam_seq + (long)b * beam * p.max_len;
+  long long* l_seq = reinterpret_cast<long long*>(smem);                               // [beam][max_len]
+  int* l_anc = reinterpret_cast<int*>(l_seq + (size_t)beam * p.max_len);               // [beam][anc_cols]
+  uint32_t* l_mem = reinterpret_cast<uint32_t*>(l_anc + (size_t)beam * (p.anc ? p.anc_cols : 0));   // [beam][mem_row / 2]
+  for (int i = tid; i < beam * p.max_len; i += 256) l_seq[i] = seq[i];
+  if (p.anc) for (int i = tid; i < beam * p.anc_cols; i += 256) l_anc[i] = p.anc[(long)b * beam * p.anc_cols + i];
+  const int mw = p.mem_row / 2;
+  if (p.mem) {
+    const uint32_t* gm = reinterpret_cast<const uint32_t*>(p.mem + (long)b * beam * p.mem_row);
+    for (int i = tid; i < beam * mw; i += 256) l_mem[i] = gm[i];
+  }
+  __syncthreads();
+  for (int i = tid; i < beam * p.max_len; i += 256) {
+    const int j = i / p.max_len, c = i - j * p.max_len;
+    const int src = win_i[j] / p.V1;
+    seq[i] = c == pos ? (long long)(win_i[j] - src * p.V1) : l_seq[src * p.max_len + c];
+  }
+  if (p.anc)
+    for (int i = tid; i < beam * p.anc_cols; i += 256) {
+      const int j = i / p.anc_cols, c = i - j * p.anc_cols;
+      p.anc[(long)b * beam * p.anc_cols + i] = l_anc[(win_i[j] / p.V1) * p.anc_cols + c];
+    }
+  if (p.mem) {
+    uint32_t* gm = reinterpret_cast<uint32_t*>(p.mem + (long)b * beam * p.mem_row);
+    for (int i = tid; i < beam * mw; i += 256) {
+      const int j = i / mw, c = i - j * mw;
+      gm[i] = l_mem[(win_i[j] / p.V1) * mw + c];
+    }
+  }
+  // ---- 3. finished beams (best p so far; the earlier / lower beam index wins ties), the -1000 penalty, next tokens
+  if (tid == 0) {
+    float pv = -INFINITY; int pi = -1;
+    for (int j = 0; j < beam; ++j) {
+      const int word = win_i[j] % p.V1;
+      const bool end = p.force_end || word == p.eos;
+      if (end && win_v[j] > pv) { pv = win_v[j]; pi = j; }
+      p.beam_sum[b * beam + j] = win_v[j] - (end ? 1000.f : 0.f);
+      p.words[b * beam + j] = word;
+    }
+    int take = -1;
+    if (pi >= 0 && pv > p.best_p[b]) { p.best_p[b] = pv; take = pi; }
+    s_best = take;
+  }
+  __syncthreads();
+  if (s_best >= 0) {
+    const int j = s_best, src = win_i[j] / p.V1;
+    for (int c = tid; c < p.max_len; c += 256)
+      p.best_seq[(long)b * p.max_len + c] = c == pos ? (long long)(win_i[j] % p.V1) : l_seq[src * p.max_len + c];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int evk_beam_step(const float* logp, int32_t ld, int32_t V1, int32_t beam, int32_t B, int32_t max_len, const int64_t* pos, int32_t eos,
+                  int32_t force_end, float* beam_sum, int64_t* beam_seq, float* best_p, int64_t* best_seq, int64_t* words, void* mem,
+                  int32_t mem_row, int32_t* anc, int32_t anc_cols, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(logp && pos && beam_sum && beam_seq && best_p && best_seq && words && B > 0 && V1 > 0 && ld >= V1 && max_len > 0, "beam_step: bad args");
+  EVK_REQUIRE(beam >= 1 && beam <= KMAX && beam <= V1, "beam_step: beam must be in [1, %d]", KMAX);
+  EVK_REQUIRE((!mem || (mem_row > 0 && mem_row % 2 == 0)) && (!anc || anc_cols > 0), "beam_step: bad state geometry");
+  const size_t lds = (size_t)beam * max_len * 8 + (anc ? (size_t)beam * anc_cols * 4 : 0) + (mem ? (size_t)beam * mem_row * 2 : 0);
+  EVK_REQUIRE(lds <= 60000, "beam_step: %zu bytes of per-sample state do not fit the staging buffer", lds);
+  BeamP p{logp, ld, V1, beam, max_len, eos, force_end, reinterpret_cast<const long long*>(pos), beam_sum, reinterpret_cast<long long*>(beam_seq),
+          best_p, reinterpret_cast<long long*>(best_seq), reinterpret_cast<long long*>(words), (bf16_t*)mem, mem_row, anc, anc_cols};
+  ProfScope ps(EVK_FAM_NORM, s);
+  hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(256), lds, s, p);
+  return evk_check_launch("beam_step");
+}
+
+}  // extern "C"

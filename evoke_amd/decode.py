@@ -20,6 +20,8 @@ from .ops import BF16, F32
 
 _INDIRECT = [os.environ.get('EVK_DECODE_INDIRECT', '1') != '0']      # beam search re-orders a row table, not the K/V caches
 _GRAPH_ENABLED = [True]          # capture the per-token launch sequence in a HIP graph (set False to debug eagerly)
+_FUSED_BOOK = [os.environ.get('EVK_DECODE_FUSED_BOOK', '1') != '0']      # beam bookkeeping as one kernel per token (csrc/beam.hip)
+stats = {}                       # facts about the last beam_search call (bench.py reads the per-token step time from here)
 
 
 def _topk(x, k):
@@ -275,6 +277,17 @@ def beam_search(dec, enc_states, enc_mask, args, return_scores=False):
             beam_sum.sub_(1000.0 * is_end.to(F32))
             return word_ix
 
+        words = torch.empty(B * beam, dtype=torch.long, device=dev)
+
+        def book_kernel(last):
+            """book(None, last) as ONE launch (csrc/beam.hip): top-beam, sequence / cache-row-table / relational-memory reorder in
+            place, finished-beam tracking, -1000 penalty, next input tokens."""
+            lp = logp[0]
+            H.check(H.lib.evk_beam_step(H.ptr(lp), lp.shape[-1], V1, beam, B, max_len, H.ptr(pos), dec.eos_idx, int(last), H.ptr(beam_sum),
+                                        H.ptr(beam_seq), H.ptr(best_p), H.ptr(best_seq), H.ptr(words), H.ptr(st.mem), st.mem[0].numel(),
+                                        H.ptr(st.anc), st.anc.shape[1], H.stream()), 'beam_step')
+            return words
+
         nb = 1
         logp = [logp]
         # t = 0 (the hypothesis count grows from B to B*beam here) runs eagerly
@@ -287,9 +300,12 @@ def beam_search(dec, enc_states, enc_mask, args, return_scores=False):
             logp_buf = st.step_static(w.reshape(-1), pos, (ar <= pos).expand(R, -1).to(torch.uint8).contiguous()).clone()
             logp[0] = logp_buf
 
+            fused_book = _FUSED_BOOK[0] and st.anc is not None and beam_seq.is_contiguous() and st.mem.is_contiguous()
+            stats['fused_bookkeeping'] = bool(fused_book)
+
             def body():
                 """steps 1 .. max_len-2: bookkeeping at position `pos`, then the decoder step that writes position pos+1."""
-                w_ = book(None, False)
+                w_ = book_kernel(False) if fused_book else book(None, False)
                 pos.add_(1)
                 kmask = (ar <= pos).expand(R, -1).to(torch.uint8).contiguous() if st.anc is None else None
                 logp_buf.copy_(st.step_static(w_.reshape(-1), pos, kmask))
@@ -314,12 +330,20 @@ def beam_search(dec, enc_states, enc_mask, args, return_scores=False):
                     import warnings
                     warnings.warn('decode: HIP graph capture failed (%s); running the steps eagerly' % e)
                     graph = None
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
             for _ in range(done, n_body):
                 if graph is not None:
                     graph.replay()
                 else:
                     body()
-            book(None, True)                                             # t = max_len - 1: every live beam is closed
+            ev1.record()
+            stats['step_events'] = (ev0, ev1, max(0, n_body - done))      # per-token step time = elapsed / count (bench.py)
+            stats['graph'] = graph is not None
+            if fused_book:
+                book_kernel(True)                                        # t = max_len - 1: every live beam is closed
+            else:
+                book(None, True)
         if return_scores:
             return best_seq, best_p
         return best_seq

@@ -234,6 +234,16 @@ int evk_nll_bwd(const float* logits, const float* lse, const int64_t* target, co
                 void* dlogits, int64_t rows, int32_t V, int32_t ld, int32_t ld_out, evk_stream_t stream);
 /* beam step (caption_model.py:70-74): k <= 8 largest of each row, descending, ties -> lowest index first */
 int evk_topk_rows(const float* x, float* vals, int64_t* idx, int64_t rows, int32_t n, int32_t k, evk_stream_t stream);
+/* One launch for the whole beam bookkeeping of a generated token (beam.hip): CaptionModel.beam_step + the finished-beam
+ * handling of CaptionModel.beam_search (modules/caption_model.py:51-106, 174-189; att_model.py:133-135) for hypothesis counts
+ * that no longer change (every step after the first).  logp [B*beam][ld] f32 log-probs (V1 = V+1 valid columns); *pos = position
+ * being written.  In place: beam_sum [B][beam], beam_seq [B][beam][max_len], best_p [B], best_seq [B][max_len], and the
+ * per-hypothesis state rows that follow their hypothesis -- mem [B*beam][mem_row] (16-bit relational memory) and anc
+ * [B*beam][anc_cols] (self-attention cache row table), either may be NULL.  words [B*beam] receives the next input tokens.
+ * force_end != 0 at the last position (every live beam is closed).  Ties -> lowest flat index. */
+int evk_beam_step(const float* logp, int32_t ld, int32_t V1, int32_t beam, int32_t B, int32_t max_len, const int64_t* pos, int32_t eos,
+                  int32_t force_end, float* beam_sum, int64_t* beam_seq, float* best_p, int64_t* best_seq, int64_t* words, void* mem,
+                  int32_t mem_row, int32_t* anc, int32_t anc_cols, evk_stream_t stream);
 /* F.normalize(p=2, eps=1e-12) rows, f32 */
 int evk_l2norm_fwd(const float* x, float* y, float* nrm, int64_t rows, int32_t D, evk_stream_t stream);
 int evk_l2norm_bwd(const float* dy, const float* y, const float* nrm, float* dx, int64_t rows, int32_t D, evk_stream_t stream);
