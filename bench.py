@@ -39,9 +39,25 @@ def make_args(task):
     return a
 
 
+def study_layout(B, views, seed):
+    """study index of every image, anchors (one per study) first, then the other views of the same studies
+    (dataloaders_v0623.py:60-116).  views: int, or 'u4' = 1..4 views per study, uniform, seeded (BASELINE config 4:
+    'Multi-view CXR (<=4 views/study, variable)', SURVEY.md section 8d: seed 7) -- ragged image counts per rank."""
+    if str(views) == 'u4':
+        rng = np.random.RandomState(seed)
+        per = rng.randint(1, 5, size=B)
+    else:
+        per = np.full(B, int(views))
+    studies = list(range(B))
+    for s in range(B):
+        studies += [s] * (int(per[s]) - 1)
+    return studies
+
+
 def synth_batch(kind, B, views, res, L, Li, device, seed):
     g = torch.Generator(device='cpu').manual_seed(seed)
-    N = B * views
+    studies = study_layout(B, views, 7 + (seed % 1000))
+    N = len(studies)
     images = torch.randn(N, 3, res, res, generator=g)
     ids = torch.randint(5, V - 2, (B, L), generator=g)
     if kind == 'finetune':
@@ -52,7 +68,6 @@ def synth_batch(kind, B, views, res, L, Li, device, seed):
     inc = torch.randint(5, V - 2, (B, max(Li, 1)), generator=g)
     inc[:, 0] = 1
     inc_masks = torch.ones(B, max(Li, 1), dtype=torch.long)
-    studies = list(range(B)) * views                   # anchors first, then the other views of the same studies
     pids = np.array(['p%08d_s%08d' % (seed * 1000 + s, s) for s in studies])
     return dict(images=images.to(device), ids=ids.to(device), masks=masks.to(device), inc=inc.to(device),
                 inc_masks=inc_masks.to(device), pids=pids)
@@ -221,13 +236,17 @@ def main():
     ap.add_argument('--no-decode', action='store_true', help='skip the decode sub-record of the default line')
     ap.add_argument('--res', type=int, default=384)
     ap.add_argument('--batch', type=int, default=32, help='studies per GPU')
-    ap.add_argument('--views', type=int, default=2)
+    ap.add_argument('--views', default='2', help="views per study: an integer, or 'u4' = 1..4 per study (uniform, seed 7 + rank): config 4")
+    ap.add_argument('--config', type=int, default=0, help='4: BASELINE config 4 = --workload pretrain --res 384 --batch 16 --views u4')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--dump-launches', default='', help='write one CSV row per profiled launch (GEMM shapes + ms) to this path')
     ap.add_argument('--no-prof', action='store_true', help='disable the in-library HIP-event timing of kernel families')
     ap.add_argument('--no-side-streams', action='store_true', help='issue the whole step on one stream (experiment)')
     ap.add_argument('--graph', type=int, default=-1, help='1: capture the whole training step in a HIP graph, 0: eager launches, -1: default')
     a = ap.parse_args()
+    if a.config == 4:
+        a.workload, a.res, a.batch, a.views = 'pretrain', 384, 16, 'u4'
+    a.views = a.views if a.views == 'u4' else int(a.views)
 
     from evoke_amd import distributed as D
     rank, world, local = D.init_distributed()
@@ -352,11 +371,11 @@ def main():
         return
     studies = a.batch * world * a.steps
     out = {
-        'metric': 'studies/sec (train step, 2-view %d^2)' % a.res, 'value': studies / dt, 'unit': 'studies/s', 'n_gpus': world,
+        'metric': 'studies/sec (train step, %s-view %d^2)' % (a.views, a.res), 'value': studies / dt, 'unit': 'studies/s', 'n_gpus': world,
         'steps': a.steps, 'warmup': n_warm, 'ms_per_step': 1e3 * dt / a.steps, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': H.STORE, 'data': 'synthetic',
-        'config': {'workload': 'EVOKE-%d two-view %s train step (fwd+bwd+allreduce+clip+RAdam), %d studies (%d images) per GPU, '
-                               'L=%d, Li=%d, V=%d, random-init weights' % (a.res, kind, a.batch, a.batch * a.views, L, Li, V),
+        'config': {'workload': 'EVOKE-%d %s-view %s train step (fwd+bwd+allreduce+clip+RAdam), %d studies (%d images) per GPU, '
+                               'L=%d, Li=%d, V=%d, random-init weights' % (a.res, a.views, kind, a.batch, int(batch['images'].shape[0]), L, Li, V),
                    'parallelism': 'dp%d' % world, 'loss_last': float(losses[-1].item()),
                    'host_launch_ms_per_step': host_issue_ms, 'host_loop_ms_per_step': 1e3 * host_dt / a.steps,
                    'step_graph': bool(use_graph and getattr(step, 'graph', None) is not None),

@@ -15,6 +15,14 @@ CASES = {
     'ft224_nomv': dict(kind='finetune', res=224, pids=[0, 1], B=2, L=10, Li=6, modes=['eval'], multiview=False),
     'pt224': dict(kind='pretrain', res=224, pids=[0, 1, 2, 0, 2, 0], B=3, L=10, Li=0, modes=['eval', 'train']),
     'pt224_nosib': dict(kind='pretrain', res=224, pids=[0, 1, 2], B=3, L=8, Li=0, modes=['eval']),
+    # BASELINE config 4 shape: Pretrain at 384^2 with 1-4 views per study (study 0: 4 views, 1: 1, 2: 3, 3: 2; anchors first)
+    'pt384_mv4': dict(kind='pretrain', res=384, pids=[0, 1, 2, 3, 0, 0, 0, 2, 2, 3], B=4, L=10, Li=0, modes=['eval', 'train']),
+    # BASELINE config 1 shape: FineTune with the distilgpt2 cross-attention decoder (args['text_decoder'] = 'distilgpt2'), single
+    # view, 224^2, batch 2.  The reference wires that decoder only in a comment (modules/utils.py:78) and its wrapper cannot be
+    # constructed under transformers 5.15, so the fixture composes what the wrapper computes: the imported
+    # reference's encoder_hidden_states fed to the in-container HF GPT2LMHeadModel(add_cross_attention) with the un-shifted
+    # cross-entropy of language_model.py:252-254 and HF beam generate (num_beams 3, max_length 16).
+    'ft224_gpt2': dict(kind='finetune_gpt2', res=224, pids=[0, 1], B=2, L=12, Li=6, modes=['eval'], max_seq_len=16, beam_size=3),
     'beam224': dict(kind='beam', res=224, pids=[0, 1, 0], B=2, L=8, Li=6, modes=['eval'], max_seq_len=20, beam_size=3),
     'beam224_b4': dict(kind='beam', res=224, pids=[0, 1], B=2, L=8, Li=0, modes=['eval'], max_seq_len=14, beam_size=4),
 }

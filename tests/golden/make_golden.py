@@ -166,6 +166,8 @@ def run_case(name, case, tmp, tokenizer):
     inp = make_inputs(case, tokenizer.get_vocab_size())
     kind = case['kind']
     args = make_args(tmp, tokenizer, case.get('max_seq_len', 100), case.get('beam_size', 3), case.get('multiview', True))
+    if kind == 'finetune_gpt2':
+        return run_finetune_gpt2(case, inp, args, tokenizer)
     if kind in ('finetune', 'beam'):
         from models.model_pretrain_finetune_v0623_large_res import FineTune
         model = FineTune(args, tokenizer, 'iu_xray')
@@ -229,6 +231,56 @@ def run_case(name, case, tmp, tokenizer):
                                    mode='inference')
             out['eval/seq'] = seq.numpy().astype(np.int64)
             out['eval/texts'] = np.array(texts)
+    return out
+
+
+GPT2_DIMS = dict(d=2048, layers=3, heads=8)          # config/finetune_config.yaml:30-32 (decoder_hidden_size / layers / heads)
+
+
+def run_finetune_gpt2(case, inp, args, tokenizer):
+    """config 1: reference FineTune up to encoder_hidden_states (visual extractor, LN1, visual head, indication cross-fusion) ->
+    HF GPT2LMHeadModel(add_cross_attention) as DistilGPT2TextDecoderModel.forward would call it (language_model.py:237-258):
+    un-shifted cross entropy; generate = HF beam search (language_model.py:271-280)."""
+    import torch.nn.functional as F
+    from transformers import GPT2Config, GPT2LMHeadModel
+    from models.model_pretrain_finetune_v0623_large_res import FineTune
+    from oracle import gpt2 as G
+    V, d, layers, heads = tokenizer.get_vocab_size(), GPT2_DIMS['d'], GPT2_DIMS['layers'], GPT2_DIMS['heads']
+    model = FineTune(args, tokenizer, 'iu_xray')
+    load_procedural(model, S.finetune_spec(V))
+    zero_dropout(model)
+    model.eval()
+    cfg = GPT2Config(vocab_size=V, n_embd=d, n_layer=layers, n_head=heads, add_cross_attention=True, is_decoder=True,
+                     bos_token_id=V - 2, eos_token_id=V - 1, pad_token_id=0)
+    dec = GPT2LMHeadModel(cfg).eval()
+    sd = {k[len(G.PRE):]: v for k, v in S.procedural_state(G.gpt2_spec(V, d, layers)).items()}
+    sd['lm_head.weight'] = sd['transformer.wte.weight']
+    dec.load_state_dict(sd, strict=False)
+    taps = {}
+    hs = hook_taps(model, {'fusion': 'multimodal_fusion_layers.0'}, taps)
+    # run the reference up to the decoder: its r2gen decoder's output is discarded, only the fusion tap is used
+    model.zero_grad()
+    model(inp['images'], inp['ids'], inp['masks'], np.array(inp['patient_ids']), inp['inc_ids'], inp['inc_masks'], mode='train')
+    for h in hs:
+        h.remove()
+    enc = taps['fusion'][0]
+    ids, am = inp['ids'], inp['masks']
+    lg = dec(input_ids=ids, attention_mask=am, encoder_hidden_states=enc).logits
+    loss = F.cross_entropy(lg.permute(0, 2, 1), ids, ignore_index=0)
+    model.zero_grad()
+    loss.backward()
+    out = {'eval/loss': np.float64(loss.item()), 'eval/tap/enc_states': reduce_tensor(enc), 'eval/tap/logits': reduce_tensor(lg)}
+    g = dict(model.named_parameters())
+    for k in ('visual_extractor.model.7.2.conv3.weight', 'visual_head.head.0.weight', 'multimodal_fusion_layers.0.crossattention.self.key.weight',
+              'text_encoder.encoder.encoder.layer.5.output.dense.weight'):
+        out['eval/grad/' + k] = reduce_tensor(g[k].grad)
+    gd = dict(dec.named_parameters())
+    for k in ('transformer.wte.weight', 'transformer.h.0.attn.c_attn.weight', 'transformer.h.1.crossattention.c_attn.weight'):
+        out['eval/grad/' + G.PRE + k] = reduce_tensor(gd[k].grad)
+    with torch.no_grad():
+        seq = dec.generate(input_ids=torch.full((case['B'], 1), V - 2), encoder_hidden_states=enc.detach(), num_beams=case['beam_size'],
+                           max_length=case['max_seq_len'], use_cache=True, bos_token_id=V - 2, eos_token_id=V - 1, pad_token_id=0, do_sample=False)
+    out['eval/seq'] = seq.numpy().astype(np.int64)
     return out
 
 

@@ -44,6 +44,8 @@ def _build(kind, args):
     ops.clear_grad_callbacks()
     torch.manual_seed(77)
     model = (FineTune if kind == 'finetune' else Pretrain)(args, load_tokenizer(), 'mimic_cxr').cuda().train()
+    if kind == 'pretrain_eval':          # BN running statistics: per-sample independent, so the 2-rank run is comparable with ONE
+        model.eval()                     # process on the concatenated batch
     opt = optim.build_two_stage_optimizer(args, model, clip_value=0.1)
     return model, opt, D.GradReducer.for_optimizer(opt, bucket_bytes=64 << 20)
 
@@ -59,6 +61,8 @@ def _step(kind, model, opt, red, shard, world):
     loss = ret['all_loss']
     loss.backward()              # all-reduce SUM; FusedOptimizer divides by world (and by the loss scale)
     red.finish()
+    if kind == 'pretrain_eval':
+        return {k: float(v.detach().reshape(-1)[0]) for k, v in ret.items()}
     return float(loss.detach())
 
 
@@ -73,15 +77,16 @@ def _worker(rank, world, port, kind, q):
         ops.set_dropout_enabled(False)
         args = dict(ARGS, task=kind if kind == 'finetune' else 'pretrain', pt_lr=5e-5, ft_lr=5e-4, optim='RAdam', weight_decay=5e-5, amsgrad=True)
         model, opt, red = _build(kind, args)
-        if kind == 'pretrain':
+        if kind != 'finetune':
             model.gather = D.gather_rows
         shard = _shard(kind, rank, V)
         losses = [_step(kind, model, opt, red, shard, world)]
         torch.cuda.synchronize()
         g0 = opt.flat_grads()[0][:200000].clone()             # reduced gradient (mean over ranks) of the first parameters
         opt.step()
-        losses.append(_step(kind, model, opt, red, shard, world))
-        opt.step()
+        if kind != 'pretrain_eval':
+            losses.append(_step(kind, model, opt, red, shard, world))
+            opt.step()
         torch.cuda.synchronize()
         sig = torch.stack([st['p'].double().sum() for st in opt.flat] + [st['p'].double().abs().sum() for st in opt.flat]).cpu()
         sigs = [torch.zeros_like(sig) for _ in range(world)]
@@ -141,3 +146,59 @@ def test_two_rank_pretrain_step_on_one_gpu():
     for rank, losses, sigs, _ in out:
         assert all(np.isfinite(losses)), losses
         assert sigs[0] == sigs[1], 'parameters diverged across ranks: %s' % (sigs,)
+
+
+def test_two_rank_pretrain_matches_the_oracle_on_the_concatenated_batch():
+    """The HIP path's cross-rank contrastive losses and reduced gradients against ONE process of the fp32 oracle on the
+    concatenated batch: BN in eval mode (per-rank batch statistics are not comparable with a
+    concatenated batch), dropout off.  The image-image loss sees all 8 images of both ranks, the global alignment all 4 studies
+    (all-gather of embeddings + study-id hashes); the per-sample local alignment averages over ranks."""
+    from evoke_amd import ops, optim
+    from oracle import functional as O
+    from tests.helpers import ARGS, V
+    out = _run('pretrain_eval')
+    hip = [r[1][0] for r in out]
+    # oracle: same seeds -> same initial weights; shards of rank 0 then rank 1
+    args = dict(ARGS, task='pretrain', pt_lr=5e-5, ft_lr=5e-4, optim='RAdam', weight_decay=5e-5, amsgrad=True)
+    model, opt, red = _build('pretrain_eval', args)
+    P = {k: (v.detach().float() if v.is_floating_point() else v.detach()).cpu().clone() for k, v in model.state_dict().items() if not k.endswith('position_ids')}
+    shards = [_shard('pretrain', r, V) for r in range(2)]
+    B = shards[0][1].shape[0]
+    # collate order of the concatenated batch: all anchors first, then the extra views (dataloaders_v0623.py:60-116)
+    imgs = torch.cat([s[0][:B].cpu() for s in shards] + [s[0][B:].cpu() for s in shards])
+    pids = np.concatenate([s[3][:B] for s in shards] + [s[3][B:] for s in shards])
+    ids = torch.cat([s[1].cpu() for s in shards])
+    masks = torch.cat([s[2].cpu() for s in shards])
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    train_keys = [k for k, v in P.items() if v.is_floating_point() and not any(t in k for t in ('running_', 'num_batches'))]
+    for k in train_keys:
+        P[k].requires_grad_(True)
+    ret = O.pretrain_forward(P, imgs, ids, masks, pids, O.DEFAULT_CFG, O.Ctx(train=False))
+    ret['all_loss'].backward()
+    want = {k: float(v.detach().reshape(-1)[0]) for k, v in ret.items()}
+    got_all = 0.5 * (hip[0]['all_loss'] + hip[1]['all_loss'])
+    print('\n[2 ranks vs concatenated oracle] all_loss hip %.6f oracle %.6f | instance %.6f/%.6f vs %.6f | multiview %.6f/%.6f vs %.6f' % (
+        got_all, want['all_loss'], hip[0]['instance_loss'], hip[1]['instance_loss'], want['instance_loss'], hip[0]['multiview_loss'],
+        hip[1]['multiview_loss'], want['multiview_loss']))
+    for r in range(2):
+        assert abs(hip[r]['instance_loss'] - want['instance_loss']) <= 1e-3 and abs(hip[r]['multiview_loss'] - want['multiview_loss']) <= 1e-3
+    assert abs(0.5 * (hip[0]['sen_text_loss'] + hip[1]['sen_text_loss']) - want['sen_text_loss']) <= 1e-3
+    assert abs(got_all - want['all_loss']) <= 1e-3
+    # reduced gradient (SUM over ranks of the loss-scaled shard gradients) / (world * scale) vs the oracle's gradient, parameter
+    # by parameter over the first 200k entries of the flat buffer (stem, layer1 ...): energy within 10 %, cosine >= 0.95
+    g0 = torch.from_numpy(out[0][3].astype(np.float32)) / (2.0 * ops.loss_scale_value())
+    worst = (0.0, 1.0)
+    names = {id(p): n for n, p in model.named_parameters()}
+    for p_, o in zip(opt.param_groups[0]['params'], opt.flat[0]['offsets']):
+        n = p_.numel()
+        if o + n > g0.numel() or n < 64:
+            continue
+        got = optim._view_like(g0[o:o + n], p_.detach().cpu()).contiguous().double().reshape(-1)
+        ref = P[names[id(p_)]].grad.double().reshape(-1)
+        e = abs(float(got.pow(2).sum() - ref.pow(2).sum())) / (float(ref.pow(2).sum()) + 1e-30)
+        c = float(got @ ref / (got.norm() * ref.norm() + 1e-30))
+        worst = (max(worst[0], e), min(worst[1], c))
+        assert e <= 0.10 and c >= 0.95, (names[id(p_)], e, c)
+    print('   reduced gradients vs oracle: worst energy error %.3e, worst cosine %.4f' % worst)
+    ops.clear_grad_callbacks()
+    ops.set_dropout_enabled(True)

@@ -275,6 +275,60 @@ def test_distilgpt2_backend_matches_hf_fixture():
     assert not bad, bad
 
 
+def test_finetune_with_distilgpt2_decoder_matches_reference_composition():
+    """BASELINE config 1 end to end: FineTune(args['text_decoder'] = 'distilgpt2') -- the switch the reference keeps in a comment
+    (modules/utils.py:78) -- single view, 224^2, batch 2, against tests/golden/ft224_gpt2.npz (imported reference encoder +
+    in-container HF GPT2LMHeadModel, see tests/golden/cases.py): eval loss, encoder-state tap, upstream and decoder gradients, and
+    the beam-3 generated token ids (mode='inference') which must be identical in the default build."""
+    from evoke_amd import ops
+    from evoke_amd.model_pretrain_finetune import FineTune
+    from oracle import gpt2 as G, spec as S
+    case, gold = CASES['ft224_gpt2'], _gold('ft224_gpt2')
+    inp = make_inputs(case, V)
+    d, layers, heads = 2048, 3, 8
+    args = dict(ARGS, text_decoder='distilgpt2', decoder_hidden_size=d, decoder_num_hidden_layers=layers, decoder_num_attention_heads=heads,
+                beam_size=case['beam_size'], max_seq_len=case['max_seq_len'])
+    model = FineTune(args, load_tokenizer(), 'iu_xray')
+    sd = {k: v for k, v in S.procedural_state(S.finetune_spec(V)).items() if not k.startswith('text_decoder.')}
+    sd.update(S.procedural_state(G.gpt2_spec(V, d, layers)))
+    sd[G.PRE + 'lm_head.weight'] = sd[G.PRE + 'transformer.wte.weight']
+    res = model.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys and all(k.endswith(('position_ids', '.attn.bias', '.attn.masked_bias')) for k in res.missing_keys), (res.unexpected_keys[:4], res.missing_keys[:4])
+    model = model.cuda().eval()
+    ops.set_dropout_enabled(False)
+    bad = []
+    taps = {}
+    hs = _hook(model, {'fusion': 'multimodal_fusion_layers.0'}, taps)
+    model.zero_grad(set_to_none=True)
+    ret = model(inp['images'].cuda(), inp['ids'].cuda(), inp['masks'].cuda(), np.array(inp['patient_ids']), inp['inc_ids'], inp['inc_masks'], mode='train')
+    for h in hs:
+        h.remove()
+    loss, want = ret['all_loss'].item(), float(gold['eval/loss'])
+    print('\n[ft224_gpt2/eval] loss hip %.6f ref %.6f  diff %.2e' % (loss, want, abs(loss - want)))
+    if abs(loss - want) > LOSS_TOL:
+        bad.append('loss %.6f vs %.6f' % (loss, want))
+    if not _report('enc_states', taps['fusion'], gold['eval/tap/enc_states'], ACT_TOL):
+        bad.append('enc_states')
+    ret['all_loss'].backward()
+    prm = dict(model.named_parameters())
+    for k in gold.files:
+        if k.startswith('eval/grad/'):
+            g = prm[k[len('eval/grad/'):]].grad
+            if g is None or not _report_grad(k[10:], g / ops.loss_scale_value(), gold[k]):
+                bad.append(k)
+    with torch.no_grad():
+        texts, seq = model(inp['images'].cuda(), inp['ids'].cuda(), inp['masks'].cuda(), np.array(inp['patient_ids']), inp['inc_ids'],
+                           inp['inc_masks'], mode='inference')
+    seq, wseq = seq.cpu(), torch.from_numpy(gold['eval/seq'])
+    print('   seq hip', seq.tolist())
+    print('   seq ref', wseq.tolist())
+    assert len(texts) == case['B'] and seq.dtype == torch.long
+    if F16:
+        assert seq.shape == wseq.shape and torch.equal(seq, wseq), 'generated token ids differ from the HF fixture'
+    ops.set_dropout_enabled(True)
+    assert not bad, bad
+
+
 def test_loss_parity_at_realistic_token_count():
     """Eval-mode loss at a realistic token count (8 studies x 2 views, <= 60 report tokens, 30 indication tokens) against the
     fp32 CPU oracle on the same procedural weights.  The north star's goal is 1e-3.  bf16 storage measures |d| = 3.5e-3 on a

@@ -165,3 +165,21 @@ def test_gpt2_backend_vs_hf():
         P = S.procedural_state(spec)
         assert G.beam_search(P, enc, heads, layers, 3, 16, V - 2, V - 1, 0).tolist() == gold['eval/seq_b3'].tolist()
         assert G.beam_search(P, enc, heads, layers, 1, 10, V - 2, V - 1, 0).tolist() == gold['eval/seq_b1'].tolist()
+
+
+def test_finetune_with_gpt2_decoder_vs_reference_composition():
+    """BASELINE config 1 (FineTune + distilgpt2 decoder, single view, 224^2, batch 2): the oracle's encoder states fed to the
+    oracle's GPT-2 restatement against the fixture composed from the imported reference's encoder + in-container HF GPT-2."""
+    from oracle import functional as O, gpt2 as G
+    case, gold = CASES['ft224_gpt2'], _load('ft224_gpt2')
+    inp = make_inputs(case, V)
+    d, layers, heads = 2048, 3, 8
+    P = S.procedural_state(S.finetune_spec(V))
+    P.update(S.procedural_state(G.gpt2_spec(V, d, layers)))
+    with torch.no_grad():
+        x, _ = O.finetune_encoder_states(P, inp['images'], inp['patient_ids'], case['B'], inp['inc_ids'], inp['inc_masks'], O.DEFAULT_CFG, O.Ctx())
+        _check(reduce_tensor(x), gold['eval/tap/enc_states'], 2e-4, 'enc_states')
+        loss = G.gpt2_train_loss(P, inp['ids'], inp['masks'], x, heads, layers)
+        assert abs(loss.item() - float(gold['eval/loss'])) < 2e-5, (loss.item(), float(gold['eval/loss']))
+        seq = G.beam_search(P, x, heads, layers, case['beam_size'], case['max_seq_len'], V - 2, V - 1, 0)
+        assert seq.tolist() == gold['eval/seq'].tolist()
