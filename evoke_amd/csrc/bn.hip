@@ -132,13 +132,17 @@ struct FinP {
   const float* sum; const float* sumsq; const float* gamma; const float* beta; float* rmean; float* rvar;
   float* scale; float* shift; float* mean; float* invstd; int C; float count, momentum, eps; int training;
 };
+__device__ __forceinline__ void bn_finalize_channel(const FinP& p, int c, float sum, float sumsq);
 __global__ void bn_finalize_kernel(const FinP p) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= p.C) return;
+  bn_finalize_channel(p, c, p.training ? p.sum[c] : 0.f, p.training ? p.sumsq[c] : 0.f);
+}
+__device__ __forceinline__ void bn_finalize_channel(const FinP& p, int c, float sum, float sumsq) {
   float mu, var;
   if (p.training) {
-    mu = p.sum[c] / p.count;
-    var = fmaxf(p.sumsq[c] / p.count - mu * mu, 0.f);
+    mu = sum / p.count;
+    var = fmaxf(sumsq / p.count - mu * mu, 0.f);
     if (p.rmean) {
       p.rmean[c] = (1.f - p.momentum) * p.rmean[c] + p.momentum * mu;
       p.rvar[c] = (1.f - p.momentum) * p.rvar[c] + p.momentum * var * (p.count / fmaxf(p.count - 1.f, 1.f));
@@ -153,6 +157,72 @@ __global__ void bn_finalize_kernel(const FinP p) {
   p.shift[c] = b - mu * g * is;
   p.mean[c] = mu;
   p.invstd[c] = is;
+}
+
+// second reduction stage of the gate statistics a data-gradient GEMM epilogue wrote (gemm.hip: gatestats): 8 channels per block
+__global__ __launch_bounds__(256) void bn_bwd_sums_from_gate_kernel(const float* __restrict__ part, int nblk, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, float* __restrict__ sum_g, float* __restrict__ sum_gx,
+                                                                    float* dbeta_acc, float* dgamma_acc, int C) {
+  __shared__ float red[16][17];
+  const int j = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 8 + (j & 7);
+  const int col = (j < 8 ? 0 : C) + c;
+  const long ld = 2L * C;
+  float acc[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+  if (c < C) {
+    int b = rl;
+    for (; b + 16 * 7 < nblk; b += 16 * 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += part[(long)(b + 16 * u) * ld + col];
+    }
+    for (; b < nblk; b += 16) acc[0] += part[(long)b * ld + col];
+  }
+  red[rl][j] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (threadIdx.x < 8 && c < C) {
+    float sg = 0.f, sgz = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { sg += red[q][threadIdx.x]; sgz += red[q][threadIdx.x + 8]; }
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sgx = g != 0.f ? (sgz - b * sg) / g : 0.f;
+    sum_g[c] = sg; sum_gx[c] = sgx;
+    if (dbeta_acc) dbeta_acc[c] += sg;
+    if (dgamma_acc) dgamma_acc[c] += sgx;
+  }
+}
+
+// colreduce_final + bn_finalize in ONE launch for the training forward of the trunk (two dependent ~5 us launches on the critical
+// path of each of the 104 convolutions otherwise): a block sums the partial rows of 8 channels -- 16 columns: their sums and their
+// sums of squares -- with 16 row-lanes, then 8 threads finish the statistics of those channels.
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ part, int nblk, float* __restrict__ sum_out,
+                                                                float* __restrict__ sumsq_out, const FinP p) {
+  __shared__ float red[16][17];
+  const int j = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 8 + (j & 7);
+  const int col = (j < 8 ? 0 : p.C) + c;
+  const long ld = 2L * p.C;
+  float acc[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+  if (c < p.C) {
+    int b = rl;
+    for (; b + 16 * 7 < nblk; b += 16 * 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += part[(long)(b + 16 * u) * ld + col];
+    }
+    for (; b < nblk; b += 16) acc[0] += part[(long)b * ld + col];
+  }
+  red[rl][j] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  if (threadIdx.x < 8 && c < p.C) {
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { s0 += red[q][threadIdx.x]; s1 += red[q][threadIdx.x + 8]; }
+    sum_out[c] = s0; sumsq_out[c] = s1;
+    bn_finalize_channel(p, c, s0, s1);
+  }
 }
 
 // y = relu?(x*scale[c] + shift[c] + resid).  The grid stride (gridDim.x * 256) is a multiple of G (G divides 256), so a thread
@@ -481,6 +551,26 @@ int evk_bn_finalize(const float* sum, const float* sumsq, const float* gamma, co
   ProfScope ps(EVK_FAM_REDUCE, s);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((int)cdiv(C, 256)), dim3(256), 0, s, p);
   return evk_check_launch("bn_finalize");
+}
+
+int evk_bn_bwd_sums_from_gate_partials(const float* part, int32_t nblk, const float* gamma, const float* beta, float* sum_g, float* sum_gx,
+                                       float* dbeta_acc, float* dgamma_acc, int32_t C, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(part && sum_g && sum_gx && nblk > 0 && C > 0 && C % 8 == 0, "bn_bwd_sums_from_gate_partials: bad args");
+  ProfScope ps(EVK_FAM_REDUCE, s);
+  hipLaunchKernelGGL(bn_bwd_sums_from_gate_kernel, dim3(C / 8), dim3(256), 0, s, part, (int)nblk, gamma, beta, sum_g, sum_gx, dbeta_acc, dgamma_acc, (int)C);
+  return evk_check_launch("bn_bwd_sums_from_gate_partials");
+}
+
+int evk_bn_stats_finalize_from_partials(const float* part, int32_t nblk, float* sum, float* sumsq, const float* gamma, const float* beta,
+                                        float* running_mean, float* running_var, float* scale, float* shift, float* mean, float* invstd,
+                                        int32_t C, float count, float momentum, float eps, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(part && sum && sumsq && scale && shift && mean && invstd && nblk > 0 && C > 0 && C % 8 == 0 && count > 0, "bn_stats_finalize_from_partials: bad args");
+  FinP p{sum, sumsq, gamma, beta, running_mean, running_var, scale, shift, mean, invstd, C, count, momentum, eps, 1};
+  ProfScope ps(EVK_FAM_REDUCE, s);
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C / 8), dim3(256), 0, s, part, (int)nblk, sum, sumsq, p);
+  return evk_check_launch("bn_stats_finalize_from_partials");
 }
 
 int evk_bn_apply(const void* x, const float* scale, const float* shift, const void* resid, void* y, int64_t M, int32_t C,

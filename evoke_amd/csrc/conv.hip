@@ -105,6 +105,11 @@ int evk_conv2d_dgrad_add(const void* dy, const void* w, const void* resid, void*
 
 int evk_conv2d_dgrad_gated(const void* dy, const void* w, const void* resid, const void* gate, void* dx, const evk_conv_geom* g,
                            evk_stream_t stream) {
+  return evk_conv2d_dgrad_gated_stats(dy, w, resid, gate, dx, g, nullptr, 0, nullptr, stream);
+}
+
+int evk_conv2d_dgrad_gated_stats(const void* dy, const void* w, const void* resid, const void* gate, void* dx, const evk_conv_geom* g,
+                                 float* part, int64_t part_bytes, int32_t* nblk, evk_stream_t stream) {
   if (int e = check_geom(g)) return e;
   const int T = g->KH * g->KW;
   EVK_REQUIRE(ilog2_exact(g->Co) >= 3, "conv dgrad: Co must be a power of two >= 8");
@@ -117,6 +122,11 @@ int evk_conv2d_dgrad_gated(const void* dy, const void* w, const void* resid, con
   d.batch_outer = d.batch_inner = 1; d.alpha = 1.f; d.c_dtype = EVK_BF16;
   if (resid) { d.resid = resid; d.ldr = g->Ci; d.r_dtype = EVK_BF16; }
   if (gate) { d.relu_gate = gate; d.ldg = g->Ci; }
+  if (part) {
+    EVK_REQUIRE(gate && nblk && part_bytes >= evk_conv_stats_bytes(d.M, g->Ci), "conv dgrad: gate statistics need a gate and a large enough buffer");
+    *nblk = stats_rows(d.M, g->Ci);
+    d.gatestats = part;
+  }
   d.g = *g;
   return evk_gemm_launch(&d, stream);
 }

@@ -34,6 +34,7 @@ struct GemmP {
   int lds_store;                    // bf16 output rows leave through LDS in 16-byte pieces (needs N % 8 == 0, ldc % 8 == 0, aligned C)
   const bf16_t* gate; long ldg;     // optional ReLU gate: C = (gate > 0) ? C : 0, applied last (bf16 [M][ldg], batch 1)
   float* colstats;                  // per 64-row block partial column sums / sums of squares [row block][2][N] (or null)
+  float* gatestats;                 // per 64-row block partial column sums of the GATED output g and of g * gate [row block][2][N] (or null)
   float* slab; long slab_mn;        // split-K partial slabs [z][split][M][N] f32 (accumulate mode with splitk > 1)
   int b_klog, b_kmask; long b_tapstride;
   // gather geometry
@@ -346,6 +347,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[4][4]
       }
     }
   }
+  // batch-norm backward sums of the NEXT layer down, taken from this data-gradient GEMM's epilogue: the output is the gradient
+  // g w.r.t. z = relu(gamma * xhat + beta) of that layer, gated by z > 0, and where the gate is open xhat = (z - beta) / gamma --
+  // so sum(g) and sum(g * z) per column are all its backward needs (bn.hip: bn_bwd_sums_from_gate_kernel), at no extra traffic:
+  // the gate tile is loaded anyway.
+  float gs[4][4], gz[4][4];
+#pragma unroll
+  for (int in = 0; in < 4; ++in)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { gs[in][j] = 0.f; gz[in][j] = 0.f; }
   char* Cb = reinterpret_cast<char*>(p.C) + (zo * p.sCo + zi * p.sCi) * (p.c_f32 ? 4 : 2);
   const char* Rb = p.resid ? reinterpret_cast<const char*>(p.resid) + (zo * p.sRo + zi * p.sRi) * (p.r_f32 ? 4 : 2) : nullptr;
 #pragma unroll
@@ -410,15 +420,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[4][4]
       }
       if (p.gate) {        // gradient of a ReLU whose output is `gate`: zero where the forward activation was clipped
         const bf16_t* gt = p.gate + (long)m * p.ldg + n0;
+        float gv[4] = {0.f, 0.f, 0.f, 0.f};
         if (full && (p.ldg & 3) == 0) {
           const uint2 t = *reinterpret_cast<const uint2*>(gt);
-          if (!(lo_bf(t.x) > 0.f)) v[0] = 0.f;
-          if (!(hi_bf(t.x) > 0.f)) v[1] = 0.f;
-          if (!(lo_bf(t.y) > 0.f)) v[2] = 0.f;
-          if (!(hi_bf(t.y) > 0.f)) v[3] = 0.f;
+          gv[0] = lo_bf(t.x); gv[1] = hi_bf(t.x); gv[2] = lo_bf(t.y); gv[3] = hi_bf(t.y);
         } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) if (n0 + j < p.N && !(bf2f(gt[j]) > 0.f)) v[j] = 0.f;
+          for (int j = 0; j < 4; ++j) if (n0 + j < p.N) gv[j] = bf2f(gt[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (!(gv[j] > 0.f)) v[j] = 0.f;
+        if (p.gatestats) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { gs[in][j] += v[j]; gz[in][j] += v[j] * gv[j]; }
         }
       }
       if (p.c_f32) {
@@ -439,6 +453,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[4][4]
 #pragma unroll
           for (int j = 0; j < 4; ++j) if (n0 + j < p.N) c[j] = f2bf(v[j]);
         }
+      }
+    }
+  }
+  if (p.gatestats) {
+    float* prow = p.gatestats + ((long)(tm * (TM / 64) + wm)) * 2 * p.N;
+#pragma unroll
+    for (int in = 0; in < 4; ++in) {
+      float a[4], b[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { a[j] = row16_sum(gs[in][j]); b[j] = row16_sum(gz[in][j]); }
+      const int n0 = tn * TN + wn * 64 + in * 16 + fq * 4;
+      if (frow == 0 && n0 < p.N) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (n0 + j < p.N) { prow[n0 + j] = a[j]; prow[p.N + n0 + j] = b[j]; }
       }
     }
   }
@@ -1018,6 +1046,7 @@ extern "C" int evk_gemm_launch(const evk_gemm* d, evk_stream_t stream) {
   p.alpha = d->alpha; p.act = d->act; p.c_f32 = d->c_dtype == EVK_F32; p.r_f32 = d->r_dtype == EVK_F32;
   p.accumulate = d->accumulate;
   p.colstats = reinterpret_cast<float*>(d->colstats);
+  p.gatestats = reinterpret_cast<float*>(d->gatestats);
   {
     // measured (cold caches, tools/gemm_bench.py --cold): +20 % on the write-dominated K = 64 convolutions of layer1, neutral
     // elsewhere -> on for short-K problems; EVK_LDS_STORE=0/1 forces it off / on for every eligible launch
@@ -1031,6 +1060,7 @@ extern "C" int evk_gemm_launch(const evk_gemm* d, evk_stream_t stream) {
   p.gate = reinterpret_cast<const bf16_t*>(d->relu_gate); p.ldg = d->ldg;
   EVK_REQUIRE(!p.gate || (!p.accumulate && d->batch_outer * d->batch_inner == 1 && d->ldg >= d->N), "evk_gemm: relu_gate needs batch 1, no accumulate, ldg >= N");
   EVK_REQUIRE(!p.colstats || (!p.accumulate && d->batch_outer * d->batch_inner == 1), "evk_gemm: colstats needs batch 1 and no accumulate");
+  EVK_REQUIRE(!p.gatestats || p.gate, "evk_gemm: gatestats needs relu_gate");
   EVK_REQUIRE(!p.accumulate || (p.c_f32 && !d->bias && !d->resid && d->act == EVK_ACT_NONE),
               "evk_gemm: accumulate needs f32 C and no bias/resid/act");
   const int esz = p.c_f32 ? 4 : 2;

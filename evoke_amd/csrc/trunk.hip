@@ -7,6 +7,7 @@
 // plus six rotating gradient buffers for the block-level tensors.  Every dy buffer is unique, so the weight-gradient
 // GEMMs can run on a second stream (they feed nothing before the optimizer) without slot-reuse hazards.
 #include <vector>
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -113,10 +114,26 @@ int bn_forward(const Ctx& c, int i, const void* resid, int relu, int nblk) {
   const evk_trunk_layer& l = c.L[i];
   float* st = c.at<float>(pr.stats);
   const int C = pr.C;
-  if (c.training) TRY(evk_bn_stats_from_partials(c.at<float>(c.P->part), nblk, st, st + C, C, c.s));   // the conv epilogue left the partial sums
-  TRY(evk_bn_finalize(st, st + C, l.gamma, l.beta, l.running_mean, l.running_var, st + 2 * C, st + 3 * C, st + 4 * C, st + 5 * C, C,
-                      (float)pr.M, c.cfg->momentum, c.cfg->eps, c.training, c.s));
+  if (c.training)        // the conv epilogue left the partial sums: second reduction stage + statistics in one launch
+    TRY(evk_bn_stats_finalize_from_partials(c.at<float>(c.P->part), nblk, st, st + C, l.gamma, l.beta, l.running_mean, l.running_var, st + 2 * C,
+                                            st + 3 * C, st + 4 * C, st + 5 * C, C, (float)pr.M, c.cfg->momentum, c.cfg->eps, c.s));
+  else
+    TRY(evk_bn_finalize(st, st + C, l.gamma, l.beta, l.running_mean, l.running_var, st + 2 * C, st + 3 * C, st + 4 * C, st + 5 * C, C,
+                        (float)pr.M, c.cfg->momentum, c.cfg->eps, c.training, c.s));
   return evk_bn_apply(c.at(pr.y), st + 2 * C, st + 3 * C, resid, c.at(pr.z), pr.M, C, relu, c.s);
+}
+
+// bn_backward whose two column sums come from the partial rows the producing data-gradient GEMM's epilogue wrote (no pass over dz)
+int bn_backward_from_gate(const Ctx& c, int i, const void* dz, int nblk) {
+  const Pair& pr = c.P->pairs[i];
+  const evk_trunk_layer& l = c.L[i];
+  float* st = c.at<float>(pr.stats);
+  float* sums = c.at<float>(pr.sums);
+  const int C = pr.C;
+  TRY(evk_bn_bwd_sums_from_gate_partials(c.at<float>(c.P->part), nblk, l.gamma, l.beta, sums, sums + C, l.dbeta, l.dgamma, C, c.s));
+  const float* sg = c.training ? sums : c.at<float>(c.P->zeros);
+  const float* sgx = c.training ? sums + C : c.at<float>(c.P->zeros);
+  return evk_bn_bwd_apply(dz, c.at(pr.z), c.at(pr.y), st + 2 * C, st + 4 * C, st + 5 * C, sg, sgx, c.at(pr.dy), nullptr, pr.M, C, 0, c.s);
 }
 
 // dz (gradient w.r.t. z) -> dy (gradient w.r.t. the conv output), optional dres (= masked dz, the skip-branch gradient)
@@ -235,6 +252,7 @@ int evk_trunk_backward(const evk_trunk_cfg* cfg, const evk_trunk_layer* layers, 
   Ctx c{cfg, layers, static_cast<char*>(ws), &P, stream, training};
   WgradQueue q;
   TRY(q.init(stream, wgrad_stream));
+  static const bool gate_stats = [] { const char* e = getenv("EVK_BN_GATE_STATS"); return !e || atoi(e) != 0; }();
 
   auto wgrad = [&](int i, const void* xin) -> int {
     if (!layers[i].dw) return EVK_OK;
@@ -266,13 +284,22 @@ int evk_trunk_backward(const evk_trunk_cfg* cfg, const evk_trunk_layer* layers, 
     void* T = c.at(P.gbuf[5]);
     void* gX = c.at(P.gbuf[flip]);
     flip ^= 1;
+    // bn2 / bn1 of the block: their backward sums ride on the data-gradient GEMM that produces their dz (gate statistics)
+    float* part = c.at<float>(P.part);
+    const bool gs1 = gate_stats && P.part_bytes >= evk_conv_stats_bytes(P.pairs[i + 1].M, P.pairs[i + 1].C);
+    const bool gs0 = gate_stats && P.part_bytes >= evk_conv_stats_bytes(P.pairs[i].M, P.pairs[i].C);
+    int nb1 = 0, nb0 = 0;
     TRY(bn_backward(c, i + 2, gZ, nullptr, 0));
-    TRY(evk_conv2d_dgrad_gated(c.at(P.pairs[i + 2].dy), layers[i + 2].w, nullptr, c.at(P.pairs[i + 1].z), S1, &P.pairs[i + 2].g, stream));
+    TRY(evk_conv2d_dgrad_gated_stats(c.at(P.pairs[i + 2].dy), layers[i + 2].w, nullptr, c.at(P.pairs[i + 1].z), S1, &P.pairs[i + 2].g,
+                                     gs1 ? part : nullptr, P.part_bytes, &nb1, stream));
     TRY(wgrad(i + 2, c.at(P.pairs[i + 1].z)));
-    TRY(bn_backward(c, i + 1, S1, nullptr, 0));
-    TRY(evk_conv2d_dgrad_gated(c.at(P.pairs[i + 1].dy), layers[i + 1].w, nullptr, c.at(P.pairs[i].z), S2, &P.pairs[i + 1].g, stream));
+    if (gs1) TRY(bn_backward_from_gate(c, i + 1, S1, nb1));
+    else TRY(bn_backward(c, i + 1, S1, nullptr, 0));
+    TRY(evk_conv2d_dgrad_gated_stats(c.at(P.pairs[i + 1].dy), layers[i + 1].w, nullptr, c.at(P.pairs[i].z), S2, &P.pairs[i + 1].g,
+                                     gs0 ? part : nullptr, P.part_bytes, &nb0, stream));
     TRY(wgrad(i + 1, c.at(P.pairs[i].z)));
-    TRY(bn_backward(c, i, S2, nullptr, 0));
+    if (gs0) TRY(bn_backward_from_gate(c, i, S2, nb0));
+    else TRY(bn_backward(c, i, S2, nullptr, 0));
     const void* skip = gZ;
     if (down) {
       TRY(bn_backward(c, i + 3, gZ, nullptr, 0));

@@ -40,7 +40,7 @@ class Gemm(C.Structure):
                 ('accumulate', C.c_int32), ('splitk', C.c_int32), ('b_klog', C.c_int32), ('b_tapstride', C.c_int64),
                 ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64), ('bias_stride_inner', C.c_int64), ('relu_gate', C.c_void_p),
                 ('ldg', C.c_int64),
-                ('colstats', C.c_void_p), ('g', ConvGeom)]
+                ('colstats', C.c_void_p), ('gatestats', C.c_void_p), ('g', ConvGeom)]
 
 
 class PreprocDesc(C.Structure):

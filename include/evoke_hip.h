@@ -71,6 +71,9 @@ typedef struct evk_gemm {
                                     a ReLU whose forward output is relu_gate); batch 1, no accumulate                   */
   void* colstats;                /* optional f32 [ceil(M/64) (rounded to the tile)][2][N]: per 64-row block column sums and
                                     sums of squares of alpha*A.B, from the f32 accumulators (batch 1, no accumulate)  */
+  void* gatestats;               /* optional f32 [ceil(M/64) (rounded to the tile)][2][N], needs relu_gate: per 64-row block column sums
+                                    of the gated output g and of g * relu_gate -- the batch-norm backward sums of the layer whose
+                                    ReLU output is relu_gate (evk_bn_bwd_sums_from_gate_partials)                          */
   evk_conv_geom g;               /* used by the gather modes                                            */
 } evk_gemm;
 
@@ -127,6 +130,10 @@ int evk_conv2d_dgrad(const void* dy, const void* w, void* dx, const evk_conv_geo
 int evk_conv2d_dgrad_add(const void* dy, const void* w, const void* resid, void* dx, const evk_conv_geom* g, evk_stream_t stream);
 /* dx = relu'(gate) * (dgrad(dy, w) + resid): also applies the ReLU gate of the tensor dx belongs to (gate = that tensor's
  * post-ReLU forward value), so the batch-norm backward that consumes dx needs no mask pass                          */
+/* evk_conv2d_dgrad_gated + the gate statistics of evk_gemm.gatestats: part receives *nblk rows of [2][Ci] (evk_conv_stats_bytes(rows of
+ * dx, Ci) bytes) */
+int evk_conv2d_dgrad_gated_stats(const void* dy, const void* w, const void* resid, const void* gate, void* dx, const evk_conv_geom* g,
+                                 float* part, int64_t part_bytes, int32_t* nblk, evk_stream_t stream);
 int evk_conv2d_dgrad_gated(const void* dy, const void* w, const void* resid, const void* gate, void* dx, const evk_conv_geom* g,
                            evk_stream_t stream);
 int evk_conv2d_wgrad(const void* dy, const void* x, float* dw, const evk_conv_geom* g, void* ws, int64_t ws_bytes, evk_stream_t stream);
@@ -262,6 +269,17 @@ int evk_bn_stats_from_partials(const float* part, int32_t nblk, float* sum, floa
 int evk_bn_finalize(const float* sum, const float* sumsq, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float* scale, float* shift, float* mean, float* invstd, int32_t C, float count,
                     float momentum, float eps, int32_t training, evk_stream_t stream);
+/* Batch-norm backward sums without a pass over the gradient: `part` = nblk rows of [2][C] partial sums (sum g, sum g*z) written by
+ * the epilogue of the data-gradient GEMM that produced g gated by z > 0 (evk_conv2d_dgrad_gated_stats), z = relu(gamma*xhat + beta)
+ * the layer's own forward output.  Where the gate is open xhat = (z - beta) / gamma, so sum_g = sum g and sum_gx = (sum g*z - beta *
+ * sum g) / gamma (0 for gamma == 0, where dx vanishes anyway); dbeta_acc += sum_g, dgamma_acc += sum_gx when given.
+ * Replaces evk_bn_bwd_reduce_acc for bn1 / bn2 of every bottleneck (nn.BatchNorm2d backward, torchvision resnet101). */
+int evk_bn_bwd_sums_from_gate_partials(const float* part, int32_t nblk, const float* gamma, const float* beta, float* sum_g, float* sum_gx,
+                                       float* dbeta_acc, float* dgamma_acc, int32_t C, evk_stream_t stream);
+/* evk_bn_stats_from_partials + evk_bn_finalize (training) in one launch: the trunk runner's per-convolution critical path */
+int evk_bn_stats_finalize_from_partials(const float* part, int32_t nblk, float* sum, float* sumsq, const float* gamma, const float* beta,
+                                        float* running_mean, float* running_var, float* scale, float* shift, float* mean, float* invstd,
+                                        int32_t C, float count, float momentum, float eps, evk_stream_t stream);
 int evk_bn_apply(const void* x, const float* scale, const float* shift, const void* resid, void* y, int64_t M, int32_t C,
                  int32_t relu, evk_stream_t stream);
 int evk_bn_bwd_reduce(const void* dz, const void* z, const void* x, const float* mean, const float* invstd, float* sum_g,

@@ -438,6 +438,43 @@ def test_conv_fwd_stats_and_dgrad_add():
         close(dx.float(), (xr.grad.permute(0, 2, 3, 1) + skip.float()).cpu(), 2e-2, 2e-2, 'dgrad + skip')
 
 
+def test_dgrad_gate_statistics_give_the_batchnorm_backward_sums():
+    """evk_conv2d_dgrad_gated_stats + evk_bn_bwd_sums_from_gate_partials: the data-gradient GEMM's epilogue accumulates sum(g) and
+    sum(g*z) of its ReLU-gated output per channel (z = relu(gamma*xhat + beta), the gate tensor), from which the batch-norm backward
+    sums sum(g) and sum(g*xhat) of that layer follow without a pass over g -- against f32 torch on the same 16-bit operands."""
+    import ctypes as C
+    from evoke_amd import hip as H
+    torch.manual_seed(5)
+    for (N, Hh, Ci, Co, k, stride) in [(3, 20, 64, 128, 3, 1), (2, 24, 256, 64, 1, 1), (2, 18, 128, 256, 3, 2), (1, 257, 64, 256, 1, 1)]:
+        g = H.conv_geom(N, Hh, Hh, Ci, Co, k, k, stride, k // 2)
+        M = N * Hh * Hh
+        w = (torch.randn(Co, k, k, Ci, device='cuda') * 0.05).to(BF)
+        dy = (torch.randn(N, g.Ho, g.Wo, Co, device='cuda') * 0.3).to(BF)
+        gamma, beta = 0.5 + torch.rand(Ci, device='cuda'), 0.3 * torch.randn(Ci, device='cuda')
+        xhat = torch.randn(N, Hh, Hh, Ci, device='cuda')
+        z = torch.relu(gamma * xhat + beta).to(BF)                   # the layer's forward output = the gate
+        dx = torch.empty(N, Hh, Hh, Ci, device='cuda', dtype=BF)
+        nb = H.lib.evk_conv_stats_bytes(M, Ci)
+        part = torch.empty(nb // 4, device='cuda')
+        nblk = C.c_int32(0)
+        H.check(H.lib.evk_conv2d_dgrad_gated_stats(H.ptr(dy), H.ptr(w), None, H.ptr(z), H.ptr(dx), C.byref(g), H.ptr(part), nb, C.byref(nblk), H.stream()))
+        sums = torch.empty(2, Ci, device='cuda')
+        dbeta, dgamma = torch.ones(Ci, device='cuda'), torch.ones(Ci, device='cuda')
+        H.check(H.lib.evk_bn_bwd_sums_from_gate_partials(H.ptr(part), nblk.value, H.ptr(gamma), H.ptr(beta), H.ptr(sums[0]), H.ptr(sums[1]),
+                                                         H.ptr(dbeta), H.ptr(dgamma), Ci, H.stream()))
+        xr = torch.zeros(N, Ci, Hh, Hh, device='cuda', requires_grad=True)
+        torch.nn.functional.conv2d(xr, w.float().permute(0, 3, 1, 2), stride=stride, padding=k // 2).backward(dy.float().permute(0, 3, 1, 2))
+        gref = (xr.grad.permute(0, 2, 3, 1) * (z.float() > 0)).reshape(-1, Ci)
+        zf = z.float().reshape(-1, Ci)
+        xh = (zf - beta) / gamma                                      # xhat as the gate lets it be recovered (where z > 0)
+        want_g, want_gx = gref.sum(0).cpu(), (gref * xh).sum(0).cpu()
+        scale = float(gref.abs().sum(0).max())
+        close(dx.float().reshape(-1, Ci), gref.cpu(), 2e-2, 2e-2, 'gated dgrad')
+        close(sums[0], want_g, 5e-3, 5e-3 * scale, 'sum g')
+        close(sums[1], want_gx, 5e-3, 1e-2 * scale, 'sum g*xhat')
+        close(dbeta - 1, want_g, 5e-3, 5e-3 * scale, 'dbeta acc')
+
+
 def test_native_trunk_matches_module_walk():
     """evk_trunk_forward / evk_trunk_backward (one C call per direction) against the op-by-op walk over the same parameter
     holders (conv2d / batchnorm / max-pool autograd wrappers).  Eval mode (running statistics) must agree tightly; in
