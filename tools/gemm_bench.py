@@ -5,7 +5,7 @@ import torch
 sys.path.insert(0, '.')
 from evoke_amd import hip as H, ops
 
-BF = torch.bfloat16
+BF = H.STORE_DTYPE
 
 
 def time_it(fn, iters=20):
