@@ -235,9 +235,13 @@ __global__ void optim_bump_kernel(int* __restrict__ steps, int count, const floa
 }
 
 // optim_kernel with the step count, the loss scale and the skip decision read from device memory
-struct OptDyn { OptP o; const int* step; const float* state; float inv_world; };
+struct OptDyn { OptP o; const int* step; const float* state; float inv_world; int zero_g; };
 __global__ __launch_bounds__(256) void optim_dyn_kernel(const OptDyn d) {
-  if (d.state && d.state[2] != 0.f) return;            // global overflow skip: no element of any parameter moves
+  if (d.state && d.state[2] != 0.f) {                  // global overflow skip: no element of any parameter moves
+    if (d.zero_g)                                      // ... but the (non-finite) gradients are consumed like on a taken step
+      for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < d.o.n; i += (long)gridDim.x * blockDim.x) const_cast<float*>(d.o.g)[i] = 0.f;
+    return;
+  }
   __shared__ float hp[4];
   __shared__ int rect_on;
   if (threadIdx.x == 0) {
@@ -261,6 +265,7 @@ __global__ __launch_bounds__(256) void optim_dyn_kernel(const OptDyn d) {
   const int use_rect = rect_on;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < o.n; i += (long)gridDim.x * blockDim.x) {
     float g = o.g[i] * gscale;
+    if (d.zero_g) const_cast<float*>(o.g)[i] = 0.f;     // the step consumes the gradient: no separate zero_grad pass over the buffer
     if (o.clip > 0.f) g = fminf(fmaxf(g, -o.clip), o.clip);
     float w = o.p[i];
     if (o.wd != 0.f) g += o.wd * w;
@@ -388,13 +393,13 @@ int evk_optim_step_scaled(float* p, const float* g, float* m, float* v, float* v
   return evk_check_launch("optim_step");
 }
 
-int evk_optim_step_dyn(float* p, const float* g, float* m, float* v, float* vmax, void* shadow, int64_t n, int32_t kind, float lr,
+int evk_optim_step_dyn(float* p, float* g, float* m, float* v, float* vmax, void* shadow, int64_t n, int32_t kind, float lr,
                        float beta1, float beta2, float eps, float weight_decay, float clip, const int32_t* step_dev,
-                       const float* scale_state, float inv_world, evk_stream_t stream) {
+                       const float* scale_state, float inv_world, int32_t zero_grad, evk_stream_t stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   EVK_REQUIRE(p && g && m && v && n > 0 && step_dev && (kind == 0 || kind == 1) && inv_world > 0.f, "optim_step_dyn: bad args");
   OptDyn d{{p, g, m, v, vmax, (bf16_t*)shadow, n, lr, beta1, beta2, eps, weight_decay, clip, 0.f, 0.f, 0.f, kind, 0, 1.f},
-           step_dev, scale_state, inv_world};
+           step_dev, scale_state, inv_world, zero_grad};
   ProfScope ps(EVK_FAM_OPTIM, s);
   hipLaunchKernelGGL(optim_dyn_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, d);
   return evk_check_launch("optim_step_dyn");

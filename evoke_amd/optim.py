@@ -57,6 +57,7 @@ class FusedOptimizer(torch.optim.Optimizer):
         self._hist = {}
         self.world = 1              # ranks whose gradients the all-reduce SUMS into the flat buffers (set by GradReducer)
         self._last_touched = []
+        self._step_zeroes = False       # True once a step() with in-kernel gradient zeroing has run (CUDA, world == 1)
         ops.register_grad_callback(self._on_grad)
         for g in self.param_groups:
             ps = g['params']
@@ -145,9 +146,13 @@ class FusedOptimizer(torch.optim.Optimizer):
         return [st['g'] for st in self.flat]
 
     def zero_grad(self, set_to_none=False):
-        """Gradients live in the flat buffers the kernels accumulate into: they are zeroed, never freed."""
-        for st in self.flat:
-            st['g'].zero_()
+        """Gradients live in the flat buffers the kernels accumulate into: they are zeroed, never freed.  On one rank step() has
+        already consumed (zeroed) every gradient it read, so the pass is skipped unless gradients were produced since; with
+        several ranks the all-reduce may have written into parameters this rank did not touch, so the buffers are always cleared."""
+        if self._touched or self.world > 1 or not self._step_zeroes:
+            for st in self.flat:
+                st['g'].zero_()
+            self._touched.clear()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -189,11 +194,12 @@ class FusedOptimizer(torch.optim.Optimizer):
                                                  st['v'].data_ptr() + es, (st['vmax'].data_ptr() + es) if st['vmax'] is not None else None,
                                                  (st['shadow'].data_ptr() + eb) if st['shadow'] is not None else None, b - a, self.kind,
                                                  float(g['lr']), b1, b2, g['eps'], g['weight_decay'], float(self.clip_value or 0.0), step_ptr,
-                                                 sstate, inv_world, H.stream()), 'optim_step')
+                                                 sstate, inv_world, int(self.world == 1), H.stream()), 'optim_step')
                 H.check(H.lib.evk_optim_bump(step_ptr, cnt, sstate, H.stream()), 'optim_bump')
         if scaler is not None:
             scaler.update()
         self._last_touched = [p for g in self.param_groups for p in g['params'] if id(p) in self._touched]
+        self._step_zeroes = on_gpu and self.world == 1
         self._touched.clear()
 
     def replay_hook(self):

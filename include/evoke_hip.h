@@ -352,14 +352,16 @@ int evk_attention_bwd(const void* dout, const void* k, const void* v, const void
  *   evk_optim_step_dyn     evk_optim_step with (a) the step count read from *step_dev (+1), (b) gradients multiplied by
  *                          inv_world / state[0] (inv_world = 1 / ranks: the all-reduce sums, the loss is NOT pre-divided, so
  *                          16-bit activation gradients keep the full loss scale on every rank), (c) no update at all when
- *                          state[2] is set.  scale_state may be NULL (bf16 storage: scale 1, never skips);
+ *                          state[2] is set; zero_grad != 0: the kernel also writes 0 over every gradient it read (taken or
+ *                          skipped step), which replaces the optimizer.zero_grad() pass over the buffer
+ *                          (trainer_v0401.py:428).  scale_state may be NULL (bf16 storage: scale 1, never skips);
  *   evk_optim_bump         step_dev[0..count) += 1 unless state[2] is set (per-parameter step counts live on the device so
  *                          that a skipped step does not advance them, as GradScaler.step skips optimizer.step);
  *   evk_loss_scale_update  after the optimizer: overflow -> scale *= backoff (>= min_scale), good steps = 0, skipped += 1;
  *                          else good steps += 1 and scale *= growth (<= max_scale) every `interval` good steps; clears [2]. */
-int evk_optim_step_dyn(float* p, const float* g, float* m, float* v, float* vmax, void* shadow, int64_t n, int32_t kind, float lr,
+int evk_optim_step_dyn(float* p, float* g, float* m, float* v, float* vmax, void* shadow, int64_t n, int32_t kind, float lr,
                        float beta1, float beta2, float eps, float weight_decay, float clip, const int32_t* step_dev,
-                       const float* scale_state, float inv_world, evk_stream_t stream);
+                       const float* scale_state, float inv_world, int32_t zero_grad, evk_stream_t stream);
 int evk_optim_bump(int32_t* step_dev, int32_t count, const float* scale_state, evk_stream_t stream);
 int evk_grad_nonfinite(const float* g, int64_t n, float* scale_state, evk_stream_t stream);
 int evk_loss_scale_update(float* scale_state, float growth, float backoff, int32_t interval, float min_scale, float max_scale,

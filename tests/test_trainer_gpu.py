@@ -139,7 +139,7 @@ def test_dynamic_loss_scale_skips_the_whole_step_on_overflow():
         before = p.clone()
         H.check(H.lib.evk_grad_nonfinite(H.ptr(summed), n, H.ptr(state), H.stream()))
         H.check(H.lib.evk_optim_step_dyn(H.ptr(p), H.ptr(summed), H.ptr(m), H.ptr(v), None, None, n, 0, 5e-3, 0.9, 0.999, 1e-8, 1e-4, 0.1,
-                                         H.ptr(steps), H.ptr(state), 1.0 / world, H.stream()))
+                                         H.ptr(steps), H.ptr(state), 1.0 / world, 0, H.stream()))
         H.check(H.lib.evk_optim_bump(H.ptr(steps), 2, H.ptr(state), H.stream()))
         H.check(H.lib.evk_loss_scale_update(H.ptr(state), 2.0, 0.5, interval, 1.0, 65536.0, H.stream()))
         if i in skipped_at:
