@@ -414,6 +414,22 @@ def main():
 
 
 if __name__ == '__main__':
+    # ONE JSON line on stdout: libraries that write banners to fd 1 (RCCL prints its version block there at communicator creation)
+    # are sent to stderr for the duration of the run; the real stdout is restored for the result line
+    sys.stdout.flush()
+    _real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    _print = print
+
+    def print(*a, **k):          # noqa: A001 -- module-level override used by main() / bench_decode() for the result line
+        if k.get('file') is None:
+            sys.stdout.flush()
+            os.dup2(_real_stdout, 1)
+            _print(*a, **k)
+            sys.stdout.flush()
+            os.dup2(2, 1)
+        else:
+            _print(*a, **k)
     try:
         main()
     finally:
