@@ -1,5 +1,6 @@
 // conv.hip -- NHWC bf16 convolutions of the ResNet-101 trunk as implicit GEMMs (visual_extractor.py:30-38
 // -> torchvision resnet101 children 0-7) on top of gemm.hip, plus the stem's pack / unpack kernels.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -75,8 +76,23 @@ static int stats_rows(int M, int N) { return N <= 64 ? (int)((M + 255) / 256) * 
 
 int64_t evk_conv_stats_bytes(int64_t M, int32_t C) { return (int64_t)stats_rows((int)M, C) * 2 * C * (int64_t)sizeof(float); }
 
+// short-K, wide-N pointwise products (Bottleneck conv3 forward, conv1 data gradient) go to the weight-stationary kernel
+static bool use_ws(const evk_conv_geom* g, int64_t M, int K, int N) {
+  static const int on = [] { const char* e = getenv("EVK_CONV1X1_WS"); return e ? atoi(e) : 1; }();
+  return on && is_pointwise(g) && N >= 2 * K && evk_conv1x1_ws_supported(M, K, N);
+}
+
 int evk_conv2d_fwd_stats(const void* x, const void* w, void* y, const evk_conv_geom* g, float* part, int64_t part_bytes,
                          int32_t* nblk, evk_stream_t stream) {
+  if (int e = check_geom(g)) return e;
+  const int64_t M = (int64_t)g->N * g->Ho * g->Wo;
+  if (use_ws(g, M, g->Ci, g->Co) && (!part || part_bytes >= evk_conv1x1_ws_part_bytes(M, g->Ci, g->Co)))
+    return evk_conv1x1_ws_fwd(x, w, y, M, g->Ci, g->Co, part, part_bytes, nblk, stream);
+  return evk_conv2d_fwd_stats_tile(x, w, y, g, part, part_bytes, nblk, stream);
+}
+
+int evk_conv2d_fwd_stats_tile(const void* x, const void* w, void* y, const evk_conv_geom* g, float* part, int64_t part_bytes,
+                              int32_t* nblk, evk_stream_t stream) {
   if (int e = check_geom(g)) return e;
   evk_gemm d{};
   if (part) {
@@ -111,6 +127,11 @@ int evk_conv2d_dgrad_gated(const void* dy, const void* w, const void* resid, con
 int evk_conv2d_dgrad_gated_stats(const void* dy, const void* w, const void* resid, const void* gate, void* dx, const evk_conv_geom* g,
                                  float* part, int64_t part_bytes, int32_t* nblk, evk_stream_t stream) {
   if (int e = check_geom(g)) return e;
+  {
+    const int64_t M = (int64_t)g->N * g->Hi * g->Wi;
+    if (use_ws(g, M, g->Co, g->Ci) && (!part || (gate && part_bytes >= evk_conv1x1_ws_part_bytes(M, g->Co, g->Ci))))
+      return evk_conv1x1_ws_dgrad(dy, w, resid, gate, dx, M, g->Co, g->Ci, part, part_bytes, nblk, stream);
+  }
   const int T = g->KH * g->KW;
   EVK_REQUIRE(ilog2_exact(g->Co) >= 3, "conv dgrad: Co must be a power of two >= 8");
   evk_gemm d{};

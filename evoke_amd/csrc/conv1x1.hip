@@ -1,0 +1,308 @@
+// conv1x1.hip -- weight-stationary kernel for the SHORT-K pointwise convolutions of the ResNet trunk (torchvision Bottleneck
+// conv3: planes -> 4*planes, and the data gradient of conv1: the same shape mirrored; modules/visual_extractor.py:27-43).
+//
+// These products (K = 64 ... 512 input channels, N = 4K output channels, M = 10^4 ... 10^6 pixels) are memory bound -- 205 flop
+// per byte of compulsory traffic at K = 256 -- yet the tile GEMM of gemm.hip runs them at 1.6 TB/s of algorithmic traffic: a
+// 128 x 128 tile with K = 256 pulls 128 KB of operands through the CU's vector L1 for 32 KB of output, and one CU's L1 fills at
+// ~27 GB/s.  Here the WEIGHTS never move: a workgroup owns a slice of 4 x NW output channels, each of its four
+// waves keeps its NW x K weight block in registers as MFMA A fragments for the whole launch (128 VGPRs at K = 256, NW = 64), and
+// the workgroup walks its share of the pixel tiles: the activation tile (128 pixels x K, the only operand that streams) is staged
+// in LDS once and read by all four waves, double buffered against the next tile's global loads.  Fill bytes per output byte drop
+// 4x at N = 1024; the output leaves through a wave-private LDS transpose as whole 128-byte rows.
+//   D[channel][pixel] = sum_k W[channel][k] * X[pixel][k]:  A operand = W rows (K-contiguous), B operand = pixel rows (K-contiguous,
+//   NHWC), so a lane ends up with 4 consecutive channels of one pixel.
+// Epilogues: forward = per-channel sum / sum of squares partials for the batch norm that follows (one partial row per pixel tile,
+// bn.hip's second stage sums them); data gradient = + skip gradient, ReLU gate, gate statistics (sum g, sum g*z).
+#include <stdlib.h>
+#include <algorithm>
+#include "common.h"
+
+namespace {
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true);
+  return v + __builtin_bit_cast(float, t);
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v = dpp_add<0xB1>(v);     // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);     // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);    // row_half_mirror
+  return dpp_add<0x140>(v); // row_mirror
+}
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+__device__ __forceinline__ s16x4 lds_tr_read(const bf16_t* generic_lds_ptr) {
+  lds_s16x4* p = (lds_s16x4*)(__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(uintptr_t)generic_lds_ptr;
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(p);
+}
+
+struct WsP {
+  const bf16_t* x;      // [M][K] activations (fwd: conv input; dgrad: dy)
+  const bf16_t* w;      // fwd: W[N = Co][K = Ci] (K-contiguous); dgrad: W[K = Co][N = Ci] as stored (transposed on the way into registers)
+  bf16_t* y;            // [M][N]
+  const bf16_t* skip;   // dgrad: optional [M][N] added before the gate
+  const bf16_t* gate;   // dgrad: optional [M][N], output zeroed where gate <= 0
+  float* part;          // optional [ntiles][2][N]: fwd (sum, sumsq) of y; dgrad (sum g, sum g*gate)
+  long M; int N, ntiles, slices, groups;
+};
+
+template <int K, int NW, int MT, bool DGRAD, int NWV>
+__global__ __launch_bounds__(64 * NWV, 1) void conv1x1_ws_kernel(const WsP p) {
+  constexpr int KS = K / 32, NT = NW / 16, LDA = K + 8;
+  constexpr int NTHR = 64 * NWV;
+  constexpr int CH = MT * K / 8 / NTHR;                // 16-byte chunks of an activation tile per thread
+  constexpr int OST = NW + 8;                          // row stride of the wave-private output transpose (16-bit elements)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* abuf = reinterpret_cast<bf16_t*>(smem);                          // [2][MT][LDA]
+  constexpr int NS = NWV * NW, LW = NS + 8;
+  constexpr int ABUF = (2 * MT * LDA > (DGRAD ? K * LW : 0)) ? 2 * MT * LDA : K * LW;      // elements: tile double buffer / weight staging
+  bf16_t* obuf = abuf + ABUF;                                              // [NWV waves][16][OST] output transpose
+  bf16_t* sbuf = obuf;                                                     // dgrad: the skip rows arrive in the buffer the output leaves through
+  bf16_t* gbuf = obuf + NWV * 16 * OST;                                    // (each lane reads its 8 bytes before it overwrites them); gate rows
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  // XCD-aware mapping: the `slices` workgroups that read the same pixel tiles sit on one XCD (blockIdx % 8 labels the XCD)
+  int slice, grp;
+  {
+    const int bid = blockIdx.x;
+    if (p.groups % 8 == 0) { const int xcd = bid & 7, idx = bid >> 3; grp = xcd + 8 * (idx / p.slices); slice = idx % p.slices; }
+    else { grp = bid / p.slices; slice = bid % p.slices; }
+  }
+  const int n0 = slice * NWV * NW + wave * NW;         // first output channel of this wave
+  // ---- the wave's weights: NT x KS A fragments, resident for the whole launch
+  bf16x8 wf[NT][KS];
+  if (!DGRAD) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) wf[nt][ks] = *reinterpret_cast<const bf16x8*>(p.w + (long)(n0 + nt * 16 + li) * K + ks * 32 + g * 8);
+  } else {
+    // data gradient: the weights lie [K = Co][N = Ci] (n contiguous).  The workgroup's [K][NS] slice goes through LDS as it lies and
+    // the A fragments (8 consecutive k of one channel) come back through the transposing LDS read (two 4 x 16 blocks per fragment)
+    for (int c = tid; c < K * (NS / 8); c += NTHR) {
+      const int k = c / (NS / 8), c8 = c % (NS / 8);
+      *reinterpret_cast<uint4*>(abuf + k * LW + c8 * 8) = *reinterpret_cast<const uint4*>(p.w + (long)k * p.N + slice * NS + c8 * 8);
+    }
+    __syncthreads();
+    const int q4 = li >> 2, p4 = li & 3;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16_t* tb = abuf + (ks * 32 + g * 8 + q4) * LW + wave * NW + nt * 16 + p4 * 4;
+        const s16x4 lo = lds_tr_read(tb), hi = lds_tr_read(tb + 4 * LW);
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        wf[nt][ks] = __builtin_bit_cast(bf16x8, r);
+      }
+    __syncthreads();
+  }
+
+  uint4 pf[CH];
+  auto fetch = [&](int t) {                            // global -> registers: tile t (rows beyond M read as zero)
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int ch = tid + NTHR * c, r = ch / (K / 8), kc = ch % (K / 8);
+      const long row = (long)t * MT + r;
+      pf[c] = row < p.M ? *reinterpret_cast<const uint4*>(p.x + row * K + kc * 8) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto stash = [&](int buf) {                          // registers -> LDS
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int ch = tid + NTHR * c, r = ch / (K / 8), kc = ch % (K / 8);
+      *reinterpret_cast<uint4*>(abuf + (buf * MT + r) * LDA + kc * 8) = pf[c];
+    }
+  };
+  int t = grp;
+  if (t < p.ntiles) { fetch(t); stash(0); }
+  __syncthreads();
+  int cur = 0;
+  bf16_t* ow = obuf + wave * 16 * OST;
+  for (; t < p.ntiles; t += p.groups) {
+    const int tn = t + p.groups;
+    if (tn < p.ntiles) fetch(tn);                      // in flight while this tile multiplies
+    float s0[NT][4], s1[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s0[nt][j] = 0.f; s1[nt][j] = 0.f; }
+    const bf16_t* at = abuf + cur * MT * LDA;
+#pragma unroll 1
+    for (int mt = 0; mt < MT / 16; ++mt) {
+      f32x4 acc[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      constexpr int CPR = NW / 8;                       // 16-byte chunks per pixel row of the wave's NW channels
+      constexpr int NCH = (16 * CPR + 63) / 64;         // chunks per lane for a 16-pixel group
+      // data gradient: the skip / gate rows of this pixel group, whole rows, in flight while the group multiplies
+      uint4 skv[NCH], gtv[NCH];
+      if (DGRAD) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          const int c = lane + 64 * i, pr = c / CPR, cc = c % CPR;
+          const long prow = (long)t * MT + mt * 16 + pr;
+          const bool ok = c < 16 * CPR && prow < p.M;
+          skv[i] = (ok && p.skip) ? *reinterpret_cast<const uint4*>(p.skip + prow * p.N + n0 + cc * 8) : make_uint4(0, 0, 0, 0);
+          gtv[i] = (ok && p.gate) ? *reinterpret_cast<const uint4*>(p.gate + prow * p.N + n0 + cc * 8) : make_uint4(0, 0, 0, 0);
+        }
+      }
+      const bf16_t* brow = at + (mt * 16 + li) * LDA + g * 8;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(brow + ks * 32);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = EVK_MFMA_16x16x32(wf[nt][ks], b, acc[nt], 0, 0, 0);
+      }
+      bf16_t* sw = sbuf + wave * 16 * OST;
+      bf16_t* gw = gbuf + wave * 16 * OST;
+      if (DGRAD) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          const int c = lane + 64 * i, pr = c / CPR, cc = c % CPR;
+          if (c < 16 * CPR) {
+            *reinterpret_cast<uint4*>(sw + pr * OST + cc * 8) = skv[i];
+            *reinterpret_cast<uint4*>(gw + pr * OST + cc * 8) = gtv[i];
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+      // lane holds D[channel n0 + nt*16 + 4g + j][pixel t*MT + mt*16 + li]
+      const long pix = (long)t * MT + mt * 16 + li;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        float v[4] = {acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]};
+        if (DGRAD) {
+          if (pix < p.M) {
+            if (p.skip) { const uint2 sk = *reinterpret_cast<const uint2*>(sw + li * OST + nt * 16 + g * 4); v[0] += lo_bf(sk.x); v[1] += hi_bf(sk.x); v[2] += lo_bf(sk.y); v[3] += hi_bf(sk.y); }
+            if (p.gate) {
+              const uint2 gt = *reinterpret_cast<const uint2*>(gw + li * OST + nt * 16 + g * 4);
+              const float gv[4] = {lo_bf(gt.x), hi_bf(gt.x), lo_bf(gt.y), hi_bf(gt.y)};
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { if (!(gv[j] > 0.f)) v[j] = 0.f; s0[nt][j] += v[j]; s1[nt][j] += v[j] * gv[j]; }
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { s0[nt][j] += v[j]; s1[nt][j] += v[j] * v[j]; }
+        }
+        *reinterpret_cast<uint2*>(ow + li * OST + nt * 16 + g * 4) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // 16 pixels x NW channels leave as whole rows: NW * 2 bytes per pixel, 16 bytes per lane
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i, pr = c / CPR, cc = c % CPR;
+        const long prow = (long)t * MT + mt * 16 + pr;
+        if (c < 16 * CPR && prow < p.M) *reinterpret_cast<uint4*>(p.y + prow * p.N + n0 + cc * 8) = *reinterpret_cast<const uint4*>(ow + pr * OST + cc * 8);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (p.part) {
+      float* prow = p.part + (long)t * 2 * p.N;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        float a[4], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] = row16_sum(s0[nt][j]); b[j] = row16_sum(s1[nt][j]); }
+        if (li == 0) {
+          const int c = n0 + nt * 16 + g * 4;
+          *reinterpret_cast<float4*>(prow + c) = make_float4(a[0], a[1], a[2], a[3]);
+          *reinterpret_cast<float4*>(prow + p.N + c) = make_float4(b[0], b[1], b[2], b[3]);
+        }
+      }
+    }
+    if (tn < p.ntiles) stash(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+template <int K, int NW, int MT, bool DGRAD, int NWV>
+int launch_ws(WsP p, hipStream_t s) {
+  const size_t abuf = std::max((size_t)2 * MT * (K + 8), DGRAD ? (size_t)K * (NWV * NW + 8) : (size_t)0);
+  const size_t lds = abuf * 2 + (size_t)(DGRAD ? 2 : 1) * NWV * 16 * (NW + 8) * 2;
+  static bool configured = false;
+  if (!configured && lds > 65536) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_ws_kernel<K, NW, MT, DGRAD, NWV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      evk_set_error("conv1x1_ws: hipFuncSetAttribute failed");
+      return EVK_ELAUNCH;
+    }
+    configured = true;
+  }
+  p.ntiles = (int)cdiv(p.M, MT);
+  p.slices = p.N / (NWV * NW);
+  int groups = 256 / p.slices;
+  if (groups < 1) groups = 1;
+  if (groups > p.ntiles) groups = p.ntiles;
+  if (groups >= 8) groups &= ~7;
+  p.groups = groups;
+  ProfScope ps(EVK_FAM_GEMM, s, 2.0 * (double)p.M * p.N * K);
+  evk_prof_tag((int)p.M, p.N, K, 1, 0, DGRAD ? 1 : 0);
+  hipLaunchKernelGGL((conv1x1_ws_kernel<K, NW, MT, DGRAD, NWV>), dim3(p.slices * groups), dim3(64 * NWV), lds, s, p);
+  return evk_check_launch("conv1x1_ws");
+}
+
+template <bool DGRAD>
+int dispatch(const WsP& p, int K, hipStream_t s) {
+  static const int v8 = [] { const char* e = getenv("EVK_WS_WAVES8"); return e ? atoi(e) : 1; }();
+  if (v8) switch (K) {          // 8 waves x 32 channels (2 waves per SIMD hide the LDS / store latency of the per-16-pixel epilogue)
+    case 64: return launch_ws<64, 32, 128, DGRAD, 8>(p, s);
+    case 128: return launch_ws<128, 32, 128, DGRAD, 8>(p, s);
+    case 256: return launch_ws<256, 32, 128, DGRAD, 8>(p, s);
+    case 512: return launch_ws<512, 16, 64, DGRAD, 8>(p, s);
+    default: break;
+  }
+  switch (K) {
+    case 64: return launch_ws<64, 64, 128, DGRAD, 4>(p, s);
+    case 128: return launch_ws<128, 64, 128, DGRAD, 4>(p, s);
+    case 256: return launch_ws<256, 64, 128, DGRAD, 4>(p, s);
+    case 512: return launch_ws<512, 32, 64, DGRAD, 4>(p, s);
+    default: evk_set_error("conv1x1_ws: unsupported K = %d", K); return EVK_EINVAL;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+/* 1 when the weight-stationary kernel takes the product: K in {64, 128, 256, 512}, N a multiple of the workgroup's channel slice */
+int evk_conv1x1_ws_supported(int64_t M, int32_t K, int32_t N) {
+  if (M <= 0 || N <= 0) return 0;
+  if (K == 64 || K == 128 || K == 256) return N % 256 == 0;
+  if (K == 512) return N % 128 == 0;
+  return 0;
+}
+
+int64_t evk_conv1x1_ws_part_bytes(int64_t M, int32_t K, int32_t N) { return cdiv(M, K == 512 ? 64 : 128) * 2 * (int64_t)N * 4; }
+
+int evk_conv1x1_ws_fwd(const void* x, const void* w, void* y, int64_t M, int32_t K, int32_t N, float* part, int64_t part_bytes, int32_t* nblk,
+                       evk_stream_t stream) {
+  EVK_REQUIRE(x && w && y && evk_conv1x1_ws_supported(M, K, N), "conv1x1_ws_fwd: unsupported problem M=%ld K=%d N=%d", (long)M, K, N);
+  EVK_REQUIRE(!part || (nblk && part_bytes >= evk_conv1x1_ws_part_bytes(M, K, N)), "conv1x1_ws_fwd: statistics buffer too small");
+  if (part) *nblk = (int)cdiv(M, K == 512 ? 64 : 128);
+  WsP p{(const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, nullptr, nullptr, part, M, N, 0, 0, 0};
+  return dispatch<false>(p, K, reinterpret_cast<hipStream_t>(stream));
+}
+
+/* dx[M][N] = gate(dy[M][K] . W[K][N] + skip): W as the forward stores it, [K = Co][N = Ci] */
+int evk_conv1x1_ws_dgrad(const void* dy, const void* wt, const void* skip, const void* gate, void* dx, int64_t M, int32_t K, int32_t N,
+                         float* part, int64_t part_bytes, int32_t* nblk, evk_stream_t stream) {
+  EVK_REQUIRE(dy && wt && dx && evk_conv1x1_ws_supported(M, K, N), "conv1x1_ws_dgrad: unsupported problem M=%ld K=%d N=%d", (long)M, K, N);
+  EVK_REQUIRE(!part || (gate && nblk && part_bytes >= evk_conv1x1_ws_part_bytes(M, K, N)), "conv1x1_ws_dgrad: gate statistics need a gate and a large enough buffer");
+  if (part) *nblk = (int)cdiv(M, K == 512 ? 64 : 128);
+  WsP p{(const bf16_t*)dy, (const bf16_t*)wt, (bf16_t*)dx, (const bf16_t*)skip, (const bf16_t*)gate, part, M, N, 0, 0, 0};
+  return dispatch<true>(p, K, reinterpret_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -125,11 +125,26 @@ int evk_conv2d_fwd(const void* x, const void* w, void* y, const evk_conv_geom* g
 int64_t evk_conv_stats_bytes(int64_t M, int32_t C);
 int evk_conv2d_fwd_stats(const void* x, const void* w, void* y, const evk_conv_geom* g, float* part, int64_t part_bytes,
                          int32_t* nblk, evk_stream_t stream);
+/* the tile-GEMM path of evk_conv2d_fwd_stats, bypassing the routing to the weight-stationary kernel (tests / probes compare the two) */
+int evk_conv2d_fwd_stats_tile(const void* x, const void* w, void* y, const evk_conv_geom* g, float* part, int64_t part_bytes,
+                         int32_t* nblk, evk_stream_t stream);
 int evk_conv2d_dgrad(const void* dy, const void* w, void* dx, const evk_conv_geom* g, evk_stream_t stream);
 /* dx = dgrad(dy, w) + resid (bf16, shape of dx): the skip-connection gradient of a residual block joins in the epilogue */
 int evk_conv2d_dgrad_add(const void* dy, const void* w, const void* resid, void* dx, const evk_conv_geom* g, evk_stream_t stream);
 /* dx = relu'(gate) * (dgrad(dy, w) + resid): also applies the ReLU gate of the tensor dx belongs to (gate = that tensor's
  * post-ReLU forward value), so the batch-norm backward that consumes dx needs no mask pass                          */
+/* Weight-stationary kernel for the short-K pointwise convolutions (conv1x1.hip): y[M][N] = x[M][K] . w[N][K]^T with the weights
+ * held in registers for the whole launch and only the pixel tiles streaming (torchvision Bottleneck conv3 forward: planes -> 4 planes;
+ * the data gradient of conv1 is the same shape with the transposed weights).  K in {64, 128, 256, 512}; N a multiple of 256 (128 at
+ * K = 512): evk_conv1x1_ws_supported.  part (optional): *nblk rows of [2][N] partial sums, one per pixel tile -- forward: (sum y, sum
+ * y^2) for the batch norm that follows (evk_bn_stats_finalize_from_partials); dgrad: (sum g, sum g*gate) of the gated output
+ * (evk_bn_bwd_sums_from_gate_partials).  evk_conv2d_fwd_stats / evk_conv2d_dgrad_gated_stats route eligible problems here. */
+int evk_conv1x1_ws_supported(int64_t M, int32_t K, int32_t N);
+int64_t evk_conv1x1_ws_part_bytes(int64_t M, int32_t K, int32_t N);
+int evk_conv1x1_ws_fwd(const void* x, const void* w, void* y, int64_t M, int32_t K, int32_t N, float* part, int64_t part_bytes, int32_t* nblk,
+                       evk_stream_t stream);
+int evk_conv1x1_ws_dgrad(const void* dy, const void* wt, const void* skip, const void* gate, void* dx, int64_t M, int32_t K, int32_t N,
+                         float* part, int64_t part_bytes, int32_t* nblk, evk_stream_t stream);
 /* evk_conv2d_dgrad_gated + the gate statistics of evk_gemm.gatestats: part receives *nblk rows of [2][Ci] (evk_conv_stats_bytes(rows of
  * dx, Ci) bytes) */
 int evk_conv2d_dgrad_gated_stats(const void* dy, const void* w, const void* resid, const void* gate, void* dx, const evk_conv_geom* g,
