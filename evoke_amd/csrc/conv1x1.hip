@@ -57,7 +57,8 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv1x1_ws_kernel(const WsP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* abuf = reinterpret_cast<bf16_t*>(smem);                          // [2][MT][LDA]
   constexpr int NS = NWV * NW, LW = NS + 8;
-  constexpr int ABUF = (2 * MT * LDA > (DGRAD ? K * LW : 0)) ? 2 * MT * LDA : K * LW;      // elements: tile double buffer / weight staging
+  constexpr int KCW = K < 256 ? K : 256;
+  constexpr int ABUF = (2 * MT * LDA > (DGRAD ? KCW * LW : 0)) ? 2 * MT * LDA : KCW * LW;  // elements: tile double buffer / weight staging
   bf16_t* obuf = abuf + ABUF;                                              // [NWV waves][16][OST] output transpose
   bf16_t* sbuf = obuf;                                                     // dgrad: the skip rows arrive in the buffer the output leaves through
   bf16_t* gbuf = obuf + NWV * 16 * OST;                                    // (each lane reads its 8 bytes before it overwrites them); gate rows
@@ -80,22 +81,27 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv1x1_ws_kernel(const WsP p) {
   } else {
     // data gradient: the weights lie [K = Co][N = Ci] (n contiguous).  The workgroup's [K][NS] slice goes through LDS as it lies and
     // the A fragments (8 consecutive k of one channel) come back through the transposing LDS read (two 4 x 16 blocks per fragment)
-    for (int c = tid; c < K * (NS / 8); c += NTHR) {
-      const int k = c / (NS / 8), c8 = c % (NS / 8);
-      *reinterpret_cast<uint4*>(abuf + k * LW + c8 * 8) = *reinterpret_cast<const uint4*>(p.w + (long)k * p.N + slice * NS + c8 * 8);
-    }
-    __syncthreads();
+    constexpr int KC = K < 256 ? K : 256;               // rows of the weight slice staged at a time
     const int q4 = li >> 2, p4 = li & 3;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const bf16_t* tb = abuf + (ks * 32 + g * 8 + q4) * LW + wave * NW + nt * 16 + p4 * 4;
-        const s16x4 lo = lds_tr_read(tb), hi = lds_tr_read(tb + 4 * LW);
-        typedef __attribute__((ext_vector_type(8))) short s16x8;
-        const s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        wf[nt][ks] = __builtin_bit_cast(bf16x8, r);
+    for (int kc = 0; kc < K; kc += KC) {
+      __syncthreads();
+      for (int c = tid; c < KC * (NS / 8); c += NTHR) {
+        const int k = c / (NS / 8), c8 = c % (NS / 8);
+        *reinterpret_cast<uint4*>(abuf + k * LW + c8 * 8) = *reinterpret_cast<const uint4*>(p.w + (long)(kc + k) * p.N + slice * NS + c8 * 8);
       }
+      __syncthreads();
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int k2 = 0; k2 < KC / 32; ++k2) {
+          const bf16_t* tb = abuf + (k2 * 32 + g * 8 + q4) * LW + wave * NW + nt * 16 + p4 * 4;
+          const s16x4 lo = lds_tr_read(tb), hi = lds_tr_read(tb + 4 * LW);
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          const s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          wf[nt][kc / 32 + k2] = __builtin_bit_cast(bf16x8, r);
+        }
+    }
     __syncthreads();
   }
 
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv1x1_ws_kernel(const WsP p) {
 
 template <int K, int NW, int MT, bool DGRAD, int NWV>
 int launch_ws(WsP p, hipStream_t s) {
-  const size_t abuf = std::max((size_t)2 * MT * (K + 8), DGRAD ? (size_t)K * (NWV * NW + 8) : (size_t)0);
+  const size_t abuf = std::max((size_t)2 * MT * (K + 8), DGRAD ? (size_t)(K < 256 ? K : 256) * (NWV * NW + 8) : (size_t)0);
   const size_t lds = abuf * 2 + (size_t)(DGRAD ? 2 : 1) * NWV * 16 * (NW + 8) * 2;
   static bool configured = false;
   if (!configured && lds > 65536) {
@@ -261,6 +267,7 @@ int dispatch(const WsP& p, int K, hipStream_t s) {
     case 128: return launch_ws<128, 32, 128, DGRAD, 8>(p, s);
     case 256: return launch_ws<256, 32, 128, DGRAD, 8>(p, s);
     case 512: return launch_ws<512, 16, 64, DGRAD, 8>(p, s);
+    case 1024: return launch_ws<1024, 16, 32, DGRAD, 8>(p, s);
     default: break;
   }
   switch (K) {
@@ -268,6 +275,7 @@ int dispatch(const WsP& p, int K, hipStream_t s) {
     case 128: return launch_ws<128, 64, 128, DGRAD, 4>(p, s);
     case 256: return launch_ws<256, 64, 128, DGRAD, 4>(p, s);
     case 512: return launch_ws<512, 32, 64, DGRAD, 4>(p, s);
+    case 1024: return launch_ws<1024, 16, 32, DGRAD, 8>(p, s);
     default: evk_set_error("conv1x1_ws: unsupported K = %d", K); return EVK_EINVAL;
   }
 }
@@ -276,21 +284,22 @@ int dispatch(const WsP& p, int K, hipStream_t s) {
 
 extern "C" {
 
-/* 1 when the weight-stationary kernel takes the product: K in {64, 128, 256, 512}, N a multiple of the workgroup's channel slice */
+/* 1 when the weight-stationary kernel takes the product: K in {64, 128, 256, 512, 1024}, N a multiple of the workgroup's channel slice */
 int evk_conv1x1_ws_supported(int64_t M, int32_t K, int32_t N) {
   if (M <= 0 || N <= 0) return 0;
   if (K == 64 || K == 128 || K == 256) return N % 256 == 0;
-  if (K == 512) return N % 128 == 0;
+  if (K == 512 || K == 1024) return N % 128 == 0;
   return 0;
 }
 
-int64_t evk_conv1x1_ws_part_bytes(int64_t M, int32_t K, int32_t N) { return cdiv(M, K == 512 ? 64 : 128) * 2 * (int64_t)N * 4; }
+static int ws_tile_rows(int K) { return K == 1024 ? 32 : (K == 512 ? 64 : 128); }
+int64_t evk_conv1x1_ws_part_bytes(int64_t M, int32_t K, int32_t N) { return cdiv(M, ws_tile_rows(K)) * 2 * (int64_t)N * 4; }
 
 int evk_conv1x1_ws_fwd(const void* x, const void* w, void* y, int64_t M, int32_t K, int32_t N, float* part, int64_t part_bytes, int32_t* nblk,
                        evk_stream_t stream) {
   EVK_REQUIRE(x && w && y && evk_conv1x1_ws_supported(M, K, N), "conv1x1_ws_fwd: unsupported problem M=%ld K=%d N=%d", (long)M, K, N);
   EVK_REQUIRE(!part || (nblk && part_bytes >= evk_conv1x1_ws_part_bytes(M, K, N)), "conv1x1_ws_fwd: statistics buffer too small");
-  if (part) *nblk = (int)cdiv(M, K == 512 ? 64 : 128);
+  if (part) *nblk = (int)cdiv(M, ws_tile_rows(K));
   WsP p{(const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, nullptr, nullptr, part, M, N, 0, 0, 0};
   return dispatch<false>(p, K, reinterpret_cast<hipStream_t>(stream));
 }
@@ -300,7 +309,7 @@ int evk_conv1x1_ws_dgrad(const void* dy, const void* wt, const void* skip, const
                          float* part, int64_t part_bytes, int32_t* nblk, evk_stream_t stream) {
   EVK_REQUIRE(dy && wt && dx && evk_conv1x1_ws_supported(M, K, N), "conv1x1_ws_dgrad: unsupported problem M=%ld K=%d N=%d", (long)M, K, N);
   EVK_REQUIRE(!part || (gate && nblk && part_bytes >= evk_conv1x1_ws_part_bytes(M, K, N)), "conv1x1_ws_dgrad: gate statistics need a gate and a large enough buffer");
-  if (part) *nblk = (int)cdiv(M, K == 512 ? 64 : 128);
+  if (part) *nblk = (int)cdiv(M, ws_tile_rows(K));
   WsP p{(const bf16_t*)dy, (const bf16_t*)wt, (bf16_t*)dx, (const bf16_t*)skip, (const bf16_t*)gate, part, M, N, 0, 0, 0};
   return dispatch<true>(p, K, reinterpret_cast<hipStream_t>(stream));
 }

@@ -135,8 +135,8 @@ int evk_conv2d_dgrad_add(const void* dy, const void* w, const void* resid, void*
  * post-ReLU forward value), so the batch-norm backward that consumes dx needs no mask pass                          */
 /* Weight-stationary kernel for the short-K pointwise convolutions (conv1x1.hip): y[M][N] = x[M][K] . w[N][K]^T with the weights
  * held in registers for the whole launch and only the pixel tiles streaming (torchvision Bottleneck conv3 forward: planes -> 4 planes;
- * the data gradient of conv1 is the same shape with the transposed weights).  K in {64, 128, 256, 512}; N a multiple of 256 (128 at
- * K = 512): evk_conv1x1_ws_supported.  part (optional): *nblk rows of [2][N] partial sums, one per pixel tile -- forward: (sum y, sum
+ * the data gradient of conv1 is the same shape with the transposed weights; conv1 forward / conv3 data gradient at K = 512, 1024).
+ * K in {64, 128, 256, 512, 1024}; N a multiple of 256 (128 at K >= 512): evk_conv1x1_ws_supported.  part (optional): *nblk rows of [2][N] partial sums, one per pixel tile -- forward: (sum y, sum
  * y^2) for the batch norm that follows (evk_bn_stats_finalize_from_partials); dgrad: (sum g, sum g*gate) of the gated output
  * (evk_bn_bwd_sums_from_gate_partials).  evk_conv2d_fwd_stats / evk_conv2d_dgrad_gated_stats route eligible problems here. */
 int evk_conv1x1_ws_supported(int64_t M, int32_t K, int32_t N);

@@ -221,3 +221,62 @@ def test_kernel_suite_with_the_256x256_tile_forced():
     tail = '\n'.join((r.stdout + r.stderr).splitlines()[-20:])
     print(tail)
     assert r.returncode == 0, tail
+
+
+WS_SHAPES = [(980, 256, 1024), (4608, 64, 256), (2304, 128, 512), (1154, 512, 2048), (2309, 1024, 256), (1000, 512, 128), (1, 64, 256)]
+
+
+@pytest.mark.parametrize('M,K,N', WS_SHAPES)
+def test_weight_stationary_pointwise_conv_forward_and_data_gradient(H, M, K, N):
+    """csrc/conv1x1.hip through its own C-ABI entry points (evk_conv1x1_ws_fwd / _dgrad), ragged M included: the output against the
+    fp32 product of the same rounded operands (one output rounding: 2^-8 relative in bf16, 2^-11 in fp16, plus the f32 summation order),
+    the per-channel statistics partials against the sums of the UNROUNDED product, and the tile GEMM path as a second witness."""
+    assert H.lib.evk_conv1x1_ws_supported(M, K, N) == 1
+    x, w = rnd(M, K, seed=11, scale=0.7).cuda(), rnd(N, K, seed=12, scale=0.05).cuda()
+    ref = x.float() @ w.float().t()
+    y = torch.empty(M, N, dtype=STORE_DTYPE, device='cuda')
+    nb = H.lib.evk_conv1x1_ws_part_bytes(M, K, N)
+    part = torch.zeros(nb // 4, device='cuda')
+    nblk = C.c_int32(0)
+    H.check(H.lib.evk_conv1x1_ws_fwd(H.ptr(x), H.ptr(w), H.ptr(y), M, K, N, H.ptr(part), nb, C.byref(nblk), H.stream()))
+    torch.cuda.synchronize()
+    rt = 2.0 ** -8 if STORE_DTYPE == torch.bfloat16 else 2.0 ** -10
+    close(y, ref.cpu(), rt, 1e-3)
+    s = part[:nblk.value * 2 * N].view(nblk.value, 2, N).sum(0)
+    assert float((s[0] - ref.sum(0)).abs().max()) <= 1e-5 * float(ref.abs().sum(0).max()) + 1e-4
+    assert float((s[1] - (ref ** 2).sum(0)).abs().max()) <= 1e-5 * float((ref ** 2).sum(0).max()) + 1e-4
+    # second witness: the tile path on the same operands rounds the same f32 sums (summation order differs: allow one ulp)
+    g = H.conv_geom(1, 1, M, K, N, 1, 1, 1, 0)
+    y2 = torch.empty(M, N, dtype=STORE_DTYPE, device='cuda')
+    nb2 = H.lib.evk_conv_stats_bytes(M, N)
+    part2 = torch.zeros(nb2 // 4, device='cuda')
+    n2 = C.c_int32(0)
+    H.check(H.lib.evk_conv2d_fwd_stats_tile(H.ptr(x), H.ptr(w), H.ptr(y2), C.byref(g), H.ptr(part2), nb2, C.byref(n2), H.stream()))
+    torch.cuda.synchronize()
+    close(y, y2.float().cpu(), 2 * rt, 1e-3)
+    # data gradient: dx = gate(dy . W + skip), W stored [K][N]; gate statistics = (sum g, sum g * z) per channel
+    wt = w.t().contiguous()
+    skip = rnd(M, N, seed=13, scale=0.3).cuda()
+    gate = torch.relu(rnd(M, N, seed=14).float()).to(STORE_DTYPE).cuda()
+    dx = torch.empty(M, N, dtype=STORE_DTYPE, device='cuda')
+    part.zero_()
+    H.check(H.lib.evk_conv1x1_ws_dgrad(H.ptr(x), H.ptr(wt), H.ptr(skip), H.ptr(gate), H.ptr(dx), M, K, N, H.ptr(part), nb, C.byref(nblk), H.stream()))
+    torch.cuda.synchronize()
+    gref = (ref + skip.float()) * (gate.float() > 0)
+    close(dx, gref.cpu(), rt, 1e-3)
+    s = part[:nblk.value * 2 * N].view(nblk.value, 2, N).sum(0)
+    gz = gref * gate.float()
+    assert float((s[0] - gref.sum(0)).abs().max()) <= 1e-5 * float(gref.abs().sum(0).max()) + 1e-4
+    assert float((s[1] - gz.sum(0)).abs().max()) <= 1e-5 * float(gz.abs().sum(0).max()) + 1e-4
+
+
+def test_weight_stationary_kernel_refuses_what_it_cannot_tile(H):
+    """Shapes outside the instantiated set are reported as unsupported and the entry point returns an error (no fallback inside it)."""
+    assert H.lib.evk_conv1x1_ws_supported(100, 96, 256) == 0
+    assert H.lib.evk_conv1x1_ws_supported(100, 64, 200) == 0
+    x = torch.zeros(100, 96, dtype=STORE_DTYPE, device='cuda')
+    w = torch.zeros(256, 96, dtype=STORE_DTYPE, device='cuda')
+    y = torch.zeros(100, 256, dtype=STORE_DTYPE, device='cuda')
+    part = torch.zeros(1 << 16, device='cuda')
+    n = C.c_int32(0)
+    assert H.lib.evk_conv1x1_ws_fwd(H.ptr(x), H.ptr(w), H.ptr(y), 100, 96, 256, H.ptr(part), part.numel() * 4, C.byref(n), H.stream()) != 0

@@ -7,7 +7,8 @@ sys.path.insert(0, '.')
 from evoke_amd import hip as H
 
 BF = H.STORE_DTYPE
-SHAPES = [(64, 24, 256, 1024), (64, 96, 64, 256), (64, 48, 128, 512), (64, 12, 512, 2048), (5, 14, 256, 1024)]   # images, H, Ci, Co
+SHAPES = [(64, 24, 256, 1024), (64, 96, 64, 256), (64, 48, 128, 512), (64, 12, 512, 2048), (5, 14, 256, 1024),
+          (64, 24, 1024, 256), (64, 48, 512, 128)]   # images, H, Ci, Co
 
 
 def cold(fn, iters=8):
