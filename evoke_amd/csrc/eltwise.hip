@@ -263,26 +263,66 @@ __global__ __launch_bounds__(256) void optim_dyn_kernel(const OptDyn d) {
   const OptP& o = d.o;
   const float bc1 = hp[0], bc2_sqrt = hp[1], rect = hp[2], gscale = hp[3];
   const int use_rect = rect_on;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < o.n; i += (long)gridDim.x * blockDim.x) {
-    float g = o.g[i] * gscale;
-    if (d.zero_g) const_cast<float*>(o.g)[i] = 0.f;     // the step consumes the gradient: no separate zero_grad pass over the buffer
+  // one element of the update (same arithmetic, element by element, as optim_kernel)
+  auto upd = [&](float g, float& w, float& m, float& v, float& vm) {
+    g *= gscale;
     if (o.clip > 0.f) g = fminf(fmaxf(g, -o.clip), o.clip);
-    float w = o.p[i];
     if (o.wd != 0.f) g += o.wd * w;
-    const float m = o.beta1 * o.m[i] + (1.f - o.beta1) * g;
-    const float v = o.beta2 * o.v[i] + (1.f - o.beta2) * g * g;
-    o.m[i] = m; o.v[i] = v;
+    m = o.beta1 * m + (1.f - o.beta1) * g;
+    v = o.beta2 * v + (1.f - o.beta2) * g * g;
     if (o.kind == 0) {
       const float mh = m / bc1;
       if (use_rect) w -= o.lr * mh * rect * bc2_sqrt / (sqrtf(v) + o.eps);
       else w -= o.lr * mh;
     } else {
       float vv = v;
-      if (o.vmax) { vv = fmaxf(o.vmax[i], v); o.vmax[i] = vv; }
+      if (o.vmax) { vv = fmaxf(vm, v); vm = vv; }
       w -= (o.lr / bc1) * m / (sqrtf(vv) / bc2_sqrt + o.eps);
     }
-    o.p[i] = w;
+  };
+  const long gtid = blockIdx.x * (long)blockDim.x + threadIdx.x, gstride = (long)gridDim.x * blockDim.x;
+  // 16-byte lanes over the aligned body.  The buffers of one group share their element offset (optim.py: one flat layout), so a
+  // scalar head of up to 3 elements brings all of them to a 16-byte boundary (8 bytes for the 2-byte shadow) at once; views that
+  // do not line up that way take the scalar loop throughout.
+  const long head = (long)((16 - (reinterpret_cast<uintptr_t>(o.p) & 15)) & 15) >> 2;
+  const bool al = ((reinterpret_cast<uintptr_t>(o.p) & 3) == 0) && head <= o.n &&
+                  (((reinterpret_cast<uintptr_t>(o.g + head) | reinterpret_cast<uintptr_t>(o.m + head) | reinterpret_cast<uintptr_t>(o.v + head) |
+                     (o.vmax ? reinterpret_cast<uintptr_t>(o.vmax + head) : 0)) & 15) == 0) &&
+                  (!o.shadow || (reinterpret_cast<uintptr_t>(o.shadow + head) & 7) == 0);
+  const long n4 = al ? (o.n - head) >> 2 : 0;
+  auto scalar = [&](long i) {
+    float w = o.p[i], m = o.m[i], v = o.v[i], vm = o.vmax ? o.vmax[i] : 0.f;
+    const float g = o.g[i];
+    if (d.zero_g) const_cast<float*>(o.g)[i] = 0.f;     // the step consumes the gradient: no separate zero_grad pass over the buffer
+    upd(g, w, m, v, vm);
+    o.p[i] = w; o.m[i] = m; o.v[i] = v;
+    if (o.vmax) o.vmax[i] = vm;
     if (o.shadow) o.shadow[i] = f2bf(w);
+  };
+  if (!al) {
+    for (long i = gtid; i < o.n; i += gstride) scalar(i);
+    return;
+  }
+  if (gtid < head) scalar(gtid);
+  for (long i = head + (n4 << 2) + gtid; i < o.n; i += gstride) scalar(i);
+  const OptP q{o.p + head, o.g + head, o.m + head, o.v + head, o.vmax ? o.vmax + head : nullptr, o.shadow ? o.shadow + head : nullptr};
+  for (long i = gtid; i < n4; i += gstride) {
+    float4 g4 = reinterpret_cast<const float4*>(q.g)[i], w4 = reinterpret_cast<float4*>(q.p)[i];
+    float4 m4 = reinterpret_cast<float4*>(q.m)[i], v4 = reinterpret_cast<float4*>(q.v)[i];
+    float4 x4 = o.vmax ? reinterpret_cast<float4*>(q.vmax)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (d.zero_g) reinterpret_cast<float4*>(const_cast<float*>(q.g))[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    upd(g4.x, w4.x, m4.x, v4.x, x4.x); upd(g4.y, w4.y, m4.y, v4.y, x4.y);
+    upd(g4.z, w4.z, m4.z, v4.z, x4.z); upd(g4.w, w4.w, m4.w, v4.w, x4.w);
+    reinterpret_cast<float4*>(q.p)[i] = w4;
+    reinterpret_cast<float4*>(q.m)[i] = m4;
+    reinterpret_cast<float4*>(q.v)[i] = v4;
+    if (q.vmax) reinterpret_cast<float4*>(q.vmax)[i] = x4;
+    if (q.shadow) {
+      uint2 pk;
+      pk.x = pack2bf(w4.x, w4.y);
+      pk.y = pack2bf(w4.z, w4.w);
+      reinterpret_cast<uint2*>(q.shadow)[i] = pk;
+    }
   }
 }
 
@@ -401,7 +441,7 @@ int evk_optim_step_dyn(float* p, float* g, float* m, float* v, float* vmax, void
   OptDyn d{{p, g, m, v, vmax, (bf16_t*)shadow, n, lr, beta1, beta2, eps, weight_decay, clip, 0.f, 0.f, 0.f, kind, 0, 1.f},
            step_dev, scale_state, inv_world, zero_grad};
   ProfScope ps(EVK_FAM_OPTIM, s);
-  hipLaunchKernelGGL(optim_dyn_kernel, dim3(ew_blocks(n)), dim3(256), 0, s, d);
+  hipLaunchKernelGGL(optim_dyn_kernel, dim3(std::min(ew_blocks(n / 4 + 1), 2048)), dim3(256), 0, s, d);
   return evk_check_launch("optim_step_dyn");
 }
 

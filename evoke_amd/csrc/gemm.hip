@@ -30,6 +30,7 @@ struct GemmP {
   long sAo, sAi, sBo, sBi, sCo, sCi, sRo, sRi, sbias;
   float alpha; int act, c_f32, r_f32, accumulate, vec_ok;
   int ksteps_per_split, tilesN, kslice_xcd;
+  int group_m;        // tile order inside an XCD's run: super-rows of group_m M-tiles, N fastest across, M fastest inside (0/1 = plain M-major)
   int fast_loads;                   // interior tiles take the select-free loader path (EVK_FAST_LOADS=0 disables)
   int lds_store;                    // bf16 output rows leave through LDS in 16-byte pieces (needs N % 8 == 0, ldc % 8 == 0, aligned C)
   const bf16_t* gate; long ldg;     // optional ReLU gate: C = (gate > 0) ? C : 0, applied last (bf16 [M][ldg], batch 1)
@@ -513,7 +514,22 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : ((SB && WM == 2) ? 
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int tm = wg / p.tilesN, tn = wg - tm * p.tilesN;
+  // Tile order.  The blocks resident on one XCD at a time (2-3 per CU x 32 CUs) are consecutive wg: M-major order makes that wave one
+  // M-tile row x many N-tiles, so with N wide every B panel is live in one block only and is fetched again for each M row the XCD
+  // owns (measured: 4640 x 16384 x 2048 fetched 1.33 GB for 86 MB of operands).  Super-rows of group_m M-tiles swept N-first make
+  // the wave group_m x (wave / group_m) tiles: each live A panel serves wave/group_m blocks and each B panel group_m of them.
+  int tm, tn;
+  if (p.group_m > 1 && p.tilesN > 1) {
+    const int tilesM = gridDim.x / p.tilesN;
+    const int gsz = p.group_m * p.tilesN;
+    const int gi = wg / gsz, first = gi * p.group_m;
+    const int rows = min(tilesM - first, p.group_m);
+    const int r = wg - gi * gsz;
+    tn = r / rows;
+    tm = first + (r - tn * rows);
+  } else {
+    tm = wg / p.tilesN; tn = wg - tm * p.tilesN;
+  }
   const int zo = bz / p.bi, zi = bz - zo * p.bi;
   const int k_begin = by * p.ksteps_per_split * BK;
   const int k_end = min(p.K, k_begin + p.ksteps_per_split * BK);
@@ -1001,6 +1017,10 @@ int launch_modes(GemmP& p, int batch, int splitk_req, void* ws, long ws_bytes, c
   splitk = (int)cdiv(ksteps, p.ksteps_per_split);
   static const int kslice = [] { const char* e = getenv("EVK_KSLICE_XCD"); return e ? atoi(e) : 1; }();
   p.kslice_xcd = kslice;
+  // measured (tools/gemm_bench.py --cold, 4640 x 16384 x 2048): 256-wide tiles (32 resident per XCD) 745 -> 785 TFLOP/s with 4-row groups,
+  // the NN data gradient on 128-wide tiles (64-96 resident) 780 -> 850 with 8; EVK_GROUP_M forces a value (0 = plain M-major order)
+  static const int group_m = [] { const char* e = getenv("EVK_GROUP_M"); return e ? atoi(e) : -1; }();
+  p.group_m = group_m >= 0 ? group_m : (big ? 4 : 8);
   dim3 grid(tilesM * p.tilesN, splitk, batch);
   int rc;
   if constexpr (AMODE == EVK_A_PLAIN && BMODE == EVK_B_PLAIN) {
