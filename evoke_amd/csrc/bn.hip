@@ -160,14 +160,15 @@ __device__ __forceinline__ void bn_finalize_channel(const FinP& p, int c, float 
 }
 
 // second reduction stage of the gate statistics a data-gradient GEMM epilogue wrote (gemm.hip: gatestats): 8 channels per block
+// rows = 2: (sum g, sum g*z) -> sum_gx through z = gamma*xhat + beta;  rows = 3 (invstd given): (sum g, -, sum g*(x - mean)) -> sum_gx = invstd * row 2
 __global__ __launch_bounds__(256) void bn_bwd_sums_from_gate_kernel(const float* __restrict__ part, int nblk, const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta, float* __restrict__ sum_g, float* __restrict__ sum_gx,
-                                                                    float* dbeta_acc, float* dgamma_acc, int C) {
+                                                                    float* dbeta_acc, float* dgamma_acc, int C, int rows, const float* __restrict__ invstd) {
   __shared__ float red[16][17];
   const int j = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int c = blockIdx.x * 8 + (j & 7);
-  const int col = (j < 8 ? 0 : C) + c;
-  const long ld = 2L * C;
+  const int col = (j < 8 ? 0 : (rows - 1) * C) + c;
+  const long ld = (long)rows * C;
   float acc[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) acc[u] = 0.f;
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_from_gate_kernel(const float*
 #pragma unroll
     for (int q = 0; q < 16; ++q) { sg += red[q][threadIdx.x]; sgz += red[q][threadIdx.x + 8]; }
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-    const float sgx = g != 0.f ? (sgz - b * sg) / g : 0.f;
+    const float sgx = invstd ? sgz * invstd[c] : (g != 0.f ? (sgz - b * sg) / g : 0.f);
     sum_g[c] = sg; sum_gx[c] = sgx;
     if (dbeta_acc) dbeta_acc[c] += sg;
     if (dgamma_acc) dgamma_acc[c] += sgx;
@@ -558,8 +559,18 @@ int evk_bn_bwd_sums_from_gate_partials(const float* part, int32_t nblk, const fl
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   EVK_REQUIRE(part && sum_g && sum_gx && nblk > 0 && C > 0 && C % 8 == 0, "bn_bwd_sums_from_gate_partials: bad args");
   ProfScope ps(EVK_FAM_REDUCE, s);
-  hipLaunchKernelGGL(bn_bwd_sums_from_gate_kernel, dim3(C / 8), dim3(256), 0, s, part, (int)nblk, gamma, beta, sum_g, sum_gx, dbeta_acc, dgamma_acc, (int)C);
+  hipLaunchKernelGGL(bn_bwd_sums_from_gate_kernel, dim3(C / 8), dim3(256), 0, s, part, (int)nblk, gamma, beta, sum_g, sum_gx, dbeta_acc, dgamma_acc, (int)C, 2, nullptr);
   return evk_check_launch("bn_bwd_sums_from_gate_partials");
+}
+
+int evk_bn_bwd_sums_from_xstat_partials(const float* part, int32_t nblk, const float* invstd, float* sum_g, float* sum_gx, float* dbeta_acc,
+                                        float* dgamma_acc, int32_t C, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(part && invstd && sum_g && sum_gx && nblk > 0 && C > 0 && C % 8 == 0, "bn_bwd_sums_from_xstat_partials: bad args");
+  ProfScope ps(EVK_FAM_REDUCE, s);
+  hipLaunchKernelGGL(bn_bwd_sums_from_gate_kernel, dim3(C / 8), dim3(256), 0, s, part, (int)nblk, nullptr, nullptr, sum_g, sum_gx, dbeta_acc, dgamma_acc, (int)C, 3,
+                     invstd);
+  return evk_check_launch("bn_bwd_sums_from_xstat_partials");
 }
 
 int evk_bn_stats_finalize_from_partials(const float* part, int32_t nblk, float* sum, float* sumsq, const float* gamma, const float* beta,

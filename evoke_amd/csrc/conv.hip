@@ -124,6 +124,23 @@ int evk_conv2d_dgrad_gated(const void* dy, const void* w, const void* resid, con
   return evk_conv2d_dgrad_gated_stats(dy, w, resid, gate, dx, g, nullptr, 0, nullptr, stream);
 }
 
+int64_t evk_conv_xstat_bytes(const evk_conv_geom* g) {
+  if (!g || check_geom(g)) return 0;
+  const int64_t M = (int64_t)g->N * g->Hi * g->Wi;
+  return use_ws(g, M, g->Co, g->Ci) ? evk_conv1x1_ws_part_bytes(M, g->Co, g->Ci) / 2 * 3 : 0;
+}
+
+int evk_conv2d_dgrad_gated_xstat(const void* dy, const void* w, const void* resid, const void* gate, void* dx, const evk_conv_geom* g,
+                                 const void* stat_x, const float* stat_mean, float* part, int64_t part_bytes, int32_t* nblk, evk_stream_t stream) {
+  if (int e = check_geom(g)) return e;
+  EVK_REQUIRE(nblk, "conv dgrad xstat: nblk is required");
+  *nblk = 0;
+  const int64_t need = evk_conv_xstat_bytes(g);
+  if (stat_x && gate && part && need > 0 && part_bytes >= need)
+    return evk_conv1x1_ws_dgrad_xstat(dy, w, resid, gate, dx, (int64_t)g->N * g->Hi * g->Wi, g->Co, g->Ci, stat_x, stat_mean, part, part_bytes, nblk, stream);
+  return evk_conv2d_dgrad_gated(dy, w, resid, gate, dx, g, stream);
+}
+
 int evk_conv2d_dgrad_gated_stats(const void* dy, const void* w, const void* resid, const void* gate, void* dx, const evk_conv_geom* g,
                                  float* part, int64_t part_bytes, int32_t* nblk, evk_stream_t stream) {
   if (int e = check_geom(g)) return e;

@@ -44,7 +44,9 @@ struct WsP {
   bf16_t* y;            // [M][N]
   const bf16_t* skip;   // dgrad: optional [M][N] added before the gate
   const bf16_t* gate;   // dgrad: optional [M][N], output zeroed where gate <= 0
-  float* part;          // optional [ntiles][2][N]: fwd (sum, sumsq) of y; dgrad (sum g, sum g*gate)
+  float* part;          // optional [ntiles][2][N]: fwd (sum, sumsq) of y; dgrad (sum g, sum g*gate); [ntiles][3][N] with sx
+  const bf16_t* sx;     // dgrad: optional [M][N] second statistic operand: third partial row = sum over pixels of dx * (sx - smean)
+  const float* smean;   // [N] per-channel offset of sx (the batch mean of the batch norm whose input sx is), or null
   long M; int N, ntiles, slices, groups;
 };
 
@@ -121,6 +123,12 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv1x1_ws_kernel(const WsP p) {
       *reinterpret_cast<uint4*>(abuf + (buf * MT + r) * LDA + kc * 8) = pf[c];
     }
   };
+  constexpr int CPRW = NW / 8;                         // 16-byte chunks per pixel row of the wave's NW channels
+  const bool xstat = DGRAD && p.sx && p.part;
+  const int prn = xstat ? 3 : 2;                       // partial rows per tile
+  float mu[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) mu[k] = (xstat && p.smean) ? p.smean[n0 + (lane % CPRW) * 8 + k] : 0.f;
   int t = grp;
   if (t < p.ntiles) { fetch(t); stash(0); }
   __syncthreads();
@@ -129,11 +137,13 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv1x1_ws_kernel(const WsP p) {
   for (; t < p.ntiles; t += p.groups) {
     const int tn = t + p.groups;
     if (tn < p.ntiles) fetch(tn);                      // in flight while this tile multiplies
-    float s0[NT][4], s1[NT][4];
+    float s0[NT][4], s1[NT][4], tx[8];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) { s0[nt][j] = 0.f; s1[nt][j] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tx[k] = 0.f;
     const bf16_t* at = abuf + cur * MT * LDA;
 #pragma unroll 1
     for (int mt = 0; mt < MT / 16; ++mt) {
@@ -143,7 +153,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv1x1_ws_kernel(const WsP p) {
       constexpr int CPR = NW / 8;                       // 16-byte chunks per pixel row of the wave's NW channels
       constexpr int NCH = (16 * CPR + 63) / 64;         // chunks per lane for a 16-pixel group
       // data gradient: the skip / gate rows of this pixel group, whole rows, in flight while the group multiplies
-      uint4 skv[NCH], gtv[NCH];
+      uint4 skv[NCH], gtv[NCH], sxv[NCH];
       if (DGRAD) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
@@ -152,6 +162,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv1x1_ws_kernel(const WsP p) {
           const bool ok = c < 16 * CPR && prow < p.M;
           skv[i] = (ok && p.skip) ? *reinterpret_cast<const uint4*>(p.skip + prow * p.N + n0 + cc * 8) : make_uint4(0, 0, 0, 0);
           gtv[i] = (ok && p.gate) ? *reinterpret_cast<const uint4*>(p.gate + prow * p.N + n0 + cc * 8) : make_uint4(0, 0, 0, 0);
+          sxv[i] = (ok && xstat) ? *reinterpret_cast<const uint4*>(p.sx + prow * p.N + n0 + cc * 8) : make_uint4(0, 0, 0, 0);
         }
       }
       const bf16_t* brow = at + (mt * 16 + li) * LDA + g * 8;
@@ -208,14 +219,25 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv1x1_ws_kernel(const WsP p) {
       for (int i = 0; i < NCH; ++i) {
         const int c = lane + 64 * i, pr = c / CPR, cc = c % CPR;
         const long prow = (long)t * MT + mt * 16 + pr;
-        if (c < 16 * CPR && prow < p.M) *reinterpret_cast<uint4*>(p.y + prow * p.N + n0 + cc * 8) = *reinterpret_cast<const uint4*>(ow + pr * OST + cc * 8);
+        if (c < 16 * CPR && prow < p.M) {
+          const uint4 o = *reinterpret_cast<const uint4*>(ow + pr * OST + cc * 8);
+          *reinterpret_cast<uint4*>(p.y + prow * p.N + n0 + cc * 8) = o;
+          if (DGRAD && xstat) {         // the lane holds 8 channels of one pixel of the (rounded) result and of sx
+            const uint32_t ov[4] = {o.x, o.y, o.z, o.w}, xv[4] = {sxv[i].x, sxv[i].y, sxv[i].z, sxv[i].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              tx[2 * k] += lo_bf(ov[k]) * (lo_bf(xv[k]) - mu[2 * k]);
+              tx[2 * k + 1] += hi_bf(ov[k]) * (hi_bf(xv[k]) - mu[2 * k + 1]);
+            }
+          }
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     if (p.part) {
-      float* prow = p.part + (long)t * 2 * p.N;
+      float* prow = p.part + (long)t * prn * p.N;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         float a[4], b[4];
@@ -225,6 +247,18 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv1x1_ws_kernel(const WsP p) {
           const int c = n0 + nt * 16 + g * 4;
           *reinterpret_cast<float4*>(prow + c) = make_float4(a[0], a[1], a[2], a[3]);
           *reinterpret_cast<float4*>(prow + p.N + c) = make_float4(b[0], b[1], b[2], b[3]);
+        }
+      }
+      if (DGRAD && xstat) {             // lanes with equal lane % CPRW hold the same 8 channels (one pixel row each): sum over the rows
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+#pragma unroll
+          for (int off = CPRW; off < 64; off <<= 1) tx[k] += __shfl_xor(tx[k], off, 64);
+        }
+        if (lane < CPRW) {
+          float* d = prow + 2 * p.N + n0 + lane * 8;
+          *reinterpret_cast<float4*>(d) = make_float4(tx[0], tx[1], tx[2], tx[3]);
+          *reinterpret_cast<float4*>(d + 4) = make_float4(tx[4], tx[5], tx[6], tx[7]);
         }
       }
     }
@@ -300,17 +334,26 @@ int evk_conv1x1_ws_fwd(const void* x, const void* w, void* y, int64_t M, int32_t
   EVK_REQUIRE(x && w && y && evk_conv1x1_ws_supported(M, K, N), "conv1x1_ws_fwd: unsupported problem M=%ld K=%d N=%d", (long)M, K, N);
   EVK_REQUIRE(!part || (nblk && part_bytes >= evk_conv1x1_ws_part_bytes(M, K, N)), "conv1x1_ws_fwd: statistics buffer too small");
   if (part) *nblk = (int)cdiv(M, ws_tile_rows(K));
-  WsP p{(const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, nullptr, nullptr, part, M, N, 0, 0, 0};
+  WsP p{(const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, nullptr, nullptr, part, nullptr, nullptr, M, N, 0, 0, 0};
   return dispatch<false>(p, K, reinterpret_cast<hipStream_t>(stream));
 }
 
 /* dx[M][N] = gate(dy[M][K] . W[K][N] + skip): W as the forward stores it, [K = Co][N = Ci] */
 int evk_conv1x1_ws_dgrad(const void* dy, const void* wt, const void* skip, const void* gate, void* dx, int64_t M, int32_t K, int32_t N,
                          float* part, int64_t part_bytes, int32_t* nblk, evk_stream_t stream) {
+  return evk_conv1x1_ws_dgrad_xstat(dy, wt, skip, gate, dx, M, K, N, nullptr, nullptr, part, part_bytes, nblk, stream);
+}
+
+/* same, with a third partial row per pixel tile when stat_x is given: sum over pixels of dx * (stat_x - stat_mean), the second column sum
+   of the batch-norm backward whose INPUT is stat_x and whose output gradient is dx (part then holds [nblk][3][N] floats) */
+int evk_conv1x1_ws_dgrad_xstat(const void* dy, const void* wt, const void* skip, const void* gate, void* dx, int64_t M, int32_t K, int32_t N,
+                               const void* stat_x, const float* stat_mean, float* part, int64_t part_bytes, int32_t* nblk, evk_stream_t stream) {
   EVK_REQUIRE(dy && wt && dx && evk_conv1x1_ws_supported(M, K, N), "conv1x1_ws_dgrad: unsupported problem M=%ld K=%d N=%d", (long)M, K, N);
-  EVK_REQUIRE(!part || (gate && nblk && part_bytes >= evk_conv1x1_ws_part_bytes(M, K, N)), "conv1x1_ws_dgrad: gate statistics need a gate and a large enough buffer");
+  const int64_t need = evk_conv1x1_ws_part_bytes(M, K, N) / 2 * (stat_x ? 3 : 2);
+  EVK_REQUIRE(!part || (gate && nblk && part_bytes >= need), "conv1x1_ws_dgrad: gate statistics need a gate and a large enough buffer");
+  EVK_REQUIRE(!stat_x || part, "conv1x1_ws_dgrad: stat_x needs the partials buffer");
   if (part) *nblk = (int)cdiv(M, ws_tile_rows(K));
-  WsP p{(const bf16_t*)dy, (const bf16_t*)wt, (bf16_t*)dx, (const bf16_t*)skip, (const bf16_t*)gate, part, M, N, 0, 0, 0};
+  WsP p{(const bf16_t*)dy, (const bf16_t*)wt, (bf16_t*)dx, (const bf16_t*)skip, (const bf16_t*)gate, part, (const bf16_t*)stat_x, stat_mean, M, N, 0, 0, 0};
   return dispatch<true>(p, K, reinterpret_cast<hipStream_t>(stream));
 }
 

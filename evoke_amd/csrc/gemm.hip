@@ -663,7 +663,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN > 4 ? 1 : ((SB && WM == 2) ? 
 // ALL loads of a chunk in flight at once (80 KB of LDS per chunk): a K = 512 product pays 2 global-load latencies
 // instead of the 8 of the throughput kernel's 64-deep pipeline.
 // ------------------------------------------------------------------------------------------------
-constexpr int SK_KC = 256, SK_TM = 128;      // SK_KC: the K granularity the launcher requires
+constexpr int SK_KC = 256;                   // the K granularity the launcher requires
 template <int KC>
 __device__ __forceinline__ int sk_off(int row, int chunk) { return row * (KC * 2) + ((chunk ^ (row & 15)) << 4); }
 

@@ -73,6 +73,7 @@ int make_plan(const evk_trunk_cfg* cfg, int N, int H, int W, Plan& P) {
       evk_conv_geom g2 = geom(N, h, w, planes, planes, 3, stride, 1);
       evk_conv_geom g3 = geom(N, ho, wo, planes, planes * 4, 1, 1, 0);
       add_pair(g1, planes, (long)N * h * w);
+      if (evk_conv_xstat_bytes(&g1) > part) part = evk_conv_xstat_bytes(&g1);
       add_pair(g2, planes, (long)N * ho * wo);
       add_pair(g3, planes * 4, (long)N * ho * wo);
       if (down) {
@@ -131,6 +132,19 @@ int bn_backward_from_gate(const Ctx& c, int i, const void* dz, int nblk) {
   float* sums = c.at<float>(pr.sums);
   const int C = pr.C;
   TRY(evk_bn_bwd_sums_from_gate_partials(c.at<float>(c.P->part), nblk, l.gamma, l.beta, sums, sums + C, l.dbeta, l.dgamma, C, c.s));
+  const float* sg = c.training ? sums : c.at<float>(c.P->zeros);
+  const float* sgx = c.training ? sums + C : c.at<float>(c.P->zeros);
+  return evk_bn_bwd_apply(dz, c.at(pr.z), c.at(pr.y), st + 2 * C, st + 4 * C, st + 5 * C, sg, sgx, c.at(pr.dy), nullptr, pr.M, C, 0, c.s);
+}
+
+// bn_backward whose column sums (sum g, sum g*(x - mean)) were left by the data gradient that produced dz (evk_conv2d_dgrad_gated_xstat)
+int bn_backward_from_xstat(const Ctx& c, int i, const void* dz, int nblk) {
+  const Pair& pr = c.P->pairs[i];
+  const evk_trunk_layer& l = c.L[i];
+  float* st = c.at<float>(pr.stats);
+  float* sums = c.at<float>(pr.sums);
+  const int C = pr.C;
+  TRY(evk_bn_bwd_sums_from_xstat_partials(c.at<float>(c.P->part), nblk, st + 5 * C, sums, sums + C, l.dbeta, l.dgamma, C, c.s));
   const float* sg = c.training ? sums : c.at<float>(c.P->zeros);
   const float* sgx = c.training ? sums + C : c.at<float>(c.P->zeros);
   return evk_bn_bwd_apply(dz, c.at(pr.z), c.at(pr.y), st + 2 * C, st + 4 * C, st + 5 * C, sg, sgx, c.at(pr.dy), nullptr, pr.M, C, 0, c.s);
@@ -253,6 +267,8 @@ int evk_trunk_backward(const evk_trunk_cfg* cfg, const evk_trunk_layer* layers, 
   WgradQueue q;
   TRY(q.init(stream, wgrad_stream));
   static const bool gate_stats = [] { const char* e = getenv("EVK_BN_GATE_STATS"); return !e || atoi(e) != 0; }();
+  static const bool x_stats = [] { const char* e = getenv("EVK_BN_XSTATS"); return !e || atoi(e) != 0; }();
+  int nbz = 0;                           // > 0: the kernel that produced gZ left bn3's backward sums of the current block in P.part
 
   auto wgrad = [&](int i, const void* xin) -> int {
     if (!layers[i].dw) return EVK_OK;
@@ -289,7 +305,8 @@ int evk_trunk_backward(const evk_trunk_cfg* cfg, const evk_trunk_layer* layers, 
     const bool gs1 = gate_stats && P.part_bytes >= evk_conv_stats_bytes(P.pairs[i + 1].M, P.pairs[i + 1].C);
     const bool gs0 = gate_stats && P.part_bytes >= evk_conv_stats_bytes(P.pairs[i].M, P.pairs[i].C);
     int nb1 = 0, nb0 = 0;
-    TRY(bn_backward(c, i + 2, gZ, nullptr, 0));
+    if (nbz > 0) TRY(bn_backward_from_xstat(c, i + 2, gZ, nbz));
+    else TRY(bn_backward(c, i + 2, gZ, nullptr, 0));
     TRY(evk_conv2d_dgrad_gated_stats(c.at(P.pairs[i + 2].dy), layers[i + 2].w, nullptr, c.at(P.pairs[i + 1].z), S1, &P.pairs[i + 2].g,
                                      gs1 ? part : nullptr, P.part_bytes, &nb1, stream));
     TRY(wgrad(i + 2, c.at(P.pairs[i + 1].z)));
@@ -307,7 +324,16 @@ int evk_trunk_backward(const evk_trunk_cfg* cfg, const evk_trunk_layer* layers, 
       TRY(wgrad(i + 3, X));
       skip = T;
     }
-    TRY(evk_conv2d_dgrad_gated(c.at(P.pairs[i].dy), layers[i].w, skip, xgate, gX, &P.pairs[i].g, stream));
+    // the gradient w.r.t. the block input IS the previous block's output gradient: its bn3 sums ride on this epilogue (weight-stationary
+    // kernel only; nbz = 0 otherwise and that block reduces gX itself).  Training-mode statistics only: st + 4C holds the batch mean.
+    nbz = 0;
+    if (b > 0 && x_stats && training) {
+      const int ip = first[b - 1] + 2;
+      TRY(evk_conv2d_dgrad_gated_xstat(c.at(P.pairs[i].dy), layers[i].w, skip, xgate, gX, &P.pairs[i].g, c.at(P.pairs[ip].y),
+                                       c.at<float>(P.pairs[ip].stats) + 4 * P.pairs[ip].C, part, P.part_bytes, &nbz, stream));
+    } else {
+      TRY(evk_conv2d_dgrad_gated(c.at(P.pairs[i].dy), layers[i].w, skip, xgate, gX, &P.pairs[i].g, stream));
+    }
     TRY(wgrad(i, X));
     gZ = gX;
   }

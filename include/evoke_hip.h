@@ -145,10 +145,23 @@ int evk_conv1x1_ws_fwd(const void* x, const void* w, void* y, int64_t M, int32_t
                        evk_stream_t stream);
 int evk_conv1x1_ws_dgrad(const void* dy, const void* wt, const void* skip, const void* gate, void* dx, int64_t M, int32_t K, int32_t N,
                          float* part, int64_t part_bytes, int32_t* nblk, evk_stream_t stream);
+/* evk_conv1x1_ws_dgrad with a third partial row per pixel tile: sum over pixels of dx * (stat_x - stat_mean[channel]) -- with stat_x the
+ * INPUT of the batch norm whose output gradient dx is (conv3's raw output for bn3 of the previous bottleneck; torchvision Bottleneck:
+ * out = relu(bn3(conv3(.)) + identity)) this is sum g * (x - mean), the second column sum of nn.BatchNorm2d's backward, so the block-output
+ * gradient is never re-read for it.  part then holds [nblk][3][N] floats (1.5 x evk_conv1x1_ws_part_bytes) */
+int evk_conv1x1_ws_dgrad_xstat(const void* dy, const void* wt, const void* skip, const void* gate, void* dx, int64_t M, int32_t K, int32_t N,
+                               const void* stat_x, const float* stat_mean, float* part, int64_t part_bytes, int32_t* nblk, evk_stream_t stream);
 /* evk_conv2d_dgrad_gated + the gate statistics of evk_gemm.gatestats: part receives *nblk rows of [2][Ci] (evk_conv_stats_bytes(rows of
  * dx, Ci) bytes) */
 int evk_conv2d_dgrad_gated_stats(const void* dy, const void* w, const void* resid, const void* gate, void* dx, const evk_conv_geom* g,
                                  float* part, int64_t part_bytes, int32_t* nblk, evk_stream_t stream);
+/* evk_conv2d_dgrad_gated that also tries to leave the batch-norm backward sums of the layer dx is the output gradient of (stat_x = that
+ * layer's conv output, stat_mean = its batch mean): when the problem is one the weight-stationary kernel takes, *nblk > 0 rows of
+ * [3][Ci] partials (sum g, sum g*gate, sum g*(stat_x - mean)) are written for evk_bn_bwd_sums_from_xstat_partials; otherwise the plain
+ * gated data gradient runs and *nblk = 0 (the caller reduces dx itself: evk_bn_bwd_reduce_acc) */
+int64_t evk_conv_xstat_bytes(const evk_conv_geom* g);
+int evk_conv2d_dgrad_gated_xstat(const void* dy, const void* w, const void* resid, const void* gate, void* dx, const evk_conv_geom* g,
+                                 const void* stat_x, const float* stat_mean, float* part, int64_t part_bytes, int32_t* nblk, evk_stream_t stream);
 int evk_conv2d_dgrad_gated(const void* dy, const void* w, const void* resid, const void* gate, void* dx, const evk_conv_geom* g,
                            evk_stream_t stream);
 int evk_conv2d_wgrad(const void* dy, const void* x, float* dw, const evk_conv_geom* g, void* ws, int64_t ws_bytes, evk_stream_t stream);
@@ -291,6 +304,10 @@ int evk_bn_finalize(const float* sum, const float* sumsq, const float* gamma, co
  * Replaces evk_bn_bwd_reduce_acc for bn1 / bn2 of every bottleneck (nn.BatchNorm2d backward, torchvision resnet101). */
 int evk_bn_bwd_sums_from_gate_partials(const float* part, int32_t nblk, const float* gamma, const float* beta, float* sum_g, float* sum_gx,
                                        float* dbeta_acc, float* dgamma_acc, int32_t C, evk_stream_t stream);
+/* the same second stage for the [3][C] partial rows of evk_conv2d_dgrad_gated_xstat: sum_g = sum of row 0, sum_gx = invstd * sum of row 2
+ * (row 2 already carries x - mean) */
+int evk_bn_bwd_sums_from_xstat_partials(const float* part, int32_t nblk, const float* invstd, float* sum_g, float* sum_gx,
+                                        float* dbeta_acc, float* dgamma_acc, int32_t C, evk_stream_t stream);
 /* evk_bn_stats_from_partials + evk_bn_finalize (training) in one launch: the trunk runner's per-convolution critical path */
 int evk_bn_stats_finalize_from_partials(const float* part, int32_t nblk, float* sum, float* sumsq, const float* gamma, const float* beta,
                                         float* running_mean, float* running_var, float* scale, float* shift, float* mean, float* invstd,

@@ -268,6 +268,20 @@ def test_weight_stationary_pointwise_conv_forward_and_data_gradient(H, M, K, N):
     gz = gref * gate.float()
     assert float((s[0] - gref.sum(0)).abs().max()) <= 1e-5 * float(gref.abs().sum(0).max()) + 1e-4
     assert float((s[1] - gz.sum(0)).abs().max()) <= 1e-5 * float(gz.abs().sum(0).max()) + 1e-4
+    # third partial row: sum over pixels of dx * (stat_x - mean) with the ROUNDED dx (what a later pass over dx would have read)
+    sx = rnd(M, N, seed=15, scale=1.5).cuda()
+    mean = torch.randn(N, device='cuda') * 0.5
+    part3 = torch.zeros(nb // 4 * 3 // 2, device='cuda')
+    dx2 = torch.empty_like(dx)
+    H.check(H.lib.evk_conv1x1_ws_dgrad_xstat(H.ptr(x), H.ptr(wt), H.ptr(skip), H.ptr(gate), H.ptr(dx2), M, K, N, H.ptr(sx), H.ptr(mean),
+                                             H.ptr(part3), part3.numel() * 4, C.byref(nblk), H.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(dx2, dx)
+    s3 = part3[:nblk.value * 3 * N].view(nblk.value, 3, N).sum(0)
+    assert torch.allclose(s3[:2], s, rtol=0, atol=0)
+    want = (dx.float() * (sx.float() - mean)).sum(0)
+    scale = float((dx.float() * (sx.float() - mean)).abs().sum(0).max())
+    assert float((s3[2] - want).abs().max()) <= 1e-5 * scale + 1e-4
 
 
 def test_weight_stationary_kernel_refuses_what_it_cannot_tile(H):
