@@ -38,6 +38,14 @@ __device__ __forceinline__ s16x4 lds_tr_read(const bf16_t* generic_lds_ptr) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16(p);
 }
 
+// rows of the [K][NS] weight slice the data gradient stages through LDS at a time: the largest power of two (>= 32) that fits the tile
+// double buffer, so the staging never sets the LDS footprint
+constexpr int ws_kc(int K, int MT, int LW) {
+  int kc = 32;
+  while (kc * 2 <= K && kc * 2 <= 256 && kc * 2 * LW <= 2 * MT * (K + 8)) kc *= 2;
+  return kc;
+}
+
 struct WsP {
   const bf16_t* x;      // [M][K] activations (fwd: conv input; dgrad: dy)
   const bf16_t* w;      // fwd: W[N = Co][K = Ci] (K-contiguous); dgrad: W[K = Co][N = Ci] as stored (transposed on the way into registers)
@@ -59,7 +67,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv1x1_ws_kernel(const WsP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* abuf = reinterpret_cast<bf16_t*>(smem);                          // [2][MT][LDA]
   constexpr int NS = NWV * NW, LW = NS + 8;
-  constexpr int KCW = K < 256 ? K : 256;
+  constexpr int KCW = ws_kc(K, MT, NWV * NW + 8);
   constexpr int ABUF = (2 * MT * LDA > (DGRAD ? KCW * LW : 0)) ? 2 * MT * LDA : KCW * LW;  // elements: tile double buffer / weight staging
   bf16_t* obuf = abuf + ABUF;                                              // [NWV waves][16][OST] output transpose
   bf16_t* sbuf = obuf;                                                     // dgrad: the skip rows arrive in the buffer the output leaves through
@@ -83,7 +91,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv1x1_ws_kernel(const WsP p) {
   } else {
     // data gradient: the weights lie [K = Co][N = Ci] (n contiguous).  The workgroup's [K][NS] slice goes through LDS as it lies and
     // the A fragments (8 consecutive k of one channel) come back through the transposing LDS read (two 4 x 16 blocks per fragment)
-    constexpr int KC = K < 256 ? K : 256;               // rows of the weight slice staged at a time
+    constexpr int KC = KCW;                              // rows of the weight slice staged at a time
     const int q4 = li >> 2, p4 = li & 3;
 #pragma unroll
     for (int kc = 0; kc < K; kc += KC) {
@@ -270,7 +278,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv1x1_ws_kernel(const WsP p) {
 
 template <int K, int NW, int MT, bool DGRAD, int NWV>
 int launch_ws(WsP p, hipStream_t s) {
-  const size_t abuf = std::max((size_t)2 * MT * (K + 8), DGRAD ? (size_t)(K < 256 ? K : 256) * (NWV * NW + 8) : (size_t)0);
+  const size_t abuf = std::max((size_t)2 * MT * (K + 8), DGRAD ? (size_t)ws_kc(K, MT, NWV * NW + 8) * (NWV * NW + 8) : (size_t)0);
   const size_t lds = abuf * 2 + (size_t)(DGRAD ? 2 : 1) * NWV * 16 * (NW + 8) * 2;
   static bool configured = false;
   if (!configured && lds > 65536) {
