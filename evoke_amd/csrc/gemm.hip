@@ -432,8 +432,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[4][4]
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (!(gv[j] > 0.f)) v[j] = 0.f;
         if (p.gatestats) {
+          // Plain v_add_f32 / v_fmac_f32 on purpose.  Left to the vectoriser these eight accumulations become v_pk_add_f32 with
+          // op_sel:[0,1] op_sel_hi:[1,0] (the low result reads the HIGH half of the other operand), and on gfx950 that form returned a
+          // stale high half for lanes 48-63 about once in 10^6 results: one partial entry off by ~1 in every few launches, same inputs
+          // (tools/gatestats_determinism.py; found by tests/test_model_gpu.py::test_full_size_step_properties).  tests/test_abi.py
+          // checks the built code objects for that instruction form.
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { gs[in][j] += v[j]; gz[in][j] += v[j] * gv[j]; }
+          for (int j = 0; j < 4; ++j) {
+            asm volatile("v_add_f32 %0, %0, %1" : "+v"(gs[in][j]) : "v"(v[j]));
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(gz[in][j]) : "v"(v[j]), "v"(gv[j]));
+          }
         }
       }
       if (p.c_f32) {

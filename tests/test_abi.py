@@ -35,3 +35,20 @@ def test_argument_validation_without_gpu():
     d = H.Gemm()
     assert H.lib.evk_gemm_launch(ctypes.byref(d), None) == -1
     assert b'null operand' in H.lib.evk_last_error()
+
+
+def test_built_kernels_avoid_the_cross_half_packed_f32_form():
+    """A property of the BUILT code objects, checked on the CPU box by disassembly (tools/check_packed_opsel.py): no
+    v_pk_{add,mul,fma}_f32 whose low result reads the high half of a VGPR operand (op_sel bit set).  The compiler's vectoriser produced
+    that form for the gate-statistic accumulators of csrc/gemm.hip and on MI355X it returned a stale value for lanes 48-63 about once
+    per 10^6 results (same launch, same inputs, a different partial sum every few launches) -- the kernels now spell those
+    accumulations as scalar instructions; this keeps a compiler or source change from bringing the form back unnoticed."""
+    import importlib.util
+    from evoke_amd import build
+    spec = importlib.util.spec_from_file_location('check_packed_opsel', os.path.join(REPO, 'tools', 'check_packed_opsel.py'))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    for lib in (build.build(), build.LIB_BF16):
+        assert len(chk.code_objects(lib)) >= 8, lib
+        bad = chk.suspicious(lib)
+        assert not bad, (lib, bad[:5])
