@@ -433,7 +433,7 @@ def test_full_size_step_properties():
             p.grad = None
         torch.manual_seed(5)
         loss = run(slice(0, B), True)
-        ops.scale_loss(loss).backward()
+        loss.backward()                 # the model's forward already attached the loss scale to the graph (ops.scale_loss)
         ops.join_side_streams()
         torch.cuda.synchronize()
         outs.append((loss.item(), [None if p.grad is None else p.grad.detach().clone() for p in params]))
@@ -468,6 +468,55 @@ def test_full_size_step_properties():
     print('[full size] train loss %.6f / %.6f; %d gradients bit-identical, %d within 1e-5 (atomic column sums); with gradient: %s' % (l0, l1, exact, loose, got))
     assert exact >= 300
     assert all(v > 0 for v in got.values()), got
+
+
+
+def test_full_size_beam_decode_properties():
+    """BASELINE config 5 at its full size (384^2, 64 studies x 2 views, beam 4, max_seq_len 100) through FineTune.forward(mode='inference'):
+      * integer output, so two runs of the same batch must give IDENTICAL token ids (graph replays, device-side beam bookkeeping)
+      * beam search is per study (modules/caption_model.py:26-202 keeps every study's beams apart): decoding the first 32 studies alone
+        must reproduce their rows of the 64-study result; the GEMMs see a different row count, so a near-tie may flip -- at least 99 % of
+        the token positions must agree and at least 90 % of the studies must match exactly
+      * every sequence stays inside the vocabulary and is zero after its first 0 (the reference's end-of-sequence convention)."""
+    from evoke_amd import ops
+    from evoke_amd.model_pretrain_finetune import FineTune
+    from oracle import spec as S
+    args = dict(ARGS)
+    args['beam_size'], args['max_seq_len'] = 4, 100
+    model = FineTune(args, load_tokenizer(), 'mimic_cxr')
+    load_procedural(model, S.finetune_spec(V))
+    model.eval()
+    g = torch.Generator().manual_seed(44)
+    B, Li = 64, 30
+    images = torch.randn(2 * B, 3, 384, 384, generator=g).cuda()
+    ids = torch.zeros(B, 100, dtype=torch.long).cuda()
+    masks = torch.ones(B, 100, dtype=torch.long).cuda()
+    inc = torch.randint(5, V - 2, (B, Li), generator=g)
+    inc[:, 0] = 1
+    incm = torch.ones(B, Li, dtype=torch.long)
+
+    def run(n):
+        img = torch.cat([images[:n], images[B:B + n]])
+        pids = np.array(['p%d_s%d' % (i % n, i % n) for i in range(2 * n)])
+        with torch.no_grad():
+            out = model(img, ids[:n], masks[:n], pids, inc[:n], incm[:n], mode='inference')
+        seq = out[1] if isinstance(out, (tuple, list)) else out
+        return seq.detach().cpu()
+
+    a, b = run(B), run(B)
+    assert a.shape[0] == B and a.dtype == torch.long
+    assert torch.equal(a, b), 'beam search produced different token ids on the same batch'
+    assert int(a.min()) >= 0 and int(a.max()) < V + 1
+    for row in a:
+        z = (row == 0).nonzero()
+        if len(z):
+            assert int(row[int(z[0]):].abs().sum()) == 0
+    h = run(B // 2)
+    agree = float((h == a[:B // 2]).float().mean())
+    exact = float((h == a[:B // 2]).all(dim=1).float().mean())
+    print('\n[full size] decode: repeatable; half batch vs full batch: %.4f of the tokens, %.3f of the studies identical; mean length %.1f'
+          % (agree, exact, float((a != 0).sum(1).float().mean())))
+    assert agree >= 0.99 and exact >= 0.90, (agree, exact)
 
 
 EDGE = {

@@ -92,7 +92,7 @@ for r in range(runs):
     for _, p in params:
         p.grad = None
     loss = model(images, ids, masks, pids, inc, incm, mode='train')['all_loss']
-    ops.scale_loss(loss).backward()
+    loss.backward()                 # the model's forward already attached the loss scale to the graph (ops.scale_loss)
     ops.join_side_streams()
     torch.cuda.synchronize()
     losses.append(loss.item())
