@@ -352,11 +352,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[4][4]
   // g w.r.t. z = relu(gamma * xhat + beta) of that layer, gated by z > 0, and where the gate is open xhat = (z - beta) / gamma --
   // so sum(g) and sum(g * z) per column are all its backward needs (bn.hip: bn_bwd_sums_from_gate_kernel), at no extra traffic:
   // the gate tile is loaded anyway.
-  float gs[4][4], gz[4][4];
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 gs[4][2], gz[4][2];
 #pragma unroll
   for (int in = 0; in < 4; ++in)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { gs[in][j] = 0.f; gz[in][j] = 0.f; }
+    for (int h = 0; h < 2; ++h) { gs[in][h] = f32x2{0.f, 0.f}; gz[in][h] = f32x2{0.f, 0.f}; }
   char* Cb = reinterpret_cast<char*>(p.C) + (zo * p.sCo + zi * p.sCi) * (p.c_f32 ? 4 : 2);
   const char* Rb = p.resid ? reinterpret_cast<const char*>(p.resid) + (zo * p.sRo + zi * p.sRi) * (p.r_f32 ? 4 : 2) : nullptr;
 #pragma unroll
@@ -432,15 +433,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[4][4]
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (!(gv[j] > 0.f)) v[j] = 0.f;
         if (p.gatestats) {
-          // Plain v_add_f32 / v_fmac_f32 on purpose.  Left to the vectoriser these eight accumulations become v_pk_add_f32 with
-          // op_sel:[0,1] op_sel_hi:[1,0] (the low result reads the HIGH half of the other operand), and on gfx950 that form returned a
-          // stale high half for lanes 48-63 about once in 10^6 results: one partial entry off by ~1 in every few launches, same inputs
-          // (tools/gatestats_determinism.py; found by tests/test_model_gpu.py::test_full_size_step_properties).  tests/test_abi.py
-          // checks the built code objects for that instruction form.
+          // Explicit two-wide vectors in natural order (low = even column).  Left to the SLP vectoriser these scalar accumulations were
+          // paired in SWAPPED order -- v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0], the low result reading the HIGH half of the other
+          // operand -- and on gfx950 that form returned a stale high half for lanes 48-63 about once in 10^6 results: one partial entry
+          // off by ~1 every few launches, same inputs (tools/gatestats_determinism.py; found by tests/test_model_gpu.py::
+          // test_full_size_step_properties).  tests/test_abi.py checks the built code objects for that instruction form.
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            asm volatile("v_add_f32 %0, %0, %1" : "+v"(gs[in][j]) : "v"(v[j]));
-            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(gz[in][j]) : "v"(v[j]), "v"(gv[j]));
+          for (int h = 0; h < 2; ++h) {
+            const f32x2 vv = {v[2 * h], v[2 * h + 1]}, gg = {gv[2 * h], gv[2 * h + 1]};
+            gs[in][h] += vv;
+            gz[in][h] += vv * gg;
           }
         }
       }
@@ -471,7 +473,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[4][4]
     for (int in = 0; in < 4; ++in) {
       float a[4], b[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { a[j] = row16_sum(gs[in][j]); b[j] = row16_sum(gz[in][j]); }
+      for (int j = 0; j < 4; ++j) { a[j] = row16_sum(gs[in][j >> 1][j & 1]); b[j] = row16_sum(gz[in][j >> 1][j & 1]); }
       const int n0 = tn * TN + wn * 64 + in * 16 + fq * 4;
       if (frow == 0 && n0 < p.N) {
 #pragma unroll
