@@ -436,7 +436,9 @@ inline int row_blocks(long rows) { return (int)cdiv(rows, WPB); }
 // ------------------------------------------------------------------------------------------------
 struct DecAttP { const bf16_t* q; const bf16_t* k; const bf16_t* v; const unsigned char* mask; bf16_t* out; int R, S, H, kv_div; float scale;
                  const int* rowmap;      // optional [R][S]: cache row that holds position s of hypothesis r (beam-search cache indirection)
-                 const long long* last_pos; };   // optional device scalar: only positions <= *last_pos exist (neither read nor attended)
+                 const long long* last_pos;      // optional device scalar: only positions <= *last_pos exist (neither read nor attended)
+                 const bf16_t* knew; const bf16_t* vnew; long ldq; };   // optional: this step's K / V rows [R][ldq] (fused qkv output); the kernel
+                                                 // attends to them as position *last_pos and appends them to row r of the caches
 
 __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttP p) {
   // lane = (g, c): g = lane >> 3 picks one of 8 key rows per pass, c = lane & 7 one 16-byte chunk of the 128-byte head row, so
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttP p) {
   const long HD = (long)p.H * 64;
   float qr[8];
   {
-    const uint4 u = *reinterpret_cast<const uint4*>(p.q + (long)r * HD + h * 64 + c * 8);
+    const uint4 u = *reinterpret_cast<const uint4*>(p.q + (long)r * (p.ldq ? p.ldq : HD) + h * 64 + c * 8);
     qr[0] = lo_bf(u.x); qr[1] = hi_bf(u.x); qr[2] = lo_bf(u.y); qr[3] = hi_bf(u.y);
     qr[4] = lo_bf(u.z); qr[5] = hi_bf(u.z); qr[6] = lo_bf(u.w); qr[7] = hi_bf(u.w);
   }
@@ -461,6 +463,16 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttP p) {
   const unsigned char* mk = p.mask ? p.mask + rk * p.S : nullptr;
   const int Seff = p.last_pos ? min(p.S, (int)*p.last_pos + 1) : p.S;
   const int passes = (Seff + 7) >> 3;
+  // fused append: the new key / value of this hypothesis are read from the projection's output for position Seff - 1 and copied into
+  // the caches for the later steps (nothing in this launch reads the copies)
+  const int snew = p.knew ? Seff - 1 : -1;
+  const bf16_t* kn = p.knew ? p.knew + (long)r * p.ldq + h * 64 + c * 8 : nullptr;
+  const bf16_t* vn = p.vnew ? p.vnew + (long)r * p.ldq + h * 64 + c * 8 : nullptr;
+  if (p.knew && g == 0) {
+    const long dst = ((long)r * p.S + snew) * HD + h * 64 + c * 8;
+    *reinterpret_cast<uint4*>(const_cast<bf16_t*>(p.k) + dst) = *reinterpret_cast<const uint4*>(kn);
+    *reinterpret_cast<uint4*>(const_cast<bf16_t*>(p.v) + dst) = *reinterpret_cast<const uint4*>(vn);
+  }
   // cache row of every position: r / kv_div, or -- beam search without moving the caches -- the row of the ancestor that
   // wrote position s (rowmap); staged in LDS so that no K / V load waits on an index load
   for (int s = lane; s < Seff; s += 64) sr[wv][s] = p.rowmap ? p.rowmap[(long)r * p.S + s] : (int)rk;
@@ -471,7 +483,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttP p) {
     const int s = it * 8 + g;
     float a = 0.f;
     if (s < Seff) {
-      const uint4 u = *reinterpret_cast<const uint4*>(kb + ((long)sr[wv][s] * p.S + s) * HD);
+      const uint4 u = *reinterpret_cast<const uint4*>(s == snew ? kn : kb + ((long)sr[wv][s] * p.S + s) * HD);
       a = lo_bf(u.x) * qr[0] + hi_bf(u.x) * qr[1] + lo_bf(u.y) * qr[2] + hi_bf(u.y) * qr[3] + lo_bf(u.z) * qr[4] + hi_bf(u.z) * qr[5] +
           lo_bf(u.w) * qr[6] + hi_bf(u.w) * qr[7];
     }
@@ -502,7 +514,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttP p) {
   for (int it = 0; it < passes; ++it) {
     const int s = it * 8 + g;
     if (s < Seff) {
-      const uint4 u = *reinterpret_cast<const uint4*>(vb + ((long)sr[wv][s] * p.S + s) * HD);
+      const uint4 u = *reinterpret_cast<const uint4*>(s == snew ? vn : vb + ((long)sr[wv][s] * p.S + s) * HD);
       const float ps = sl[wv][s];
       o[0] += ps * lo_bf(u.x); o[1] += ps * hi_bf(u.x); o[2] += ps * lo_bf(u.y); o[3] += ps * hi_bf(u.y);
       o[4] += ps * lo_bf(u.z); o[5] += ps * hi_bf(u.z); o[6] += ps * lo_bf(u.w); o[7] += ps * hi_bf(u.w);
@@ -638,7 +650,7 @@ int evk_decode_attention(const void* q, const void* k, const void* v, const unsi
   EVK_REQUIRE(q && k && v && out && R > 0 && S > 0 && heads > 0, "decode_attention: null/empty");
   EVK_REQUIRE(head_dim == 64 && S <= 256, "decode_attention: head_dim must be 64 and S <= 256 (got %d, %d)", head_dim, S);
   EVK_REQUIRE(kv_div >= 1 && R % kv_div == 0, "decode_attention: R=%d must be a multiple of kv_div=%d", R, kv_div);
-  DecAttP p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, mask, (bf16_t*)out, R, S, heads, kv_div, scale, nullptr, nullptr};
+  DecAttP p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, mask, (bf16_t*)out, R, S, heads, kv_div, scale, nullptr, nullptr, nullptr, nullptr, 0};
   ProfScope ps(EVK_FAM_NORM, s);
   hipLaunchKernelGGL(decode_attn_kernel, dim3((int)cdiv((long)R * heads, 4)), dim3(256), 0, s, p);
   return evk_check_launch("decode_attention");
@@ -651,10 +663,25 @@ int evk_decode_attention_indirect(const void* q, const void* k, const void* v, c
   EVK_REQUIRE(q && k && v && out && rowmap && R > 0 && S > 0 && heads > 0, "decode_attention_indirect: null/empty");
   EVK_REQUIRE(head_dim == 64 && S <= 256, "decode_attention_indirect: head_dim must be 64 and S <= 256 (got %d, %d)", head_dim, S);
   DecAttP p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, mask, (bf16_t*)out, R, S, heads, 1, scale, rowmap,
-            reinterpret_cast<const long long*>(last_pos)};
+            reinterpret_cast<const long long*>(last_pos), nullptr, nullptr, 0};
   ProfScope ps(EVK_FAM_NORM, s);
   hipLaunchKernelGGL(decode_attn_kernel, dim3((int)cdiv((long)R * heads, 4)), dim3(256), 0, s, p);
   return evk_check_launch("decode_attention_indirect");
+}
+
+int evk_decode_attention_qkv(const void* qkv, int64_t ldq, void* k_cache, void* v_cache, const int32_t* rowmap, const int64_t* last_pos, void* out,
+                             int32_t R, int32_t S, int32_t heads, int32_t head_dim, float scale, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(qkv && k_cache && v_cache && out && rowmap && last_pos && R > 0 && S > 0 && heads > 0, "decode_attention_qkv: null/empty");
+  EVK_REQUIRE(head_dim == 64 && S <= 256, "decode_attention_qkv: head_dim must be 64 and S <= 256 (got %d, %d)", head_dim, S);
+  const int64_t HD = (int64_t)heads * 64;
+  EVK_REQUIRE(ldq >= 3 * HD && ldq % 8 == 0 && (reinterpret_cast<uintptr_t>(qkv) & 15) == 0, "decode_attention_qkv: qkv rows must hold q | k | v and be 16-byte aligned");
+  const bf16_t* base = (const bf16_t*)qkv;
+  DecAttP p{base, (const bf16_t*)k_cache, (const bf16_t*)v_cache, nullptr, (bf16_t*)out, R, S, heads, 1, scale, rowmap,
+            reinterpret_cast<const long long*>(last_pos), base + HD, base + 2 * HD, (long)ldq};
+  ProfScope ps(EVK_FAM_NORM, s);
+  hipLaunchKernelGGL(decode_attn_kernel, dim3((int)cdiv((long)R * heads, 4)), dim3(256), 0, s, p);
+  return evk_check_launch("decode_attention_qkv");
 }
 
 }  // extern "C"

@@ -20,6 +20,7 @@ from .ops import BF16, F32
 
 _INDIRECT = [os.environ.get('EVK_DECODE_INDIRECT', '1') != '0']      # beam search re-orders a row table, not the K/V caches
 _GRAPH_ENABLED = [True]          # capture the per-token launch sequence in a HIP graph (set False to debug eagerly)
+_FUSED_APPEND = [os.environ.get('EVK_DECODE_FUSED_APPEND', '1') != '0']  # K / V cache append + strided q inside the self-attention kernel
 _FUSED_BOOK = [os.environ.get('EVK_DECODE_FUSED_BOOK', '1') != '0']      # beam bookkeeping as one kernel per token (csrc/beam.hip)
 stats = {}                       # facts about the last beam_search call (bench.py reads the per-token step time from here)
 
@@ -181,13 +182,20 @@ class _DecoderState:
             n = fw.norm(3 * i, x, deltas)
             sa = layer.self_attn
             qkv = fw.qkv(i, n.view(-1, d))
-            q = qkv[:, :d].contiguous().view(-1, 1, d)
-            self.ks[i].index_copy_(1, pos, qkv[:, d:2 * d].unsqueeze(1))
-            self.vs[i].index_copy_(1, pos, qkv[:, 2 * d:].unsqueeze(1))
-            if self.anc is not None:         # positions <= pos only: the kernel reads the step index from the device
-                c = _attend1(q, self.ks[i], self.vs[i], h, None, rowmap=self.anc, last_pos=pos)
+            if self.anc is not None and _FUSED_APPEND[0] and qkv.stride(0) % 8 == 0:
+                # q read in place, this step's K / V attended to straight from qkv and appended to the caches by the same kernel
+                c = torch.empty(qkv.shape[0], 1, d, dtype=qkv.dtype, device=qkv.device)
+                H.check(H.lib.evk_decode_attention_qkv(H.ptr(qkv), qkv.stride(0), H.ptr(self.ks[i]), H.ptr(self.vs[i]), H.ptr(self.anc), H.ptr(pos),
+                                                       H.ptr(c), qkv.shape[0], self.ks[i].shape[1], h, d // h, C.c_float(1.0 / math.sqrt(d // h)),
+                                                       H.stream()), 'decode_attention_qkv')
             else:
-                c = _attend1(q, self.ks[i], self.vs[i], h, kmask)
+                q = qkv[:, :d].contiguous().view(-1, 1, d)
+                self.ks[i].index_copy_(1, pos, qkv[:, d:2 * d].unsqueeze(1))
+                self.vs[i].index_copy_(1, pos, qkv[:, 2 * d:].unsqueeze(1))
+                if self.anc is not None:         # positions <= pos only: the kernel reads the step index from the device
+                    c = _attend1(q, self.ks[i], self.vs[i], h, None, rowmap=self.anc, last_pos=pos)
+                else:
+                    c = _attend1(q, self.ks[i], self.vs[i], h, kmask)
             x = sa.linears[3](c, resid=x)
             n = fw.norm(3 * i + 1, x, deltas)
             ca = layer.src_attn

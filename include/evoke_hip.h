@@ -263,6 +263,12 @@ int evk_decode_attention(const void* q, const void* k, const void* v, const unsi
 int evk_decode_attention_indirect(const void* q, const void* k, const void* v, const unsigned char* mask, const int32_t* rowmap,
                                   const int64_t* last_pos, void* out, int32_t R, int32_t S, int32_t heads, int32_t head_dim, float scale,
                                   evk_stream_t stream);
+/* evk_decode_attention_indirect fed by the fused q | k | v projection of the step (qkv bf16 [R][ldq], ldq >= 3 * heads * 64): q is read in
+ * place, this step's key / value are attended to as position *last_pos straight from qkv and appended to row r of the caches for the
+ * later steps -- the `self.ks[:, t] = k; self.vs[:, t] = v` state update of the incremental MultiHeadedAttention
+ * (encoder_decoder.py:182-214 driven by caption_model.py:beam_search) without a copy kernel.  rowmap[r][*last_pos] must be r. */
+int evk_decode_attention_qkv(const void* qkv, int64_t ldq, void* k_cache, void* v_cache, const int32_t* rowmap, const int64_t* last_pos, void* out,
+                             int32_t R, int32_t S, int32_t heads, int32_t head_dim, float scale, evk_stream_t stream);
 int evk_log_softmax_nll_fwd(const float* logits, float* logp, float* lse, const int64_t* target, const float* wmask, float* acc2,
                             int64_t rows, int32_t V, int32_t ld, int32_t ld_out, evk_stream_t stream);
 int evk_nll_bwd(const float* logits, const float* lse, const int64_t* target, const float* wmask, const float* gscale,
