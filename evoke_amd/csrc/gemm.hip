@@ -40,6 +40,8 @@ struct GemmP {
   int b_klog, b_kmask; long b_tapstride;
   // gather geometry
   int Hi, Wi, Ho, Wo, KH, KW, sh, sw, ph, pw, lgs;
+  // optional LayerNorm of the A rows on their way into LDS (gemm_skinny_kernel<512,..>, K == 512): ln_g != null enables
+  const float* ln_g; const float* ln_b; const bf16_t* ln_dg; const bf16_t* ln_db; long ln_ld; float ln_eps; int ln_mode;
   int lgC, Cg;       // channels of the gathered tensor (power of two)
   int rows_per_img, row_w;  // decomposition of the GEMM row (A_CONV: Ho*Wo, Wo; A_DGRAD: Hi*Wi, Wi)
   long sN, sH, sW;
@@ -717,6 +719,48 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmP p) {
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   load(0);
+  if constexpr (KC == 512) {
+    // LayerNorm prologue (K == 512 == the normalised width): thread (wave, lane) holds chunk `lane` of rows wave + 4 i -- the element
+    // mapping of norm.hip's ln_fwd_kernel, whose arithmetic is repeated here term for term (sum of the lane's 8 values, wave_sum,
+    // squared deviations, wave_sum, (v - mu) * r * g + b) so that the 16-bit rows entering LDS are the ones that kernel would have
+    // written to memory; the norm launch in front of the GEMM and its round trip disappear (decode step: 10 per generated token).
+    if (p.ln_g) {
+      float g8[8], b8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { g8[j] = p.ln_g[lane * 8 + j]; b8[j] = p.ln_b[lane * 8 + j]; }
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int m = m0 + wave + 4 * i;
+        if (m >= p.M) continue;                        // wave-uniform
+        const uint32_t w4[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+        float v[8], g[8], b[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[2 * j] = lo_bf(w4[j]); v[2 * j + 1] = hi_bf(w4[j]); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { g[j] = g8[j]; b[j] = b8[j]; }
+        if (p.ln_dg) {
+          const uint4 dg = *reinterpret_cast<const uint4*>(p.ln_dg + (long)m * p.ln_ld + lane * 8);
+          const uint4 db = *reinterpret_cast<const uint4*>(p.ln_db + (long)m * p.ln_ld + lane * 8);
+          const uint32_t dgw[4] = {dg.x, dg.y, dg.z, dg.w}, dbw[4] = {db.x, db.y, db.z, db.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { g[2 * j] += lo_bf(dgw[j]); g[2 * j + 1] += hi_bf(dgw[j]); b[2 * j] += lo_bf(dbw[j]); b[2 * j + 1] += hi_bf(dbw[j]); }
+        }
+        float sm = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sm += v[j];
+        const float mu = wave_sum(sm) / 512;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = v[j] - mu; q += d * d; }
+        q = wave_sum(q);
+        const float r = p.ln_mode == 0 ? rsqrtf(q / 512 + p.ln_eps) : 1.f / (sqrtf(q / (512 - 1)) + p.ln_eps);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (v[j] - mu) * r * g[j] + b[j];
+        ra[i] = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
+      }
+    }
+  }
   for (int k0 = 0; k0 < p.K; k0 += KC) {
     store();
     __syncthreads();
@@ -1050,6 +1094,26 @@ int launch_modes(GemmP& p, int batch, int splitk_req, void* ws, long ws_bytes, c
 inline bool al(const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 }  // namespace
+
+// y[M][N] = act(LayerNorm(x)[M][512] . W[N][512]^T + bias) (+ resid): the norm happens in the GEMM's operand load (decode step)
+extern "C" int evk_linear_ln(const void* x, const float* gamma, const float* beta, const void* dgam, const void* dbet, int64_t ld_delta,
+                             float eps, int32_t mode, const void* w, const float* bias, const void* resid, int64_t ldr, void* y, int32_t y_dtype,
+                             int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t act, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(x && gamma && beta && w && y && M > 0 && N > 0, "linear_ln: null operand");
+  EVK_REQUIRE(K == 512 && M <= 4096, "linear_ln: built for K = 512 (the decoder width) and M <= 4096 (got K=%d M=%d)", K, M);
+  EVK_REQUIRE((dgam == nullptr) == (dbet == nullptr) && (!dgam || ld_delta % 8 == 0) && (mode == 0 || mode == 1), "linear_ln: bad deltas / mode");
+  EVK_REQUIRE(ldc >= N && (!resid || ldr >= N) && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0 &&
+              (!dgam || ((reinterpret_cast<uintptr_t>(dgam) | reinterpret_cast<uintptr_t>(dbet)) & 15) == 0), "linear_ln: alignment / leading dimensions");
+  GemmP p{};
+  p.A = (const bf16_t*)x; p.B = (const bf16_t*)w; p.C = y; p.bias = bias; p.resid = resid;
+  p.M = M; p.N = N; p.K = K; p.lda = K; p.ldb = K; p.ldc = ldc; p.ldr = ldr; p.bi = 1;
+  p.alpha = 1.f; p.act = act; p.c_f32 = y_dtype == EVK_F32; p.r_f32 = 0;
+  p.ln_g = gamma; p.ln_b = beta; p.ln_dg = (const bf16_t*)dgam; p.ln_db = (const bf16_t*)dbet; p.ln_ld = ld_delta; p.ln_eps = eps; p.ln_mode = mode;
+  evk_prof_tag(M, N, K, 1, 0, 0);
+  ProfScope ps(EVK_FAM_GEMM, s, 2.0 * M * (double)N * K);
+  return launch_skinny_cfg<512, 16, 64>(p, s);
+}
 
 extern "C" int64_t evk_gemm_workspace_bytes(const evk_gemm* d) {
   if (!d || !d->accumulate || d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->N % 4)) return 0;

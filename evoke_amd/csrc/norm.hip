@@ -479,18 +479,28 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttP p) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  for (int it = 0; it < passes; ++it) {
-    const int s = it * 8 + g;
-    float a = 0.f;
-    if (s < Seff) {
-      const uint4 u = *reinterpret_cast<const uint4*>(s == snew ? kn : kb + ((long)sr[wv][s] * p.S + s) * HD);
-      a = lo_bf(u.x) * qr[0] + hi_bf(u.x) * qr[1] + lo_bf(u.y) * qr[2] + hi_bf(u.y) * qr[3] + lo_bf(u.z) * qr[4] + hi_bf(u.z) * qr[5] +
-          lo_bf(u.w) * qr[6] + hi_bf(u.w) * qr[7];
+  // the key rows of UNR passes are requested before the first is used: one memory round trip per UNR x 8 keys, not per 8
+  // (the step is latency bound: 18 dependent round trips for the 144 cross-attention keys were most of this kernel's 17-21 us)
+  constexpr int UNR = 6;
+  for (int it0 = 0; it0 < passes; it0 += UNR) {
+    uint4 ku[UNR];
+#pragma unroll
+    for (int j = 0; j < UNR; ++j) {
+      const int s = (it0 + j) * 8 + g;
+      ku[j] = s < Seff ? *reinterpret_cast<const uint4*>(s == snew ? kn : kb + ((long)sr[wv][s] * p.S + s) * HD) : make_uint4(0, 0, 0, 0);
     }
-    a += __shfl_xor(a, 1, 64);
-    a += __shfl_xor(a, 2, 64);
-    a += __shfl_xor(a, 4, 64);
-    if (c == 0 && s < Seff) sl[wv][s] = (mk && !mk[s]) ? -INFINITY : a * p.scale;
+#pragma unroll
+    for (int j = 0; j < UNR; ++j) {
+      const int s = (it0 + j) * 8 + g;
+      const uint4 u = ku[j];
+      float a = lo_bf(u.x) * qr[0] + hi_bf(u.x) * qr[1] + lo_bf(u.y) * qr[2] + hi_bf(u.y) * qr[3] + lo_bf(u.z) * qr[4] + hi_bf(u.z) * qr[5] +
+                lo_bf(u.w) * qr[6] + hi_bf(u.w) * qr[7];
+      if (!(s < Seff)) a = 0.f;
+      a += __shfl_xor(a, 1, 64);
+      a += __shfl_xor(a, 2, 64);
+      a += __shfl_xor(a, 4, 64);
+      if (c == 0 && s < Seff) sl[wv][s] = (mk && !mk[s]) ? -INFINITY : a * p.scale;
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -511,13 +521,22 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttP p) {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int it = 0; it < passes; ++it) {
-    const int s = it * 8 + g;
-    if (s < Seff) {
-      const uint4 u = *reinterpret_cast<const uint4*>(s == snew ? vn : vb + ((long)sr[wv][s] * p.S + s) * HD);
-      const float ps = sl[wv][s];
-      o[0] += ps * lo_bf(u.x); o[1] += ps * hi_bf(u.x); o[2] += ps * lo_bf(u.y); o[3] += ps * hi_bf(u.y);
-      o[4] += ps * lo_bf(u.z); o[5] += ps * hi_bf(u.z); o[6] += ps * lo_bf(u.w); o[7] += ps * hi_bf(u.w);
+  for (int it0 = 0; it0 < passes; it0 += UNR) {
+    uint4 vu[UNR];
+#pragma unroll
+    for (int j = 0; j < UNR; ++j) {
+      const int s = (it0 + j) * 8 + g;
+      vu[j] = s < Seff ? *reinterpret_cast<const uint4*>(s == snew ? vn : vb + ((long)sr[wv][s] * p.S + s) * HD) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < UNR; ++j) {
+      const int s = (it0 + j) * 8 + g;
+      if (s < Seff) {
+        const uint4 u = vu[j];
+        const float ps = sl[wv][s];
+        o[0] += ps * lo_bf(u.x); o[1] += ps * hi_bf(u.x); o[2] += ps * lo_bf(u.y); o[3] += ps * hi_bf(u.y);
+        o[4] += ps * lo_bf(u.z); o[5] += ps * hi_bf(u.z); o[6] += ps * lo_bf(u.w); o[7] += ps * hi_bf(u.w);
+      }
     }
   }
 #pragma unroll

@@ -21,6 +21,12 @@ from .ops import BF16, F32
 _INDIRECT = [os.environ.get('EVK_DECODE_INDIRECT', '1') != '0']      # beam search re-orders a row table, not the K/V caches
 _GRAPH_ENABLED = [True]          # capture the per-token launch sequence in a HIP graph (set False to debug eagerly)
 _FUSED_APPEND = [os.environ.get('EVK_DECODE_FUSED_APPEND', '1') != '0']  # K / V cache append + strided q inside the self-attention kernel
+# decoder norms applied in the operand load of the projection that follows (evk_linear_ln): 'off' (default), 'final' = only the unconditional last norm in
+# front of the logits -- measured 0.489 -> 0.499 ms per token: 16 rows x 2 dependent wave reductions per wave cost more than the norm launch --,
+# 'all' = the nine conditional norms too -- measured 0.49 -> 0.64 ms per token: every one of the
+# N/16 workgroups of a projection re-reads its 64 rows of per-hypothesis gamma / beta deltas, 128 KB against a 64 KB activation tile, and a
+# workgroup's loads are bound by one CU's L1 fill rate.  The entry point stays (bit-identical to norm + GEMM, tested).
+_FUSED_LN = [os.environ.get('EVK_DECODE_FUSED_LN', 'off')]
 _FUSED_BOOK = [os.environ.get('EVK_DECODE_FUSED_BOOK', '1') != '0']      # beam bookkeeping as one kernel per token (csrc/beam.hip)
 stats = {}                       # facts about the last beam_search call (bench.py reads the per-token step time from here)
 
@@ -103,6 +109,25 @@ class _FusedDecodeWeights:
         c = self.clns[i]
         return ops.layernorm(x, self.geff[i], self.beff[i], eps=c.eps, mode=1, dgam=deltas[2 * i].unsqueeze(1), dbet=deltas[2 * i + 1].unsqueeze(1))
 
+    def ln_linear(self, x, gamma, beta, eps, w, bias, N, deltas=None, act=H.ACT_NONE, resid=None, out_f32=False):
+        """act(LayerNorm(x) @ w^T + bias) (+ resid) in ONE launch (evk_linear_ln: the norm runs in the GEMM's operand load); x (R, 512)
+        16-bit, w (>= N rows, 512) 16-bit, deltas = (dgam, dbet) rows of the conditional norm or None.  Output (R, pad8(N))."""
+        R, K = x.shape[0], x.shape[-1]
+        Np = (N + 7) // 8 * 8
+        mk = torch.zeros if Np != N else torch.empty
+        y = mk(R, Np, dtype=torch.float32 if out_f32 else BF16, device=x.device)
+        dg, db = deltas if deltas is not None else (None, None)
+        H.check(H.lib.evk_linear_ln(H.ptr(x), H.ptr(gamma), H.ptr(beta), H.ptr(dg) if dg is not None else None, H.ptr(db) if db is not None else None,
+                                    dg.stride(0) if dg is not None else 0, C.c_float(eps), 1, H.ptr(w), H.ptr(bias) if bias is not None else None,
+                                    H.ptr(resid) if resid is not None else None, Np, H.ptr(y), H.F32 if out_f32 else H.BF16, Np, R, N, K, act,
+                                    H.stream()), 'linear_ln')
+        return y
+
+    def cln_linear(self, i, x, deltas, w, bias, N, act=H.ACT_NONE):
+        """conditional norm i of the decoder followed by a projection"""
+        c = self.clns[i]
+        return self.ln_linear(x, self.geff[i], self.beff[i], c.eps, w, bias, N, deltas=(deltas[2 * i], deltas[2 * i + 1]), act=act)
+
     def qkv(self, li, n):
         R, d = n.shape[0], self.d
         out = torch.empty(R, 3 * d, dtype=BF16, device=n.device)
@@ -178,10 +203,16 @@ class _DecoderState:
         fw, d = self.fused, model.d_model
         deltas = fw.cln_deltas(memory)
         x = emb
+        ln_ok = d == 512 and x.shape[0] <= 4096
+        fuse_ln = _FUSED_LN[0] == 'all' and ln_ok
+        x = x.view(-1, d)
         for i, layer in enumerate(model.decoder.layers):
-            n = fw.norm(3 * i, x, deltas)
             sa = layer.self_attn
-            qkv = fw.qkv(i, n.view(-1, d))
+            if fuse_ln:
+                qkv = fw.cln_linear(3 * i, x, deltas, fw.qkv_w[i], fw.qkv_b[i], 3 * d)
+            else:
+                n = fw.norm(3 * i, x, deltas)
+                qkv = fw.qkv(i, n.view(-1, d))
             if self.anc is not None and _FUSED_APPEND[0] and qkv.stride(0) % 8 == 0:
                 # q read in place, this step's K / V attended to straight from qkv and appended to the caches by the same kernel
                 c = torch.empty(qkv.shape[0], 1, d, dtype=qkv.dtype, device=qkv.device)
@@ -196,15 +227,25 @@ class _DecoderState:
                     c = _attend1(q, self.ks[i], self.vs[i], h, None, rowmap=self.anc, last_pos=pos)
                 else:
                     c = _attend1(q, self.ks[i], self.vs[i], h, kmask)
-            x = sa.linears[3](c, resid=x)
-            n = fw.norm(3 * i + 1, x, deltas)
-            ca = layer.src_attn
-            c = _attend1(ca.linears[0](n), self.kc[i], self.vc[i], h, self.src_mask)
-            x = ca.linears[3](c, resid=x)
-            n = fw.norm(3 * i + 2, x, deltas)
-            x = layer.feed_forward(n, resid=x)
-        out = model.decoder.norm(x)
-        logits = self.dec.logit(out, out_f32=True)
+            x = sa.linears[3](c.view(-1, d), resid=x)
+            ca, ff = layer.src_attn, layer.feed_forward
+            if fuse_ln:
+                q = fw.cln_linear(3 * i + 1, x, deltas, ops.shadow(ca.linears[0].weight), ca.linears[0].bias, d)
+            else:
+                q = ca.linears[0](fw.norm(3 * i + 1, x, deltas))
+            c = _attend1(q.view(-1, 1, d), self.kc[i], self.vc[i], h, self.src_mask)
+            x = ca.linears[3](c.view(-1, d), resid=x)
+            if fuse_ln:
+                hid = fw.cln_linear(3 * i + 2, x, deltas, ops.shadow(ff.w_1.weight), ff.w_1.bias, ff.w_1.weight.shape[0], act=H.ACT_RELU)
+                x = ff.w_2(hid, resid=x)
+            else:
+                x = ff(fw.norm(3 * i + 2, x, deltas), resid=x)
+        fn, lg = model.decoder.norm, self.dec.logit
+        if ln_ok and _FUSED_LN[0] in ('all', 'final'):
+            V1 = lg.weight.shape[0]
+            logits = fw.ln_linear(x, fn.gamma, fn.beta, fn.eps, ops.shadow(lg.weight, pad_rows=(V1 % 8 != 0)), lg.bias, V1, out_f32=True)
+        else:
+            logits = self.dec.logit(fn(x), out_f32=True)
         return ops.log_softmax(logits.view(logits.shape[0], -1), self.dec.vocab_size + 1)
 
     def step(self, it):

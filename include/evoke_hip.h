@@ -116,6 +116,13 @@ int evk_replay_destroy(void* plan);
  * (visual_extractor.py:30-38 -> torchvision), and their autograd backward passes.                      */
 int evk_gemm_launch(const evk_gemm* desc, evk_stream_t stream);
 int64_t evk_gemm_workspace_bytes(const evk_gemm* desc);   /* 0 when no workspace is needed */
+/* y[M][N] = act(LN(x)[M][512] . w[N][512]^T + bias) (+ resid, bf16 [M][ldr]): the LayerNorm of evk_layernorm_fwd (same modes, same
+ * arithmetic, optional per-row conditional deltas dgam / dbet bf16 [M][ld_delta]) applied to the rows of x as they are loaded by the
+ * GEMM, so `sublayer(x) = x + f(norm(x))` (encoder_decoder.py:114-126, 144-179) costs one launch per projection in the per-token decode
+ * step instead of norm + projection.  K must be 512 (the decoder width of the released configuration). */
+int evk_linear_ln(const void* x, const float* gamma, const float* beta, const void* dgam, const void* dbet, int64_t ld_delta,
+                  float eps, int32_t mode, const void* w, const float* bias, const void* resid, int64_t ldr, void* y, int32_t y_dtype,
+                  int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t act, evk_stream_t stream);
 
 /* NHWC bf16 convolution, weights KRSC bf16 ([Co][KH][KW][Ci]); y = conv(x, w) [+ nothing]: BN is separate.
  * fwd:   y[N,Ho,Wo,Co]      dgrad: dx[N,Hi,Wi,Ci]      wgrad: dw[Co,KH,KW,Ci] (f32, accumulated)       */

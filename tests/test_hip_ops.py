@@ -612,3 +612,45 @@ def test_native_trunk_frozen_parameters_and_no_grad():
     with torch.no_grad():
         y3 = t(img)
     assert y3.shape == (2, 2, 2, 2048) and torch.isfinite(y3.float()).all()
+
+
+@pytest.mark.parametrize('R,N,cond,act,f32', [(256, 1536, True, 0, False), (256, 512, True, 1, False), (256, 1445, False, 0, True), (37, 512, True, 0, False),
+                                              (1, 16, False, 0, False)])
+def test_linear_with_layernorm_in_the_operand_load_equals_norm_then_linear(R, N, cond, act, f32):
+    """evk_linear_ln (the decode step's `x + f(norm(x))` sublayers, encoder_decoder.py:114-126, 144-179, as one launch per projection)
+    against the two launches it replaces -- evk_layernorm_fwd (R2Gen mode, optional conditional deltas) then the skinny GEMM.  The
+    prologue repeats the norm kernel's arithmetic term for term on the same lane / element mapping, so the result must be BIT-identical
+    (beam search compares scores for ties: a last-bit difference could change a token)."""
+    import ctypes as C
+    from evoke_amd import hip as H, ops
+    torch.manual_seed(R + N)
+    K = 512
+    x = (torch.randn(R, K, device='cuda') * 1.3 + 0.2).to(BF)
+    gamma, beta = 1 + 0.1 * torch.randn(K, device='cuda'), 0.1 * torch.randn(K, device='cuda')
+    dg = (0.05 * torch.randn(R, K, device='cuda')).to(BF) if cond else None
+    db = (0.05 * torch.randn(R, K, device='cuda')).to(BF) if cond else None
+    Np = (N + 7) // 8 * 8
+    w = torch.zeros(Np, K, device='cuda', dtype=BF)
+    w[:N] = (torch.randn(N, K, device='cuda') * 0.05).to(BF)
+    bias = 0.1 * torch.randn(N, device='cuda')
+    resid = (torch.randn(R, Np, device='cuda') * 0.5).to(BF) if act == 0 and not f32 else None
+    odt = torch.float32 if f32 else BF
+    with torch.no_grad():
+        n = ops.layernorm(x, gamma, beta, eps=1e-6, mode=1, dgam=dg, dbet=db)
+        want = torch.zeros(R, Np, device='cuda', dtype=odt)
+        ops.gemm(n, w, want, R, N, K, lda=K, ldb=K, ldc=Np, bias=bias, resid=resid, ldr=Np, act=act)
+    got = torch.zeros(R, Np, device='cuda', dtype=odt)
+    H.check(H.lib.evk_linear_ln(H.ptr(x), H.ptr(gamma), H.ptr(beta), H.ptr(dg) if cond else None, H.ptr(db) if cond else None, K if cond else 0,
+                                C.c_float(1e-6), 1, H.ptr(w), H.ptr(bias), H.ptr(resid) if resid is not None else None, Np, H.ptr(got),
+                                H.F32 if f32 else H.BF16, Np, R, N, K, act, H.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(got, want), 'max |d| %.3g' % float((got.float() - want.float()).abs().max())
+    # and against fp32 torch on the same operands (R2Gen norm: unbiased std, eps added to the std)
+    xf = x.float()
+    g, b = gamma + (dg.float() if cond else 0), beta + (db.float() if cond else 0)
+    ref = (g * (xf - xf.mean(-1, keepdim=True)) / (xf.std(-1, keepdim=True) + 1e-6) + b) @ w[:N].float().t() + bias
+    if act == 1:
+        ref = torch.relu(ref)
+    if resid is not None:
+        ref = ref + resid[:, :N].float()
+    close(got[:, :N].float(), ref.cpu(), 2e-2, 2e-2, 'linear_ln vs fp32')
