@@ -33,18 +33,33 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const BeamP p) {
   __shared__ float win_v[KMAX]; __shared__ int win_i[KMAX];
   __shared__ int s_best;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int beam = p.beam, n = beam * p.V1;
+  const int beam = p.beam;
   // ---- 1. top-`beam` candidates
   float bv[KMAX]; int bi[KMAX];
 #pragma unroll
   for (int j = 0; j < KMAX; ++j) { bv[j] = -INFINITY; bi[j] = 0x7fffffff; }
-  for (int c = tid; c < n; c += 256) {
-    const int src = c / p.V1, w = c - src * p.V1;
-    float v = p.beam_sum[b * beam + src] + p.logp[(long)(b * beam + src) * p.ld + w];
-    int id = c;
+  // a thread's share of one source beam is requested in one batch (UNR loads in flight), then inserted: the step is latency bound, and
+  // one dependent L2 round trip per candidate (23 per thread at beam 4, V = 1444) was most of this kernel's time.  Which thread sees
+  // which candidate does not matter: the order (score, then lowest flat index) is total.
+  constexpr int UNR = 8;
+  for (int src = 0; src < beam; ++src) {
+    const float base = p.beam_sum[b * beam + src];
+    const float* row = p.logp + (long)(b * beam + src) * p.ld;
+    for (int w0 = tid; w0 < p.V1; w0 += 256 * UNR) {
+      float lv[UNR];
 #pragma unroll
-    for (int j = 0; j < KMAX; ++j)
-      if (j < beam && (v > bv[j] || (v == bv[j] && id < bi[j]))) { const float tv = bv[j]; const int ti = bi[j]; bv[j] = v; bi[j] = id; v = tv; id = ti; }
+      for (int u = 0; u < UNR; ++u) { const int w = w0 + 256 * u; lv[u] = w < p.V1 ? row[w] : 0.f; }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int w = w0 + 256 * u;
+        if (w >= p.V1) continue;
+        float v = base + lv[u];
+        int id = src * p.V1 + w;
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j)
+          if (j < beam && (v > bv[j] || (v == bv[j] && id < bi[j]))) { const float tv = bv[j]; const int ti = bi[j]; bv[j] = v; bi[j] = id; v = tv; id = ti; }
+      }
+    }
   }
   for (int r = 0; r < beam; ++r) {
     float best = bv[0]; int bid = bi[0];

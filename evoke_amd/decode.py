@@ -27,6 +27,7 @@ _FUSED_APPEND = [os.environ.get('EVK_DECODE_FUSED_APPEND', '1') != '0']  # K / V
 # N/16 workgroups of a projection re-reads its 64 rows of per-hypothesis gamma / beta deltas, 128 KB against a 64 KB activation tile, and a
 # workgroup's loads are bound by one CU's L1 fill rate.  The entry point stays (bit-identical to norm + GEMM, tested).
 _FUSED_LN = [os.environ.get('EVK_DECODE_FUSED_LN', 'off')]
+_SPLIT_CLN = [os.environ.get('EVK_DECODE_SPLIT_CLN', '1') != '0']       # first conditional-norm MLP layer as two launches (see cln_deltas)
 _FUSED_BOOK = [os.environ.get('EVK_DECODE_FUSED_BOOK', '1') != '0']      # beam bookkeeping as one kernel per token (csrc/beam.hip)
 stats = {}                       # facts about the last beam_search call (bench.py reads the per-token step time from here)
 
@@ -100,7 +101,11 @@ class _FusedDecodeWeights:
         R, K = memory.shape[0], memory.shape[-1]
         n, d = self.n, self.d
         hid = torch.empty(R, n * d, dtype=BF16, device=memory.device)
-        ops.gemm(memory, self.w1, hid, R, n * d, K, lda=K, ldb=K, ldc=n * d, bias=self.b1, act=H.ACT_RELU)
+        # two column halves: 72 output tiles each, which the launcher gives to the latency-oriented skinny kernel (whole 256-deep K chunks
+        # in flight, 128 x 32 tiles on 576 workgroups) instead of 144 tiles of the throughput kernel on 144 of 256 CUs (54 -> ~40 us)
+        half = (n // 2) * d if _SPLIT_CLN[0] and n % 2 == 0 else n * d
+        for off in range(0, n * d, half):
+            ops.gemm(memory, self.w1[off:off + half], hid[:, off:], R, half, K, lda=K, ldb=K, ldc=n * d, bias=self.b1[off:off + half], act=H.ACT_RELU)
         out = torch.empty(n, R, d, dtype=BF16, device=memory.device)
         ops.gemm(hid, self.w2, out, R, d, d, lda=n * d, ldb=d, ldc=d, batch=(1, n), sA=(0, d), sB=(0, d * d), sC=(0, R * d))
         return out
