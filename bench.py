@@ -132,28 +132,34 @@ def decode_record(model, a, rank, world, dev, with_cpu):
         with torch.no_grad():
             return model(bb['images'], bb['ids'], bb['masks'], bb['pids'], bb['inc'], bb['inc_masks'], mode='inference')[1]
 
-    for _ in range(max(1, min(a.warmup, 2))):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
+    # Replicas: no rank waits for another inside the measurement.  A rank that fails reports an infinite time, and the ONE collective
+    # (max over ranks) sits outside the guarded region so that every rank reaches it whatever happened -- a barrier inside would hang
+    # the whole job on a single rank's exception.
     n = max(2, min(a.steps, 4))
-    t0 = time.perf_counter()
-    step_ms = []
-    for _ in range(n):
-        seq = step()
-        ev0, ev1, cnt = DEC.stats['step_events']
-        step_ms.append((ev0, ev1, cnt))
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    dt = time.perf_counter() - t0
+    step_ms, dt, err = [], float('inf'), None
+    try:
+        for _ in range(max(1, min(a.warmup, 2))):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            seq = step()
+            ev0, ev1, cnt = DEC.stats['step_events']
+            step_ms.append((ev0, ev1, cnt))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    except Exception as e:          # noqa: BLE001
+        err = e
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+    if err is not None:
+        raise err
     if rank != 0:
         return None
     dt = float(tt.item())
+    if not (dt < float('inf')):
+        raise RuntimeError('decode failed on another rank')
     per_step_ms = sum(e0.elapsed_time(e1) for e0, e1, c in step_ms) / max(1, sum(c for _, _, c in step_ms))
     td = model.text_decoder
     w_params = sum(p.numel() for m in (td.model.decoder, td.model.rm, td.logit) for p in m.parameters())
