@@ -226,6 +226,12 @@ def decode_cpu_baseline(model, a, dev, beam, L):
     base = dict(value=Bc * L / dt, unit='tokens/s', cores=threads, kind='port',
                 sample='oracle beam search (full-prefix re-decode per step, as the reference) incl. encoder, beam %d, %d studies x %d views %dx%d, '
                        '%d steps, one run of %.1f s' % (beam, Bc, a.views, a.res, a.res, L, dt))
+    def oracle_score(sq):          # teacher-forced fp32 log-probability the oracle gives a sequence (no [EOS] on these weights: all L tokens)
+        ids = torch.cat([torch.full((sq.shape[0], 1), V - 2, dtype=sq.dtype), sq[:, :-1]], 1)
+        with torch.no_grad():
+            lp = O.r2_forward_logprobs(P, ids, x, torch.ones_like(ids), m, cfg, O.Ctx())
+        return [round(float(v), 4) for v in lp.gather(2, sq.unsqueeze(-1)).squeeze(-1).sum(1)]
+    sc_h, sc_r = oracle_score(hip_seq), oracle_score(ref_seq)
     pref = []
     for hs, rs in zip(hip_seq.tolist(), ref_seq.tolist()):
         k = 0
@@ -233,6 +239,7 @@ def decode_cpu_baseline(model, a, dev, beam, L):
             k += 1
         pref.append(k)
     par = dict(identical_sequences=same_seq, token_agreement=same_tok, bleu4_vs_oracle=bl[3], studies=Bc, common_prefix_tokens=pref,
+               oracle_logprob_of_engine_sequences=sc_h, oracle_logprob_of_oracle_sequences=sc_r,
                note='engine (16-bit) vs CPU oracle (fp32) on the same inputs and the procedural weights of the golden fixtures, beam %d, %d positions; '
                     'an untrained network never emits [EOS] and its logit gaps are tiny, so once one near-tie resolves differently the rest of the '
                     'sequence differs -- common_prefix_tokens says where; the <= 40-position golden cases are token-exact (tests)' % (beam, L))
