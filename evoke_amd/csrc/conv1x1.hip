@@ -142,16 +142,18 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv1x1_ws_kernel(const WsP p) {
   __syncthreads();
   int cur = 0;
   bf16_t* ow = obuf + wave * 16 * OST;
+  // statistics accumulate over ALL the pixel tiles this workgroup walks (fixed order: repeatable) and leave as ONE partial row per
+  // workgroup group: the second reduction stage (bn.hip) reads <= 256 rows instead of one per 128 pixels (4608 at layer1)
+  float s0[NT][4], s1[NT][4], tx[8];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s0[nt][j] = 0.f; s1[nt][j] = 0.f; }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) tx[k] = 0.f;
   for (; t < p.ntiles; t += p.groups) {
     const int tn = t + p.groups;
     if (tn < p.ntiles) fetch(tn);                      // in flight while this tile multiplies
-    float s0[NT][4], s1[NT][4], tx[8];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { s0[nt][j] = 0.f; s1[nt][j] = 0.f; }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) tx[k] = 0.f;
     const bf16_t* at = abuf + cur * MT * LDA;
 #pragma unroll 1
     for (int mt = 0; mt < MT / 16; ++mt) {
@@ -244,35 +246,35 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv1x1_ws_kernel(const WsP p) {
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    if (p.part) {
-      float* prow = p.part + (long)t * prn * p.N;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        float a[4], b[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { a[j] = row16_sum(s0[nt][j]); b[j] = row16_sum(s1[nt][j]); }
-        if (li == 0) {
-          const int c = n0 + nt * 16 + g * 4;
-          *reinterpret_cast<float4*>(prow + c) = make_float4(a[0], a[1], a[2], a[3]);
-          *reinterpret_cast<float4*>(prow + p.N + c) = make_float4(b[0], b[1], b[2], b[3]);
-        }
-      }
-      if (DGRAD && xstat) {             // lanes with equal lane % CPRW hold the same 8 channels (one pixel row each): sum over the rows
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-#pragma unroll
-          for (int off = CPRW; off < 64; off <<= 1) tx[k] += __shfl_xor(tx[k], off, 64);
-        }
-        if (lane < CPRW) {
-          float* d = prow + 2 * p.N + n0 + lane * 8;
-          *reinterpret_cast<float4*>(d) = make_float4(tx[0], tx[1], tx[2], tx[3]);
-          *reinterpret_cast<float4*>(d + 4) = make_float4(tx[4], tx[5], tx[6], tx[7]);
-        }
-      }
-    }
     if (tn < p.ntiles) stash(cur ^ 1);
     __syncthreads();
     cur ^= 1;
+  }
+  if (p.part) {
+    float* prow = p.part + (long)grp * prn * p.N;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float a[4], b[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { a[j] = row16_sum(s0[nt][j]); b[j] = row16_sum(s1[nt][j]); }
+      if (li == 0) {
+        const int c = n0 + nt * 16 + g * 4;
+        *reinterpret_cast<float4*>(prow + c) = make_float4(a[0], a[1], a[2], a[3]);
+        *reinterpret_cast<float4*>(prow + p.N + c) = make_float4(b[0], b[1], b[2], b[3]);
+      }
+    }
+    if (DGRAD && xstat) {             // lanes with equal lane % CPRW hold the same 8 channels (one pixel row each): sum over the rows
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+#pragma unroll
+        for (int off = CPRW; off < 64; off <<= 1) tx[k] += __shfl_xor(tx[k], off, 64);
+      }
+      if (lane < CPRW) {
+        float* d = prow + 2 * p.N + n0 + lane * 8;
+        *reinterpret_cast<float4*>(d) = make_float4(tx[0], tx[1], tx[2], tx[3]);
+        *reinterpret_cast<float4*>(d + 4) = make_float4(tx[4], tx[5], tx[6], tx[7]);
+      }
+    }
   }
 }
 
@@ -335,13 +337,23 @@ int evk_conv1x1_ws_supported(int64_t M, int32_t K, int32_t N) {
 }
 
 static int ws_tile_rows(int K) { return K == 1024 ? 32 : (K == 512 ? 64 : 128); }
+// workgroup groups of a launch = partial rows it writes (launch_ws: 256 / slices, at most one per pixel tile, whole XCD octets)
+static int ws_groups(int64_t M, int K, int N) {
+  const int slices = N / (K >= 512 ? 128 : 256);
+  int groups = 256 / (slices > 0 ? slices : 1);
+  const int ntiles = (int)cdiv(M, ws_tile_rows(K));
+  if (groups < 1) groups = 1;
+  if (groups > ntiles) groups = ntiles;
+  if (groups >= 8) groups &= ~7;
+  return groups;
+}
 int64_t evk_conv1x1_ws_part_bytes(int64_t M, int32_t K, int32_t N) { return cdiv(M, ws_tile_rows(K)) * 2 * (int64_t)N * 4; }
 
 int evk_conv1x1_ws_fwd(const void* x, const void* w, void* y, int64_t M, int32_t K, int32_t N, float* part, int64_t part_bytes, int32_t* nblk,
                        evk_stream_t stream) {
   EVK_REQUIRE(x && w && y && evk_conv1x1_ws_supported(M, K, N), "conv1x1_ws_fwd: unsupported problem M=%ld K=%d N=%d", (long)M, K, N);
   EVK_REQUIRE(!part || (nblk && part_bytes >= evk_conv1x1_ws_part_bytes(M, K, N)), "conv1x1_ws_fwd: statistics buffer too small");
-  if (part) *nblk = (int)cdiv(M, ws_tile_rows(K));
+  if (part) *nblk = ws_groups(M, K, N);
   WsP p{(const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, nullptr, nullptr, part, nullptr, nullptr, M, N, 0, 0, 0};
   return dispatch<false>(p, K, reinterpret_cast<hipStream_t>(stream));
 }
@@ -360,7 +372,7 @@ int evk_conv1x1_ws_dgrad_xstat(const void* dy, const void* wt, const void* skip,
   const int64_t need = evk_conv1x1_ws_part_bytes(M, K, N) / 2 * (stat_x ? 3 : 2);
   EVK_REQUIRE(!part || (gate && nblk && part_bytes >= need), "conv1x1_ws_dgrad: gate statistics need a gate and a large enough buffer");
   EVK_REQUIRE(!stat_x || part, "conv1x1_ws_dgrad: stat_x needs the partials buffer");
-  if (part) *nblk = (int)cdiv(M, ws_tile_rows(K));
+  if (part) *nblk = ws_groups(M, K, N);
   WsP p{(const bf16_t*)dy, (const bf16_t*)wt, (bf16_t*)dx, (const bf16_t*)skip, (const bf16_t*)gate, part, (const bf16_t*)stat_x, stat_mean, M, N, 0, 0, 0};
   return dispatch<true>(p, K, reinterpret_cast<hipStream_t>(stream));
 }
