@@ -284,6 +284,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const SmBP p) {
 struct LsmP {
   const float* logits; float* logp; const long long* target; const float* wmask; float* acc2;  // acc2 = {sum(-logp*w), sum(w)}
   float* lse; long rows; int V, ld, ld_out;
+  float* rownll;   // optional [rows]: -logp[target] * w per row instead of the atomic accumulation (summed by the caller: order-independent bits)
 };
 __global__ __launch_bounds__(256) void logsoftmax_kernel(const LsmP p) {
   const int lane = threadIdx.x & 63;
@@ -304,7 +305,8 @@ __global__ __launch_bounds__(256) void logsoftmax_kernel(const LsmP p) {
   }
   if (p.target && lane == 0) {
     const float w = p.wmask[row];
-    if (w != 0.f) {
+    if (p.rownll) p.rownll[row] = w != 0.f ? -(in[p.target[row]] - lse) * w : 0.f;
+    else if (w != 0.f) {
       unsafeAtomicAdd(p.acc2, -(in[p.target[row]] - lse) * w);
       unsafeAtomicAdd(p.acc2 + 1, w);
     }
@@ -613,10 +615,20 @@ int evk_log_softmax_nll_fwd(const float* logits, float* logp, float* lse, const 
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   EVK_REQUIRE(logits && rows > 0 && V > 0 && V <= ld, "log_softmax: bad args");
   EVK_REQUIRE(!target || (wmask && acc2), "log_softmax: NLL needs wmask and acc2");
-  LsmP p{logits, logp, (const long long*)target, wmask, acc2, lse, rows, V, ld, ld_out};
+  LsmP p{logits, logp, (const long long*)target, wmask, acc2, lse, rows, V, ld, ld_out, nullptr};
   ProfScope ps(EVK_FAM_NORM, s);
   hipLaunchKernelGGL(logsoftmax_kernel, dim3(row_blocks(rows)), dim3(256), 0, s, p);
   return evk_check_launch("log_softmax");
+}
+
+int evk_log_softmax_nll_rows(const float* logits, float* lse, const int64_t* target, const float* wmask, float* row_nll, int64_t rows,
+                             int32_t V, int32_t ld, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(logits && target && wmask && row_nll && rows > 0 && V > 0 && V <= ld, "log_softmax_nll_rows: bad args");
+  LsmP p{logits, nullptr, (const long long*)target, wmask, nullptr, lse, rows, V, ld, ld, row_nll};
+  ProfScope ps(EVK_FAM_NORM, s);
+  hipLaunchKernelGGL(logsoftmax_kernel, dim3(row_blocks(rows)), dim3(256), 0, s, p);
+  return evk_check_launch("log_softmax_nll_rows");
 }
 
 int evk_nll_bwd(const float* logits, const float* lse, const int64_t* target, const float* wmask, const float* gscale,

@@ -853,9 +853,11 @@ class _NllLoss(torch.autograd.Function):
         rows = _rows(logits)
         ld = logits.shape[-1]
         lse = _e(rows, dtype=F32, device=logits.device)
-        acc = _z(2, dtype=F32, device=logits.device)
-        H.check(H.lib.evk_log_softmax_nll_fwd(H.ptr(logits), None, H.ptr(lse), H.ptr(target), H.ptr(wmask), H.ptr(acc), rows, V,
-                                              ld, ld, H.stream()), 'nll_fwd')
+        row = _e(rows, dtype=F32, device=logits.device)
+        H.check(H.lib.evk_log_softmax_nll_rows(H.ptr(logits), H.ptr(lse), H.ptr(target), H.ptr(wmask), H.ptr(row), rows, V, ld, H.stream()),
+                'nll_rows')
+        # per-row values summed by torch's tree reduction: the loss has the same bits on every run (f32 atomics did not)
+        acc = torch.stack((row.sum(), wmask.sum()))
         ctx.save_for_backward(logits, lse, target, wmask, acc)
         ctx.V = V
         return acc[0] / acc[1]

@@ -278,6 +278,10 @@ int evk_decode_attention_qkv(const void* qkv, int64_t ldq, void* k_cache, void* 
                              int32_t R, int32_t S, int32_t heads, int32_t head_dim, float scale, evk_stream_t stream);
 int evk_log_softmax_nll_fwd(const float* logits, float* logp, float* lse, const int64_t* target, const float* wmask, float* acc2,
                             int64_t rows, int32_t V, int32_t ld, int32_t ld_out, evk_stream_t stream);
+/* the masked-NLL forward with one value per row (row_nll[r] = -logp[r][target[r]] * wmask[r]) instead of the two atomically accumulated
+ * sums: the caller adds the rows up (a tree reduction: the same bits on every run), lse as above.  loss.py:9-22 */
+int evk_log_softmax_nll_rows(const float* logits, float* lse, const int64_t* target, const float* wmask, float* row_nll, int64_t rows,
+                             int32_t V, int32_t ld, evk_stream_t stream);
 int evk_nll_bwd(const float* logits, const float* lse, const int64_t* target, const float* wmask, const float* gscale,
                 void* dlogits, int64_t rows, int32_t V, int32_t ld, int32_t ld_out, evk_stream_t stream);
 /* beam step (caption_model.py:70-74): k <= 8 largest of each row, descending, ties -> lowest index first */
