@@ -839,7 +839,18 @@ __global__ __launch_bounds__(NTHR) void gemm_small_kernel(const GemmP p) {
   constexpr int TILE_BYTES = (64 + 64) * BK * 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
-  const int wg = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  int wg = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if ((gridDim.y & 7) == 0) {
+    // every tile and every TAP (batch index) of one K-slice reads the same pixel rows of dY and X: slice s lives on XCD s % 8, so the
+    // nine taps of a 3x3 weight gradient fetch their slice into that L2 once (measured before: 1.14 GB fetched for 150 MB of operands)
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int per = gridDim.x * gridDim.z;               // blocks per K-slice
+    const int xcd = lin & 7, j = lin >> 3;
+    const int sl = j / per, w = j - sl * per;
+    by = xcd + 8 * sl;
+    bz = w / gridDim.x;
+    wg = w - bz * gridDim.x;
+  }
   const int tm = wg / p.tilesN, tn = wg - tm * p.tilesN;
   const int zo = bz / p.bi, zi = bz - zo * p.bi;
   const int k_begin = by * p.ksteps_per_split * BK;
@@ -914,6 +925,12 @@ inline int small_splitk(int M, int N, int K, int batch) {
   long sk = cdiv(SMALL_TARGET_BLOCKS, tiles);
   if (sk > ksteps) sk = ksteps;
   if (sk < 1) sk = 1;
+  if (sk >= 8) {            // whole K-slices per XCD (gemm_small_kernel's block remap): a multiple of 8 non-empty slices
+    for (long s8 = (sk + 4) / 8 * 8; s8 >= 8; s8 -= 8) {
+      const int per = (int)cdiv(ksteps, s8);
+      if (cdiv(ksteps, per) == s8) return (int)s8;
+    }
+  }
   const int per = (int)cdiv(ksteps, sk);
   return (int)cdiv(ksteps, per);
 }
