@@ -15,6 +15,7 @@
 #include <queue>
 #include <unordered_map>
 #include <vector>
+#include <string.h>
 #include "common.h"
 
 namespace {
@@ -88,6 +89,7 @@ void* evk_replay_build(void* graph_handle, int32_t max_lanes) {
   std::vector<int> pos(n);                    // node id -> index in issue order
   for (size_t k = 0; k < n; ++k) pos[order[k]] = (int)k;
   // node parameters
+  size_t n_bad = 0;                           // EVK_REPLAY_DEBUG: unreplayable nodes are all listed before the build fails
   for (size_t k = 0; k < n; ++k) {
     RNode& r = p->nodes[k];
     hipGraphNode_t nd = nodes[order[k]];
@@ -110,7 +112,9 @@ void* evk_replay_build(void* graph_handle, int32_t max_lanes) {
         // original's kernel arguments -- the plan is refused and the caller stays on eager launches.  Keep such copies out of
         // the step (the engine's own code has none; EVK_REPLAY_DEBUG=1 names the neighbours of the offending node).
         if (getenv("EVK_REPLAY_DEBUG")) {
-          for (size_t j = (k > 16 ? k - 16 : 0); j < k + 3 && j < n; ++j) {
+          fprintf(stderr, "[replay] multi-dimensional memcpy at node %zu: width %zu height %zu depth %zu, src pitch %zu dst pitch %zu\n", k, (size_t)mp.extent.width,
+                  (size_t)mp.extent.height, (size_t)mp.extent.depth, (size_t)mp.srcPtr.pitch, (size_t)mp.dstPtr.pitch);
+          for (size_t j = (k > 4 ? k - 4 : 0); j < k + 3 && j < n; ++j) {
             hipGraphNodeType tj; (void)hipGraphNodeGetType(nodes[order[j]], &tj);
             const char* nm = "";
             if (tj == hipGraphNodeTypeKernel) { hipKernelNodeParams kq{}; if (hipGraphKernelNodeGetParams(nodes[order[j]], &kq) == hipSuccess) nm = hipKernelNameRefByPtr(kq.func, nullptr); }
@@ -118,8 +122,18 @@ void* evk_replay_build(void* graph_handle, int32_t max_lanes) {
           }
         }
         evk_set_error("replay_build: node %zu is a multi-dimensional memcpy (not replayable)", k);
+        if (getenv("EVK_REPLAY_DEBUG")) { ++n_bad; continue; }          // list them all, fail after the walk
         delete p;
         return nullptr;
+      }
+      if (getenv("EVK_REPLAY_DEBUG")) {
+        fprintf(stderr, "[replay] 1-D memcpy at node %zu: %zu bytes kind %d\n", k, (size_t)mp.extent.width, (int)mp.kind);
+        for (size_t j = (k > 3 ? k - 3 : 0); j < k + 3 && j < n; ++j) {
+          hipGraphNodeType tj; (void)hipGraphNodeGetType(nodes[order[j]], &tj);
+          const char* nm = "";
+          if (tj == hipGraphNodeTypeKernel) { hipKernelNodeParams kq{}; if (hipGraphKernelNodeGetParams(nodes[order[j]], &kq) == hipSuccess) nm = hipKernelNameRefByPtr(kq.func, nullptr); }
+          fprintf(stderr, "[replay]    node %zu type %d %.90s\n", j, (int)tj, nm ? nm : "?");
+        }
       }
       r.type = 1;
       r.dst = (char*)mp.dstPtr.ptr + mp.dstPos.x; r.src = (const char*)mp.srcPtr.ptr + mp.srcPos.x; r.bytes = mp.extent.width; r.kind = mp.kind;
@@ -141,6 +155,7 @@ void* evk_replay_build(void* graph_handle, int32_t max_lanes) {
       return nullptr;
     }
   }
+  if (n_bad) { fprintf(stderr, "[replay] %zu multi-dimensional memcpy nodes\n", n_bad); delete p; return nullptr; }
   // Lanes = a MINIMUM PATH COVER of the dependency DAG (maximum bipartite matching between "node as predecessor" and "node as
   // successor" along the edges): every chain follows real edges only, so putting a chain on one stream adds no false
   // dependency, and the cover needs no more chains than the capture had streams (main, weight gradients, relational memory,
@@ -214,6 +229,25 @@ void* evk_replay_build(void* graph_handle, int32_t max_lanes) {
     }
     lane_tail[lane] = (int)k;
   }
+  // Lane 0 runs on the CALLER's stream, which the trainer / bench create with the higher HIP queue priority for the step's critical path.
+  // Make lane 0 the chain that carries that path -- the one with the most batch-norm kernels (they only occur in the trunk's forward /
+  // backward chain) -- instead of whichever chain happens to start first.  EVK_REPLAY_CRIT_LANE=1 enables it; it did not help (the step is
+  // 73-81 ms under the replayer with every priority assignment tried, 54 ms eager: DESIGN.md section 5).
+  {
+    const char* e = getenv("EVK_REPLAY_CRIT_LANE");
+    if (e && atoi(e) != 0 && lane_tail.size() > 1) {          // measured (bench --graph 1): 81 ms per step with, 75 ms without -- opt-in experiment
+      std::vector<int> bn(lane_tail.size(), 0);
+      for (const RNode& r : p->nodes)
+        if (r.type == 0) {
+          const char* nm = hipKernelNameRefByPtr(r.func, nullptr);
+          if (nm && (strstr(nm, "bn_apply") || strstr(nm, "bn_bwd_apply") || strstr(nm, "bn_stats_finalize"))) ++bn[r.lane];
+        }
+      int crit = 0;
+      for (size_t l = 1; l < bn.size(); ++l) if (bn[l] > bn[crit]) crit = (int)l;
+      if (crit != 0 && bn[crit] > 0)
+        for (RNode& r : p->nodes) r.lane = r.lane == crit ? 0 : (r.lane == 0 ? crit : r.lane);
+    }
+  }
   if (getenv("EVK_REPLAY_DEBUG")) {
     std::vector<int> cnt(lane_tail.size(), 0);
     for (RNode& r : p->nodes) ++cnt[r.lane];
@@ -226,8 +260,11 @@ void* evk_replay_build(void* graph_handle, int32_t max_lanes) {
     }
   }
   p->lanes.assign(lane_tail.size(), nullptr);
+  // side lanes at the default priority (0), like the eager step's side streams; EVK_REPLAY_SIDE_PRIO overrides (1 = lowest on this device)
+  const char* sp = getenv("EVK_REPLAY_SIDE_PRIO");
+  const int side_prio = sp ? atoi(sp) : 0;
   for (size_t l = 1; l < p->lanes.size(); ++l)
-    if (hipStreamCreateWithFlags(&p->lanes[l], hipStreamNonBlocking) != hipSuccess) { evk_set_error("replay_build: hipStreamCreate failed"); delete p; return nullptr; }
+    if (hipStreamCreateWithPriority(&p->lanes[l], hipStreamNonBlocking, side_prio) != hipSuccess) { evk_set_error("replay_build: hipStreamCreate failed"); delete p; return nullptr; }
   p->begin_event = new_event(p);
   for (size_t l = 1; l < p->lanes.size(); ++l) {
     const int e = new_event(p);

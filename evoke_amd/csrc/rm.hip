@@ -663,7 +663,9 @@ int evk_rm_forward(const void* xk, const void* xv, const void* gw, const void* m
     hipLaunchKernelGGL(rm_persist_fwd_kernel, dim3(B), dim3(256), 0, s, pp);
     return evk_check_launch("rm_forward (persistent)");
   }
-  if (hipMemcpyAsync(w.m, m0, RD * 2, hipMemcpyDeviceToDevice, s) != hipSuccess) { evk_set_error("rm_forward: memcpy failed"); return EVK_ELAUNCH; }
+  // copies as kernels (evk_cast 16-bit -> 16-bit), not hipMemcpyAsync: the memcpy nodes a stream capture records for them cannot be read back
+  // on ROCm 7.2 (hipGraphMemcpyNodeGetParams returns garbage), which made the step replayer refuse every plan that contains this call
+  if (int e = evk_cast(m0, EVK_BF16, w.m, EVK_BF16, RD, stream)) return e;
   if (int e = evk_act_fwd(w.m, w.tm, RD, EVK_ACT_TANH, stream)) return e;   // tm[0] = tanh(m0)
   for (int t = 0; t < L; ++t) {
     const bf16_t* m = w.m + t * RD;
@@ -688,10 +690,8 @@ int evk_rm_forward(const void* xk, const void* xv, const void* gw, const void* m
       hipLaunchKernelGGL(rm_gate_fwd2_kernel, dim3(ew_blocks(RD)), dim3(256), 0, s, gp);
     }
   }
-  if (m_last && hipMemcpyAsync(m_last, w.m + (long)L * RD, RD * 2, hipMemcpyDeviceToDevice, s) != hipSuccess) {
-    evk_set_error("rm_forward: memcpy failed");
-    return EVK_ELAUNCH;
-  }
+  if (m_last)
+    if (int e = evk_cast(w.m + (long)L * RD, EVK_BF16, m_last, EVK_BF16, RD, stream)) return e;
   return evk_check_launch("rm_forward");
 }
 

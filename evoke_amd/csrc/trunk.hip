@@ -253,7 +253,9 @@ int evk_trunk_forward(const evk_trunk_cfg* cfg, const evk_trunk_layer* layers, i
     i += down ? 4 : 3;
   }
   const Pair& last = P.pairs[i - (P.has_down.back() ? 4 : 3) + 2];
-  if (hipMemcpyAsync(out, x, last.M * last.C * 2, hipMemcpyDeviceToDevice, hs) != hipSuccess) { evk_set_error("trunk: copy-out failed"); return EVK_ELAUNCH; }
+  // a copy KERNEL, not hipMemcpyAsync: in a stream capture the 37 MB copy becomes a memcpy node that ROCm 7.2 reports as multi-dimensional,
+  // which the step replayer (replay.hip) cannot re-issue
+  TRY(evk_cast(x, EVK_BF16, out, EVK_BF16, last.M * last.C, stream));
   return EVK_OK;
 }
 

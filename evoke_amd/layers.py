@@ -314,7 +314,12 @@ def multiview_fusion(x, patient_ids, batch_size, sdpa, ln2):
     if lone:
         pieces.append(x.index_select(0, ops.index_tensor(lone, dev)))
         order += lone
-    allrows = torch.cat(pieces, 0)
+    # one group (every study has the same number of views: the common case): no concatenation -- torch.cat of a single tensor is a
+    # device-to-device hipMemcpyAsync (19 MB here), and a captured memcpy node is what the step replayer cannot re-issue --, and no
+    # gather when the anchors are already in batch order
+    allrows = pieces[0] if len(pieces) == 1 else torch.cat(pieces, 0)
+    if order == list(range(batch_size)):
+        return allrows
     inv = np.empty(batch_size, dtype=np.int64)
     inv[np.asarray(order)] = np.arange(batch_size)
     return allrows.index_select(0, ops.index_tensor(inv, dev))
@@ -626,9 +631,8 @@ class RelationalMemory(nn.Module):
         self.U = LinearP(d_model, d_model * 2)
 
     def init_memory(self, batch_size, device):
-        m = torch.zeros(batch_size, self.num_slots, self.d_model, dtype=BF16, device=device)
-        m[:, :, :self.num_slots] = torch.eye(self.num_slots, dtype=BF16, device=device)
-        return m
+        eye = torch.eye(self.num_slots, self.d_model, dtype=BF16, device=device)          # ones at [i][i], zero elsewhere
+        return eye.unsqueeze(0).expand(batch_size, -1, -1).contiguous()
 
     def run(self, emb, m0):
         """emb (B, L, d), m0 (B, slots, d) -> (memories (B, L, slots*d), last memory (B, slots, d))."""
@@ -686,7 +690,7 @@ class EncoderDecoder(nn.Module):
 
     def encode(self, enc_states, enc_mask):
         """_prepare_feature_forward + Transformer.encode: drops the global token, att_embed, 3-layer encoder."""
-        att = enc_states[:, 1:, :].contiguous()
+        att = ops.pitched_copy(enc_states[:, 1:, :])          # (not .contiguous(): see ops.pitched_copy)
         am = enc_mask[:, 1:]
         all_on = getattr(enc_mask, 'evk_all_ones', None)          # set by encoder_states: saves a device->host sync per step
         if all_on is None:

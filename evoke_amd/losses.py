@@ -27,10 +27,10 @@ from .ops import BF16, F32, _pad8
 def lm_loss(logits, ids, masks, V):
     """logits f32 (B, L, ld); position t predicts ids[:, t+1] weighted by masks[:, t+1]; the last position has weight 0."""
     B, L = ids.shape
-    target = torch.zeros(B, L, dtype=torch.long, device=logits.device)
-    target[:, :L - 1] = ids[:, 1:]
-    w = torch.zeros(B, L, dtype=F32, device=logits.device)
-    w[:, :L - 1] = masks[:, 1:].to(F32)
+    # built with cat (kernels), not with slice assignment: a copy between two row-pitched views is issued as hipMemcpy2DAsync, which a
+    # stream capture records as a memcpy node the step replayer cannot re-issue (csrc/replay.hip)
+    target = torch.cat([ids[:, 1:], torch.zeros(B, 1, dtype=torch.long, device=logits.device)], 1)
+    w = torch.cat([masks[:, 1:].to(F32), torch.zeros(B, 1, dtype=F32, device=logits.device)], 1)
     return ops.nll_loss(logits, target.view(-1), w.view(-1), V)
 
 

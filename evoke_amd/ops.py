@@ -134,6 +134,14 @@ def shadow(p, pad_rows=False):
     return sh
 
 
+def pitched_copy(x):
+    """Contiguous copy of a row-pitched view (a slice along an inner dimension).  torch issues `.contiguous()` of such a view as
+    hipMemcpy2DAsync; inside a stream capture that becomes a memcpy node whose parameters ROCm 7.2 does not report back, so the step
+    replayer (csrc/replay.hip) refuses the plan.  An elementwise kernel does the same copy and keeps the step replayable; autograd sees
+    a multiplication by one."""
+    return x if x.is_contiguous() else torch.mul(x, 1)
+
+
 def set_shadow_fresh(p, sh):
     """Used by the fused optimizer, which writes the bf16 shadow itself."""
     _shadows[id(p)] = (sh, p._version, p)
@@ -216,9 +224,17 @@ class _Uploader:
             # HIP-graph capture of a whole step (evoke_amd/graph.py): the copy becomes a memcpy node that re-reads ITS OWN pinned
             # staging buffer at every replay, so the buffer is dedicated to the graph (kept alive by the capture's owner) and no
             # event of the ring is synchronised while the stream is capturing
-            stage = torch.from_numpy(arr.reshape(-1).view(np.uint8).copy()).pin_memory()
+            # ... and the copy is a KERNEL that reads the pinned (device-mapped) buffer, not a memcpy: ROCm 7.2 does not report the
+            # parameters of captured host-to-device memcpy nodes back faithfully and the step replayer (csrc/replay.hip) cannot
+            # re-issue what it cannot read
+            pad = (nb + 3) // 4 * 4
+            host = np.zeros(pad, dtype=np.uint8)
+            host[:nb] = arr.reshape(-1).view(np.uint8)
+            stage = torch.from_numpy(host).pin_memory()
             CAPTURE_KEEPALIVE.append(stage)
-            return stage.to(self.device, non_blocking=True).view(tdt).view(arr.shape)
+            dst = torch.empty(pad, dtype=torch.uint8, device=self.device)
+            H.check(H.lib.evk_cast(stage.data_ptr(), H.F32, H.ptr(dst), H.F32, pad // 4, H.stream()), 'upload (word copy from pinned memory)')
+            return dst[:nb].view(tdt).view(arr.shape)
         if nb > self.bufs[0].numel() or nb == 0:
             return torch.from_numpy(arr).to(self.device)          # oversize / empty: plain (blocking) path
         k = self.i % len(self.bufs)

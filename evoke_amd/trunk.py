@@ -277,7 +277,7 @@ class _PatchMean(torch.autograd.Function):
     def backward(ctx, dfc):
         N, P, Cc = ctx.dims
         datt = _e(N, P, Cc, device=dfc.device)
-        H.check(H.lib.evk_patch_mean_bwd(None, H.ptr(dfc.contiguous()), H.ptr(datt), N, P, Cc, H.stream()), 'patch_mean_bwd')
+        H.check(H.lib.evk_patch_mean_bwd(None, H.ptr(ops.pitched_copy(dfc)), H.ptr(datt), N, P, Cc, H.stream()), 'patch_mean_bwd')
         return datt
 
 
