@@ -654,3 +654,44 @@ def test_linear_with_layernorm_in_the_operand_load_equals_norm_then_linear(R, N,
     if resid is not None:
         ref = ref + resid[:, :N].float()
     close(got[:, :N].float(), ref.cpu(), 2e-2, 2e-2, 'linear_ln vs fp32')
+
+
+@pytest.mark.parametrize('R,S,pos', [(256, 100, 0), (256, 100, 57), (12, 100, 99), (5, 256, 130)])
+def test_decode_attention_fed_by_the_fused_projection_equals_append_then_attend(R, S, pos):
+    """evk_decode_attention_qkv (q read in place from the q | k | v projection, this step's key / value attended to and appended by
+    the same launch) against the three steps it replaces: slice q, write k / v into cache row r at *last_pos, evk_decode_attention_indirect
+    over the row table.  Same arithmetic in the same order: outputs and caches must be BIT-identical (beam search ranks on them).
+    The row table sends every earlier position to some other hypothesis' cache row, as after beam re-ordering."""
+    import ctypes as C
+    from evoke_amd import hip as H
+    torch.manual_seed(R + S + pos)
+    heads, HD = 8, 512
+    qkv = (torch.randn(R, 3 * HD, device='cuda') * 0.7).to(BF)
+    ks = (torch.randn(R, S, HD, device='cuda') * 0.7).to(BF)
+    vs = torch.randn(R, S, HD, device='cuda').to(BF)
+    anc = torch.randint(0, R, (R, S), device='cuda', dtype=torch.int32)
+    anc[:, pos] = torch.arange(R, device='cuda', dtype=torch.int32)           # the position being written lives in the hypothesis' own row
+    lp = torch.tensor([pos], device='cuda', dtype=torch.long)
+    # reference path
+    k0, v0 = ks.clone(), vs.clone()
+    k0[:, pos] = qkv[:, HD:2 * HD]
+    v0[:, pos] = qkv[:, 2 * HD:]
+    q = qkv[:, :HD].contiguous().view(R, 1, HD)
+    want = torch.empty_like(q)
+    H.check(H.lib.evk_decode_attention_indirect(H.ptr(q), H.ptr(k0), H.ptr(v0), None, H.ptr(anc), H.ptr(lp), H.ptr(want), R, S, heads, 64,
+                                                C.c_float(0.125), H.stream()))
+    # fused path
+    k1, v1 = ks.clone(), vs.clone()
+    got = torch.empty(R, 1, HD, device='cuda', dtype=BF)
+    H.check(H.lib.evk_decode_attention_qkv(H.ptr(qkv), 3 * HD, H.ptr(k1), H.ptr(v1), H.ptr(anc), H.ptr(lp), H.ptr(got), R, S, heads, 64,
+                                           C.c_float(0.125), H.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert torch.equal(k1, k0) and torch.equal(v1, v0)
+    # and against fp32 torch: positions <= pos, each read from the row the table names
+    rows = anc[:, :pos + 1].long()
+    kk = k0[rows, torch.arange(pos + 1, device='cuda')].float().view(R, pos + 1, heads, 64).permute(0, 2, 1, 3)
+    vv = v0[rows, torch.arange(pos + 1, device='cuda')].float().view(R, pos + 1, heads, 64).permute(0, 2, 1, 3)
+    sc = (q.float().view(R, heads, 1, 64) @ kk.transpose(-1, -2)) * 0.125
+    ref = (torch.softmax(sc, -1) @ vv).permute(0, 2, 1, 3).reshape(R, 1, HD)
+    close(got.float(), ref.cpu(), 1e-2, 1e-2, 'decode attention qkv R=%d S=%d pos=%d' % (R, S, pos))
