@@ -569,8 +569,17 @@ class _RMRecurrence(torch.autograd.Function):
         B, L, d = xk.shape
         dev = xk.device
         lin = rm.attn.linears
-        wqkv = torch.cat([ops.shadow(lin[i].weight).view(d, d) for i in range(3)], 0)
-        bqkv = torch.cat([lin[i].bias.detach() for i in range(3)], 0).contiguous()
+        # fused q | k | v weights: rebuilt on every call while training (the weights move), cached for inference (decode calls this once per
+        # generated token: two concatenation kernels per token otherwise)
+        key = (ops.WEIGHT_EPOCH[0],) + tuple(lin[i].weight._version for i in range(3)) + tuple(lin[i].bias._version for i in range(3))
+        hit = getattr(rm, '_qkv_cache', None)
+        if not torch.is_grad_enabled() and hit is not None and hit[0] == key and hit[1].device == dev:
+            wqkv, bqkv = hit[1], hit[2]
+        else:
+            wqkv = torch.cat([ops.shadow(lin[i].weight).view(d, d) for i in range(3)], 0)
+            bqkv = torch.cat([lin[i].bias.detach() for i in range(3)], 0).contiguous()
+            # (never filled from inside a stream capture: captured kernels do not run, the tensors would be read before they are written)
+            rm._qkv_cache = (key, wqkv, bqkv) if not torch.is_grad_enabled() and not (dev.type == 'cuda' and torch.cuda.is_current_stream_capturing()) else None
         nb = H.lib.evk_rm_ws_bytes(B, L)
         ws = torch.empty(nb, dtype=torch.uint8, device=dev)
         out = torch.empty(B, L, rm.num_slots * d, dtype=BF16, device=dev)

@@ -134,6 +134,10 @@ def shadow(p, pad_rows=False):
     return sh
 
 
+WEIGHT_EPOCH = [0]          # bumped by FusedOptimizer.step(): the optimizer kernel rewrites parameters through raw pointers, which does not advance
+                            # torch's per-tensor version counters -- inference-time caches of derived weights key on (this, the versions)
+
+
 def pitched_copy(x):
     """Contiguous copy of a row-pitched view (a slice along an inner dimension).  torch issues `.contiguous()` of such a view as
     hipMemcpy2DAsync; inside a stream capture that becomes a memcpy node whose parameters ROCm 7.2 does not report back, so the step

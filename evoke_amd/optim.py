@@ -161,6 +161,7 @@ class FusedOptimizer(torch.optim.Optimizer):
         consecutive updated parameters with the same step history share one fused launch.  fp16 storage: the gradients carry
         the loss scale; a non-finite gradient anywhere (after the all-reduce, so every rank sees it) skips the whole step."""
         self.steps += 1
+        ops.WEIGHT_EPOCH[0] += 1
         on_gpu = bool(self.flat) and self.flat[0]['p'].is_cuda
         if on_gpu:
             ops.join_side_streams()
