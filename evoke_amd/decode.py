@@ -282,8 +282,10 @@ class _DecoderState:
 
 
 @torch.no_grad()
-def beam_search(dec, enc_states, enc_mask, args, return_scores=False):
-    """-> (B, max_seq_len) int64 token ids padded with [PAD] (= AttModel._sample_beam with sample_n = 1)."""
+def beam_search(dec, enc_states, enc_mask, args, return_scores=False, step_hook=None):
+    """-> (B, max_seq_len) int64 token ids padded with [PAD] (= AttModel._sample_beam with sample_n = 1).
+    step_hook(t, logp, beam_sum): test instrument, called on the launching stream right before the bookkeeping of position t consumes
+    `logp` (f32, one row of >= V+1 log-probabilities per live hypothesis; may be edited in place) with the running sums (B, beam)."""
     was_training = dec.training
     dec.eval()
     try:
@@ -344,7 +346,9 @@ def beam_search(dec, enc_states, enc_mask, args, return_scores=False):
 
         nb = 1
         logp = [logp]
+        hook = step_hook if step_hook is not None else (lambda *a: None)
         # t = 0 (the hypothesis count grows from B to B*beam here) runs eagerly
+        hook(0, logp[0], beam_sum)
         w = book(0, max_len == 1)
         if max_len > 1:
             nb = beam
@@ -353,6 +357,7 @@ def beam_search(dec, enc_states, enc_mask, args, return_scores=False):
             ar = torch.arange(max_len, device=dev).unsqueeze(0)
             logp_buf = st.step_static(w.reshape(-1), pos, (ar <= pos).expand(R, -1).to(torch.uint8).contiguous()).clone()
             logp[0] = logp_buf
+            hook(1, logp_buf, beam_sum)
 
             fused_book = _FUSED_BOOK[0] and st.anc is not None and beam_seq.is_contiguous() and st.mem.is_contiguous()
             stats['fused_bookkeeping'] = bool(fused_book)
@@ -373,7 +378,9 @@ def beam_search(dec, enc_states, enc_mask, args, return_scores=False):
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):                           # warm-up iterations (real steps) off the default stream
                     body()
+                    hook(2, logp_buf, beam_sum)
                     body()
+                    hook(3, logp_buf, beam_sum)
                 cur.wait_stream(side)
                 done = 2
                 try:
@@ -386,11 +393,13 @@ def beam_search(dec, enc_states, enc_mask, args, return_scores=False):
                     graph = None
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-            for _ in range(done, n_body):
+            for it_ in range(done, n_body):
                 if graph is not None:
                     graph.replay()
                 else:
                     body()
+                if step_hook is not None:
+                    step_hook(it_ + 2, logp_buf, beam_sum)       # body number it_ wrote the log-probabilities of position it_ + 2
             ev1.record()
             stats['step_events'] = (ev0, ev1, max(0, n_body - done))      # per-token step time = elapsed / count (bench.py)
             stats['graph'] = graph is not None

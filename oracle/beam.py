@@ -14,8 +14,12 @@ def _step_logprobs(P, ys, memory, src_mask, cfg, ctx):
     return F.log_softmax(O._lin(P, 'text_decoder.logit', out[:, -1]), dim=1)
 
 
-def beam_search(P, enc_states, enc_mask, cfg, bos, eos, pad=0, ctx=None, return_scores=False):
-    """-> seq (B, max_seq_len) int64, padded with `pad` (AttModel._sample_beam with sample_n=1)."""
+def beam_search(P, enc_states, enc_mask, cfg, bos, eos, pad=0, ctx=None, return_scores=False, trace=None, n_near=8):
+    """-> seq (B, max_seq_len) int64, padded with `pad` (AttModel._sample_beam with sample_n=1).
+    trace: optional list; one dict per step is appended with the search's own decision record -- the `beam + n_near` best
+    candidates of every sample in the order of the descending sort (flat index = parent beam * (V+1) + word, score = running sum
+    + log-prob, the log-prob itself) and the running sums after the step, before the -1000 penalty of finished beams.  The first
+    `beam` entries are the step's selection; the following ones are what a perturbed scorer could have picked instead."""
     ctx = ctx or O.Ctx()
     beam, max_len = cfg['beam_size'], cfg['max_seq_len']
     att, am = enc_states[:, 1:, :], enc_mask[:, 1:]
@@ -37,6 +41,10 @@ def beam_search(P, enc_states, enc_mask, cfg, bos, eos, pad=0, ctx=None, return_
         nb = lp.shape[1]
         cand = (beam_sum[:, :nb].unsqueeze(-1) + lp).reshape(bsz, -1)
         srt, ix = torch.sort(cand, -1, True)
+        if trace is not None:
+            k = min(beam + n_near, cand.shape[1])
+            trace.append({'flat': ix[:, :k].clone(), 'score': srt[:, :k].clone(), 'logp': lp.reshape(bsz, -1).gather(1, ix[:, :k]),
+                          'n_beams': nb})
         ix = ix[:, :beam]
         beam_ix, word_ix = ix // v, ix % v
         state_ix = (beam_ix + torch.arange(bsz).unsqueeze(-1) * nb).reshape(-1)

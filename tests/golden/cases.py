@@ -25,6 +25,9 @@ CASES = {
     'ft224_gpt2': dict(kind='finetune_gpt2', res=224, pids=[0, 1], B=2, L=12, Li=6, modes=['eval'], max_seq_len=16, beam_size=3),
     'beam224': dict(kind='beam', res=224, pids=[0, 1, 0], B=2, L=8, Li=6, modes=['eval'], max_seq_len=20, beam_size=3),
     'beam224_b4': dict(kind='beam', res=224, pids=[0, 1], B=2, L=8, Li=0, modes=['eval'], max_seq_len=14, beam_size=4),
+    # BASELINE config 5 at its real decode length: 384^2, two views per study, beam 4, max_seq_len 100 (the untrained network never
+    # emits [EOS], so every hypothesis runs the full 100 positions: modules/caption_model.py:142-196, modules/att_model.py:98-137)
+    'beam384_b4_L100': dict(kind='beam', res=384, pids=[0, 1, 0, 1], B=2, L=8, Li=6, modes=['eval'], max_seq_len=100, beam_size=4),
 }
 
 

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Decision trace of the L = 100 beam case (BASELINE config 5 shape), written by the CPU ORACLE after it has reproduced the
+imported reference's token ids of tests/golden/beam384_b4_L100.npz bit for bit (asserted below): per decoded position and study,
+the 12 best candidates of the descending sort of modules/caption_model.py:70-74 (flat index = parent beam * (V+1) + word, running
+score, log-probability).  The first `beam` columns are the reference's selection at that position, the rest is what a perturbed
+scorer could pick instead -- this is what lets the GPU test follow the reference's search step by step (teacher-forced) and price
+every disagreement by the reference's own score margin.
+
+Usage:  python tests/golden/make_beam_trace.py        (about a minute of CPU; needs no /root/reference)
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from oracle import beam as OB, functional as O, spec as S  # noqa: E402
+from tests.golden.cases import CASES, make_inputs  # noqa: E402
+
+V = 1444
+
+
+def main(name='beam384_b4_L100'):
+    case = CASES[name]
+    gold = np.load(os.path.join(HERE, name + '.npz'))
+    inp = make_inputs(case, V)
+    cfg = dict(O.DEFAULT_CFG, max_seq_len=case['max_seq_len'], beam_size=case['beam_size'])
+    P = S.procedural_state(S.finetune_spec(V))
+    tr = []
+    with torch.no_grad():
+        x, m = O.finetune_encoder_states(P, inp['images'], inp['patient_ids'], case['B'], inp['inc_ids'], inp['inc_masks'], cfg, O.Ctx())
+        seq, p = OB.beam_search(P, x, m, cfg, bos=V - 2, eos=V - 1, pad=0, trace=tr, return_scores=True)
+    assert seq.tolist() == gold['eval/seq'].tolist(), 'the oracle no longer reproduces the reference ids: trace not written'
+    out = {k: torch.stack([t[k] for t in tr]).numpy() for k in ('flat', 'score', 'logp')}      # (T, B, beam + 8)
+    out['best_p'] = np.asarray(p, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, name + '_trace.npz'), **out)
+    beam = case['beam_size']
+    margin = out['score'][1:, :, beam - 1] - out['score'][1:, :, beam]
+    print(name, 'trace written:', {k: v.shape for k, v in out.items()})
+    print('selection margin (beam-th minus next candidate) per study: min', margin.min(0), 'median', np.median(margin, 0),
+          'positions below 1e-2:', (margin < 1e-2).sum(0))
+
+
+if __name__ == '__main__':
+    main()

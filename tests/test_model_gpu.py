@@ -175,7 +175,7 @@ def test_trunk_follows_bf16_emulation(train):
     assert e_ref <= 1.3 * emu_vs_ref + 1e-2
 
 
-@pytest.mark.parametrize('name', [n for n, c in CASES.items() if c['kind'] == 'beam'])
+@pytest.mark.parametrize('name', [n for n, c in CASES.items() if c['kind'] == 'beam' and c['max_seq_len'] <= 40])
 def test_beam_search_matches_reference(name):
     """Incremental device-side beam search vs the reference's full re-decode.  Default (fp16-storage) build: the token ids
     must be IDENTICAL to the reference's on every sample.  bf16-storage build only: a bf16 logit can flip a near-tie, so
@@ -228,6 +228,101 @@ def test_beam_search_matches_reference(name):
         print('   oracle score of hip seq', s_h, ' of ref seq', s_r)
         for a, b in zip(s_h, s_r):
             assert a >= b - 0.05 * max(1.0, abs(b)), (a, b)
+
+
+def test_beam_search_at_100_positions_follows_the_reference_decisions():
+    """BASELINE config 5 at its real decode length (384^2, two views, beam 4, max_seq_len 100) against the imported reference's token
+    ids (tests/golden/beam384_b4_L100.npz) and the decision trace the oracle wrote after reproducing those ids bit for bit
+    (tests/golden/beam384_b4_L100_trace.npz: the 12 best candidates per position and study, with the reference's running scores).
+
+    An untrained network never emits [EOS] and its candidates lie close together: the reference's OWN margin between the last selected
+    and the first rejected candidate falls below 1e-2 at 9 / 15 of the 100 positions of the two studies (minimum 3.4e-3 / 2.6e-4), which
+    no 16-bit engine can resolve.  So the test pins the search the way it can be pinned exactly:
+      1. TEACHER-FORCED: the engine's beam search runs its product path (graph-replayed step, evk_beam_step bookkeeping) while a hook
+         replaces every step's log-probabilities by the reference's selection, so that at all 100 positions the engine holds exactly
+         the reference's hypotheses.  At every position the engine's log-probabilities of the 12 traced candidates must agree with the
+         reference's (<= LOGP_TOL), the engine's own top-beam set must equal the reference's wherever the reference's margin exceeds
+         2 x LOGP_TOL, and the forced search must return the reference's ids exactly (bookkeeping, cache row tables, memory re-order).
+      2. FREE-RUNNING: the ids must be identical to the reference's up to the first position whose margin is below 2 x LOGP_TOL, and
+         the first divergent decision must be between candidates the reference scored within 2 x LOGP_TOL of each other."""
+    from evoke_amd import decode
+    from evoke_amd.model_pretrain_finetune import FineTune
+    from oracle import spec as S
+    name = 'beam384_b4_L100'
+    case, gold, tr = CASES[name], _gold(name), _gold(name + '_trace')
+    LOGP_TOL = 5e-3 if F16 else 4e-2
+    beam, T, B, V1 = case['beam_size'], case['max_seq_len'], case['B'], V + 1
+    inp = make_inputs(case, V)
+    args = dict(ARGS, max_seq_len=T, beam_size=beam)
+    model = FineTune(args, load_tokenizer(), 'iu_xray')
+    load_procedural(model, S.finetune_spec(V))
+    model.eval()
+    flat = torch.from_numpy(tr['flat']).cuda()            # (T, B, K)
+    score = torch.from_numpy(tr['score']).cuda()
+    ref_lp = torch.from_numpy(tr['logp']).cuda()
+    want = torch.from_numpy(gold['eval/seq'])
+    margin = tr['score'][:, :, beam - 1] - tr['score'][:, :, beam]            # (T, B)
+    rec = {'err': [], 'same': []}
+
+    def forced(t, logp, beam_sum):
+        nb = 1 if t == 0 else beam
+        ld = logp.shape[-1]
+        parent, word = flat[t] // V1, flat[t] % V1                                              # (B, K)
+        rows = parent + torch.arange(B, device='cuda').unsqueeze(1) * nb
+        got = logp[rows, word]
+        rec['err'].append((got - ref_lp[t]).abs().max(dim=1).values.cpu())
+        cand = (beam_sum[:, :nb].unsqueeze(-1) + logp.view(B, nb, ld)[:, :, :V1]).reshape(B, -1)
+        mine = cand.topk(beam, dim=1).indices.sort(dim=1).values
+        rec['same'].append((mine == flat[t][:, :beam].sort(dim=1).values).all(dim=1).cpu())
+        new = torch.full_like(logp, -1e30)
+        new[rows[:, :beam], word[:, :beam]] = score[t][:, :beam] - beam_sum[:, :nb].gather(1, parent[:, :beam])
+        logp.copy_(new)
+
+    state = {'perm': torch.zeros(B, 1, dtype=torch.long, device='cuda'), 'first': [T] * B}
+
+    def watch(t, logp, beam_sum):
+        """free-running search: the engine's own selection, translated into the reference's beam numbering for as long as both hold the
+        same hypotheses; records the first position at which the two selections differ"""
+        nb = 1 if t == 0 else beam
+        ld = logp.shape[-1]
+        cand = (beam_sum[:, :nb].unsqueeze(-1) + logp.view(B, nb, ld)[:, :, :V1]).reshape(B, -1)
+        mine = cand.topk(beam, dim=1).indices                                                   # engine order
+        as_ref = state['perm'].gather(1, mine // V1) * V1 + mine % V1
+        sel = flat[t][:, :beam]
+        hit = as_ref.unsqueeze(2) == sel.unsqueeze(1)                                           # (B, mine, ref)
+        ok = hit.any(dim=2).all(dim=1).cpu()
+        for b in range(B):
+            if state['first'][b] == T and not bool(ok[b]):
+                state['first'][b] = t
+        state['perm'] = hit.float().argmax(dim=2)
+
+    with torch.no_grad():
+        x, enc_mask = model.encoder_states(inp['images'].cuda(), np.array(inp['patient_ids']), B, inp['inc_ids'], inp['inc_masks'])
+        seq_forced, p_forced = decode.beam_search(model.text_decoder, x, enc_mask, args, return_scores=True, step_hook=forced)
+        assert decode.stats.get('graph') and decode.stats.get('fused_bookkeeping'), decode.stats
+        seq_free = decode.beam_search(model.text_decoder, x, enc_mask, args, step_hook=watch)
+        seq_plain = decode.beam_search(model.text_decoder, x, enc_mask, args)
+    err = torch.stack(rec['err']).numpy()                 # (T, B)
+    same = torch.stack(rec['same']).numpy()
+    assert err.shape == (T, B)
+    print('\n[%s] teacher-forced: max |logp - reference| over 100 positions x 12 candidates: %s (tolerance %.0e); own top-%d set equals '
+          'the reference at %s of %d positions' % (name, err.max(0), LOGP_TOL, beam, same.sum(0), T))
+    assert err.max() <= LOGP_TOL, err.max(0)
+    bad = ~same & (margin > 2 * LOGP_TOL)
+    assert not bad.any(), 'the engine selects another beam set where the reference margin is %s' % margin[bad]
+    assert torch.equal(seq_forced.cpu(), want), 'forced search does not return the reference ids: bookkeeping / state re-order differ'
+    np.testing.assert_allclose(p_forced.cpu().numpy(), tr['best_p'], atol=2e-2, rtol=0)
+    assert torch.equal(seq_free, seq_plain), 'a read-only hook changed the search'
+    free = seq_free.cpu()
+    for b in range(B):
+        first = state['first'][b]
+        agree = float((free[b] == want[b]).float().mean())
+        print('   study %d free-running: selections identical to the reference for %d positions%s; token agreement of the returned '
+              'report %.2f' % (b, first, '' if first == T else ' (reference margin there: %.2e)' % margin[first, b], agree))
+        if first == T:
+            assert torch.equal(free[b], want[b])
+        else:
+            assert margin[first, b] < 2 * LOGP_TOL, 'the search leaves the reference at a decision the reference made with margin %g' % margin[first, b]
 
 
 def test_distilgpt2_backend_matches_hf_fixture():
