@@ -75,12 +75,13 @@ __global__ __launch_bounds__(256) void dropout_kernel(const bf16_t* __restrict__
 // out[r][:] = table[ids[r]][:] * scale + (pos ? pos[r % L][:] : 0) + (extra ? extra[:] : 0)
 __global__ __launch_bounds__(256) void embedding_fwd_kernel(const float* __restrict__ table, const long long* __restrict__ ids,
                                                             const float* __restrict__ pos, const float* __restrict__ extra,
-                                                            void* __restrict__ out, int out_f32, long rows, int D, int L, float scale) {
+                                                            void* __restrict__ out, int out_f32, long rows, int D, int L, float scale, long long table_rows) {
   const long total = rows * D;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long r = i / D;
     const int c = (int)(i - r * D);
-    float v = table[ids[r] * D + c] * scale;
+    const long long id = ids[r];
+    float v = (id >= 0 && id < table_rows) ? table[id * D + c] * scale : 0.f;        // an id outside the table must not become a wild read
     if (pos) v += pos[(r % L) * D + c];
     if (extra) v += extra[c];
     stx(out, out_f32, i, v);
@@ -88,12 +89,12 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(const float* __restr
 }
 // dtable[ids[r]][:] += dout[r][:] * scale  (rows with ids == padding_idx are skipped)
 __global__ __launch_bounds__(256) void embedding_bwd_kernel(const void* __restrict__ dout, int d_f32, const long long* __restrict__ ids,
-                                                            float* __restrict__ dtable, long rows, int D, float scale, long long padding_idx) {
+                                                            float* __restrict__ dtable, long rows, int D, float scale, long long padding_idx, long long table_rows) {
   const long total = rows * D;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long r = i / D;
     const long long id = ids[r];
-    if (id == padding_idx) continue;
+    if (id == padding_idx || id < 0 || id >= table_rows) continue;     // (an id outside the table must not become a wild atomic)
     unsafeAtomicAdd(dtable + id * D + (i - r * D), ldx(dout, d_f32, i) * scale);
   }
 }
@@ -229,6 +230,45 @@ __global__ void loss_scale_update_kernel(float* __restrict__ state, float growth
   state[2] = 0.f;
 }
 
+// ---- gradients of a model that no FusedOptimizer owns (the reference's own step: backward -> clip_grad_value_ -> torch.optim) --------
+// one table entry per <= 64 Ki-element piece of a parameter's f32 gradient tensor; one workgroup walks pieces with a grid stride
+struct GradChunk { float* p; int n; int pad; };
+template <int MODE>        // 0: scan for inf / NaN -> state[2];  1: g *= 1 / scale, or g = 0 on an overflowed step;  2: g *= scale
+__global__ __launch_bounds__(256) void grads_multi_kernel(const GradChunk* __restrict__ tab, int n_chunks, float* __restrict__ state) {
+  float mul = 1.f;
+  bool wipe = false;
+  if (MODE == 1) { wipe = state[2] != 0.f; mul = 1.f / state[0]; }
+  if (MODE == 2) mul = state[0];
+  bool bad = false;
+  for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    float* g = tab[c].p;
+    const int n = tab[c].n;
+    if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+      const int n4 = n >> 2;
+      for (int i = threadIdx.x; i < n4; i += 256) {
+        float4 t = reinterpret_cast<float4*>(g)[i];
+        if (MODE == 0) {
+          bad |= ((__float_as_uint(t.x) & 0x7f800000u) == 0x7f800000u) | ((__float_as_uint(t.y) & 0x7f800000u) == 0x7f800000u) |
+                 ((__float_as_uint(t.z) & 0x7f800000u) == 0x7f800000u) | ((__float_as_uint(t.w) & 0x7f800000u) == 0x7f800000u);
+        } else {
+          t = wipe ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(t.x * mul, t.y * mul, t.z * mul, t.w * mul);
+          reinterpret_cast<float4*>(g)[i] = t;
+        }
+      }
+      for (int i = (n4 << 2) + threadIdx.x; i < n; i += 256) {
+        if (MODE == 0) bad |= (__float_as_uint(g[i]) & 0x7f800000u) == 0x7f800000u;
+        else g[i] = wipe ? 0.f : g[i] * mul;
+      }
+    } else {
+      for (int i = threadIdx.x; i < n; i += 256) {
+        if (MODE == 0) bad |= (__float_as_uint(g[i]) & 0x7f800000u) == 0x7f800000u;
+        else g[i] = wipe ? 0.f : g[i] * mul;
+      }
+    }
+  }
+  if (MODE == 0 && __any(bad) && (threadIdx.x & 63) == 0) state[2] = 1.f;
+}
+
 __global__ void optim_bump_kernel(int* __restrict__ steps, int count, const float* __restrict__ state) {
   if (state && state[2] != 0.f) return;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) steps[i] += 1;
@@ -326,6 +366,96 @@ __global__ __launch_bounds__(256) void optim_dyn_kernel(const OptDyn d) {
   }
 }
 
+// ---- one optimizer step of a whole parameter GROUP (flat buffers of optim.py) in two launches -------------------------------------
+// Every per-step quantity is read from device memory: hyper-parameters (hp[0..5] = lr, beta1, beta2, eps, weight decay, clip value:
+// an lr scheduler or load_state_dict changes the buffer, not a captured kernel argument), per-parameter step counts (bias
+// corrections / rectification are evaluated PER PARAMETER, torch.optim semantics: a parameter that sat out some steps keeps its own
+// count), the loss scale and the overflow verdict.
+// coef[i] = {1 - beta1^t, sqrt(1 - beta2^t), rectification (RAdam; < 0: not rectified yet), took part in this step}
+__global__ void optim_group_coef_kernel(const float* __restrict__ hp, int kind, int n_params, int* __restrict__ steps,
+                                        const unsigned char* __restrict__ touched, float4* __restrict__ coef, const float* __restrict__ state) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_params) return;
+  const bool skip = state && state[2] != 0.f;
+  if (!touched[i]) { coef[i] = make_float4(1.f, 1.f, -1.f, 0.f); return; }
+  if (skip) { coef[i] = make_float4(1.f, 1.f, -1.f, 1.f); return; }          // the main kernel only consumes the gradient
+  const double step = (double)(steps[i] + 1), beta1 = hp[1], beta2 = hp[2];
+  steps[i] += 1;
+  const double b1t = pow(beta1, step), b2t = pow(beta2, step);
+  float rect = -1.f;
+  if (kind == 0) {
+    const double rho_inf = 2.0 / (1.0 - beta2) - 1.0;
+    const double rho_t = rho_inf - 2.0 * step * b2t / (1.0 - b2t);
+    if (rho_t > 5.0) rect = (float)sqrt((rho_t - 4.0) * (rho_t - 2.0) * rho_inf / ((rho_inf - 4.0) * (rho_inf - 2.0) * rho_t));
+  }
+  coef[i] = make_float4((float)(1.0 - b1t), (float)sqrt(1.0 - b2t), rect, 1.f);
+}
+
+struct OptGroup {
+  float* p; float* g; float* m; float* v; float* vmax; bf16_t* shadow; long n;
+  const float* hp; const long* offs; int n_params; const float4* coef; const float* state; float inv_world; int kind; int zero_g;
+};
+constexpr int OPT_CHUNK = 8192;        // elements per workgroup pass: 256 threads x 8 lanes of 4
+__global__ __launch_bounds__(256) void optim_group_kernel(const OptGroup d) {
+  const bool skip = d.state && d.state[2] != 0.f;
+  const float lr = d.hp[0], beta1 = d.hp[1], beta2 = d.hp[2], eps = d.hp[3], wd = d.hp[4], clip = d.hp[5];
+  const float gscale = d.inv_world / (d.state ? d.state[0] : 1.f);
+  __shared__ int range[2];
+  const long n_chunks = (d.n + OPT_CHUNK - 1) / OPT_CHUNK;
+  for (long c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const long e0 = c * OPT_CHUNK, e1 = min(d.n, e0 + OPT_CHUNK);
+    __syncthreads();
+    if (threadIdx.x < 2) {           // parameter index of the chunk's first / last element: largest i with offs[i] <= e
+      const long e = threadIdx.x == 0 ? e0 : e1 - 1;
+      int lo = 0, hi = d.n_params - 1;
+      while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (d.offs[mid] <= e) lo = mid; else hi = mid - 1; }
+      range[threadIdx.x] = lo;
+    }
+    __syncthreads();
+    const int p_lo = range[0], p_hi = range[1];
+    for (long e = e0 + 4 * threadIdx.x; e < e1; e += 4 * 256) {      // parameter starts are multiples of 8 elements: a lane has one owner
+      int lo = p_lo, hi = p_hi;
+      while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (d.offs[mid] <= e) lo = mid; else hi = mid - 1; }
+      const float4 cf = d.coef[lo];
+      if (cf.w == 0.f) continue;                                     // parameter without a gradient this step: untouched (torch.optim)
+      float4 g4 = *reinterpret_cast<const float4*>(d.g + e);
+      if (d.zero_g) *reinterpret_cast<float4*>(d.g + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (skip) continue;
+      float4 w4 = *reinterpret_cast<float4*>(d.p + e), m4 = *reinterpret_cast<float4*>(d.m + e), v4 = *reinterpret_cast<float4*>(d.v + e);
+      float4 x4 = d.vmax ? *reinterpret_cast<float4*>(d.vmax + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float bc1 = cf.x, bc2_sqrt = cf.y, rect = cf.z;
+      auto upd = [&](float g, float& w, float& m, float& v, float& vm) {
+        g *= gscale;
+        if (clip > 0.f) g = fminf(fmaxf(g, -clip), clip);
+        if (wd != 0.f) g += wd * w;
+        m = beta1 * m + (1.f - beta1) * g;
+        v = beta2 * v + (1.f - beta2) * g * g;
+        if (d.kind == 0) {
+          const float mh = m / bc1;
+          if (rect >= 0.f) w -= lr * mh * rect * bc2_sqrt / (sqrtf(v) + eps);
+          else w -= lr * mh;
+        } else {
+          float vv = v;
+          if (d.vmax) { vv = fmaxf(vm, v); vm = vv; }
+          w -= (lr / bc1) * m / (sqrtf(vv) / bc2_sqrt + eps);
+        }
+      };
+      upd(g4.x, w4.x, m4.x, v4.x, x4.x); upd(g4.y, w4.y, m4.y, v4.y, x4.y);
+      upd(g4.z, w4.z, m4.z, v4.z, x4.z); upd(g4.w, w4.w, m4.w, v4.w, x4.w);
+      *reinterpret_cast<float4*>(d.p + e) = w4;
+      *reinterpret_cast<float4*>(d.m + e) = m4;
+      *reinterpret_cast<float4*>(d.v + e) = v4;
+      if (d.vmax) *reinterpret_cast<float4*>(d.vmax + e) = x4;
+      if (d.shadow) {
+        uint2 pk;
+        pk.x = pack2bf(w4.x, w4.y);
+        pk.y = pack2bf(w4.z, w4.w);
+        *reinterpret_cast<uint2*>(d.shadow + e) = pk;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -363,22 +493,22 @@ int evk_dropout(const void* x, const void* resid, void* y, int64_t n, float p, u
 }
 
 int evk_embedding_fwd(const float* table, const int64_t* ids, const float* pos, const float* extra, void* out, int out_dtype,
-                      int64_t rows, int32_t D, int32_t L, float scale, evk_stream_t stream) {
+                      int64_t rows, int32_t D, int32_t L, float scale, int64_t table_rows, evk_stream_t stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  EVK_REQUIRE(table && ids && out && rows > 0 && D > 0 && L > 0, "embedding_fwd: bad args");
+  EVK_REQUIRE(table && ids && out && rows > 0 && D > 0 && L > 0 && table_rows > 0, "embedding_fwd: bad args");
   ProfScope ps(EVK_FAM_ELTWISE, s);
   hipLaunchKernelGGL(embedding_fwd_kernel, dim3(ew_blocks(rows * D)), dim3(256), 0, s, table, (const long long*)ids, pos, extra, out,
-                     out_dtype == EVK_F32, (long)rows, D, L, scale);
+                     out_dtype == EVK_F32, (long)rows, D, L, scale, (long long)table_rows);
   return evk_check_launch("embedding_fwd");
 }
 
 int evk_embedding_bwd(const void* dout, int d_dtype, const int64_t* ids, float* dtable, int64_t rows, int32_t D, float scale,
-                      int64_t padding_idx, evk_stream_t stream) {
+                      int64_t padding_idx, int64_t table_rows, evk_stream_t stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  EVK_REQUIRE(dout && ids && dtable && rows > 0 && D > 0, "embedding_bwd: bad args");
+  EVK_REQUIRE(dout && ids && dtable && rows > 0 && D > 0 && table_rows > 0, "embedding_bwd: bad args");
   ProfScope ps(EVK_FAM_ELTWISE, s);
   hipLaunchKernelGGL(embedding_bwd_kernel, dim3(ew_blocks(rows * D)), dim3(256), 0, s, dout, d_dtype == EVK_F32, (const long long*)ids,
-                     dtable, (long)rows, D, scale, (long long)padding_idx);
+                     dtable, (long)rows, D, scale, (long long)padding_idx, (long long)table_rows);
   return evk_check_launch("embedding_bwd");
 }
 
@@ -445,6 +575,27 @@ int evk_optim_step_dyn(float* p, float* g, float* m, float* v, float* vmax, void
   return evk_check_launch("optim_step_dyn");
 }
 
+int evk_optim_group_step(float* p, float* g, float* m, float* v, float* vmax, void* shadow, int64_t n, int32_t kind, const float* hp_dev,
+                         const int64_t* offsets_dev, int32_t n_params, int32_t* steps_dev, const unsigned char* touched_dev, float* coef_dev,
+                         const float* scale_state, float inv_world, int32_t zero_grad, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(p && g && m && v && n > 0 && (n & 7) == 0 && hp_dev && offsets_dev && n_params > 0 && steps_dev && touched_dev && coef_dev &&
+                  (kind == 0 || kind == 1) && inv_world > 0.f,
+              "optim_group_step: bad args");
+  EVK_REQUIRE(((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
+                reinterpret_cast<uintptr_t>(vmax) | reinterpret_cast<uintptr_t>(coef_dev)) & 15) == 0 &&
+                  (reinterpret_cast<uintptr_t>(shadow) & 7) == 0,
+              "optim_group_step: flat buffers must be 16-byte aligned");
+  ProfScope ps(EVK_FAM_OPTIM, s);
+  hipLaunchKernelGGL(optim_group_coef_kernel, dim3((unsigned)cdiv(n_params, 256)), dim3(256), 0, s, hp_dev, kind, n_params, steps_dev, touched_dev,
+                     reinterpret_cast<float4*>(coef_dev), scale_state);
+  OptGroup d{p, g, m, v, vmax, (bf16_t*)shadow, (long)n, hp_dev, (const long*)offsets_dev, n_params, reinterpret_cast<const float4*>(coef_dev),
+             scale_state, inv_world, kind, zero_grad};
+  const long chunks = cdiv(n, OPT_CHUNK);
+  hipLaunchKernelGGL(optim_group_kernel, dim3((unsigned)std::min<long>(chunks, 8192)), dim3(256), 0, s, d);
+  return evk_check_launch("optim_group_step");
+}
+
 int evk_optim_bump(int32_t* step_dev, int32_t count, const float* scale_state, evk_stream_t stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   EVK_REQUIRE(step_dev && count > 0, "optim_bump: bad args");
@@ -459,6 +610,18 @@ int evk_grad_nonfinite(const float* g, int64_t n, float* scale_state, evk_stream
   ProfScope ps(EVK_FAM_OPTIM, s);
   hipLaunchKernelGGL(grad_nonfinite_kernel, dim3(ew_blocks(n / 4 + 1)), dim3(256), 0, s, g, (long)n, scale_state);
   return evk_check_launch("grad_nonfinite");
+}
+
+int evk_grads_multi(const void* chunk_table, int32_t n_chunks, int32_t mode, float* scale_state, evk_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  EVK_REQUIRE(chunk_table && n_chunks > 0 && scale_state && mode >= 0 && mode <= 2, "grads_multi: bad args");
+  ProfScope ps(EVK_FAM_OPTIM, s);
+  const GradChunk* tab = (const GradChunk*)chunk_table;
+  const dim3 grid((unsigned)(n_chunks < 4096 ? n_chunks : 4096)), block(256);
+  if (mode == 0) hipLaunchKernelGGL(grads_multi_kernel<0>, grid, block, 0, s, tab, n_chunks, scale_state);
+  else if (mode == 1) hipLaunchKernelGGL(grads_multi_kernel<1>, grid, block, 0, s, tab, n_chunks, scale_state);
+  else hipLaunchKernelGGL(grads_multi_kernel<2>, grid, block, 0, s, tab, n_chunks, scale_state);
+  return evk_check_launch("grads_multi");
 }
 
 int evk_loss_scale_update(float* scale_state, float growth, float backoff, int32_t interval, float min_scale, float max_scale,

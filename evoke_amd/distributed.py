@@ -94,19 +94,40 @@ def gather_rows(x, patient_ids):
     return _AllGatherRows.apply(x, counts), ids
 
 
+def batch_structure(kind, patient_ids):
+    """Key of everything that decides WHICH parameters receive gradients in a step (the reducer learns per-parameter gradient
+    counts per key): the step kind (indication / no indication / pretrain) and whether any anchor has a sibling view -- a batch
+    without siblings never runs the multi-view attention and layer_norm_2 (models/...v0623_large_res.py:137-139)."""
+    pid = np.asarray(patient_ids)
+    return (kind, len(np.unique(pid)) != len(pid))
+
+
 class GradReducer:
-    """Bucketed asynchronous all-reduce over flat gradient buffers.
+    """Bucketed asynchronous gradient sum over flat gradient buffers, launched from the backward pass.
 
     flat_grads: list of 1-D f32 tensors; params: list (same length) of [(param, offset, numel), ...] describing which
     slice of the flat buffer each parameter's gradient lives in (forward order).
 
-    A parameter may receive several partial gradients in one backward (the relational-memory weights are used once per
-    token) and some receive none (statically unused branches), so "bucket complete" is decided from the per-parameter
-    callback counts LEARNED during the first step of each step kind (`begin(key)`, e.g. 'inc' / 'no_inc'); the first
-    step of a kind reduces everything at `finish()` without overlap."""
+    ORDER: every rank issues exactly one collective sequence per bucket per step, in DESCENDING bucket index (the order the
+    backward completes them in, as torch's DDP does): bucket b is launched only after bucket b+1, however early its own gradients
+    arrive.  Ranks therefore never disagree on the order of collectives, whatever their batches look like (a rank whose batch has
+    no sibling views skips the multi-view attention; that bucket then simply goes out at finish()).
+    COMPLETENESS: a parameter may receive several partial gradients in one backward and some receive none (statically unused
+    branches), so "bucket complete" is decided from per-parameter callback counts LEARNED during the first step of each batch
+    structure (`begin(key)`; batch_structure()); the first step of a structure reduces everything at finish() without overlap.  A
+    gradient that arrives for a bucket that has already gone out is an error, not a silent corruption.
+    MODE (EVK_GRAD_SYNC): 'allreduce' = one all_reduce (SUM) per bucket on f32; 'direct' = reduce-scatter + all-gather written as
+    all_to_all_single (every rank sends chunk j straight to rank j: on MI355X's xGMI mesh that is one transfer per point-to-point
+    link, all seven links at once, instead of a ring that is bound by one link), a local sum of the received chunks, and
+    all_gather_into_tensor; '16bit' = the bucket is cast to the library's 16-bit storage format, all-reduced in that format (half
+    the bytes on the links) and cast back -- an overflow of the scaled fp16 gradients becomes inf, which the optimizer's overflow
+    scan turns into a skipped step on every rank."""
 
-    def __init__(self, flat_grads, params, bucket_bytes=128 << 20, overlap=True):
+    def __init__(self, flat_grads, params, bucket_bytes=128 << 20, overlap=True, mode=None):
         self.flat, self.overlap = flat_grads, overlap
+        self.mode = mode or os.environ.get('EVK_GRAD_SYNC', 'allreduce')
+        if self.mode not in ('allreduce', 'direct', '16bit'):
+            raise ValueError('EVK_GRAD_SYNC must be allreduce, direct or 16bit')
         self.buckets = []          # (flat_index, start, end)
         self.bucket_of = {}        # id(param) -> bucket index
         elems = max(1, bucket_bytes // 4)
@@ -124,6 +145,7 @@ class GradReducer:
                     cur_start, cur_ps = end, []
         self.learned = {}
         self.handles = []
+        self.issued = []           # bucket indices in the order their collectives were issued this step (tests read it)
         self.begin('default')
         ops.register_grad_callback(self.on_grad)
 
@@ -138,53 +160,103 @@ class GradReducer:
     def begin(self, key='default'):
         self.key = key
         self.counts = {}
-        self.launched = [False] * len(self.buckets)
+        n = len(self.buckets)
+        self.launched = [False] * n
+        self.streams = [set() for _ in range(n)]      # HIP streams that produced gradients of the bucket
+        self.next = n - 1                             # the only bucket that may go out now
+        self.issued = []
         exp = self.learned.get(key)
         self.learning = exp is None
-        self.pending = [0] * len(self.buckets)
+        self.pending = [0] * n
         if exp is not None:
             for pid, c in exp.items():
                 self.pending[self.bucket_of[pid]] += c
+
+    def _active(self):
+        return world_size() > 1 or (dist.is_initialized() and os.environ.get('EVK_FORCE_DIST', '0') == '1')
+
+    def _collective(self, buf):
+        """the gradient sum of one bucket in the configured mode; returns async handles (possibly none: the blocking steps of a
+        mode run on the communication stream and are ordered by it)"""
+        world = dist.get_world_size()
+        if self.mode == 'direct' and world > 1 and buf.numel() % world == 0 and buf.numel() >= 1024 * world:
+            recv = torch.empty_like(buf)
+            dist.all_to_all_single(recv, buf)                                   # chunk j of every rank -> rank j
+            shard = recv.view(world, -1).sum(0)                                 # this rank's slice of the sum
+            return [dist.all_gather_into_tensor(buf, shard, async_op=True)]
+        if self.mode == '16bit' and buf.numel() > 0:
+            if buf.is_cuda:
+                from . import hip as H
+                low = torch.empty(buf.numel(), dtype=ops.BF16, device=buf.device)
+                H.check(H.lib.evk_cast(H.ptr(buf), H.F32, H.ptr(low), H.BF16, buf.numel(), H.stream()), 'cast')
+                dist.all_reduce(low, op=dist.ReduceOp.SUM)
+                H.check(H.lib.evk_cast(H.ptr(low), H.BF16, H.ptr(buf), H.F32, buf.numel(), H.stream()), 'cast')
+            else:
+                low = buf.to(ops.BF16)
+                dist.all_reduce(low, op=dist.ReduceOp.SUM)
+                buf.copy_(low)
+            return []
+        return [dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)]
 
     def _launch(self, b):
         if self.launched[b]:
             return
         self.launched[b] = True
-        if world_size() == 1 and not (dist.is_initialized() and os.environ.get('EVK_FORCE_DIST', '0') == '1'):
+        self.issued.append(b)
+        if not self._active():
             return
         fi, s, e = self.buckets[b]
         if self.flat[fi].is_cuda:
-            # Gradients are accumulated in place from several streams (main, wgrad, rm, text).  The collective is issued from
-            # a dedicated stream that waits for all of them, so the main stream is NOT held back at every bucket boundary
-            # (RCCL orders itself after the stream that is current at the call); finish() joins the handles.
+            # Gradients are accumulated in place from several streams (main, wgrad, rm, text).  The collective is issued from a
+            # dedicated stream that waits for the streams THIS bucket's gradients came from (not for every side stream: the
+            # weight-gradient stream of an early bucket has nothing to do with the relational memory's), so the main stream is
+            # not held back at a bucket boundary (RCCL orders itself after the stream that is current at the call).
             cur = torch.cuda.current_stream()
             comm = ops.side_stream('comm')
             comm.wait_stream(cur)
-            ops.join_side_streams(into=comm, skip='comm')
+            for st in self.streams[b]:
+                if st != comm and st != cur:
+                    comm.wait_stream(st)
             with torch.cuda.stream(comm):
-                self.handles.append(dist.all_reduce(self.flat[fi][s:e], op=dist.ReduceOp.SUM, async_op=True))
+                self.handles += self._collective(self.flat[fi][s:e])
             return
-        self.handles.append(dist.all_reduce(self.flat[fi][s:e], op=dist.ReduceOp.SUM, async_op=True))
+        self.handles += self._collective(self.flat[fi][s:e])
+
+    def _drain(self):
+        """launch, in descending order, every bucket that is complete and whose successors have all gone out"""
+        while self.next >= 0 and (self.launched[self.next] or self.pending[self.next] == 0):
+            self._launch(self.next)
+            self.next -= 1
 
     def on_grad(self, p):
         b = self.bucket_of.get(id(p))
         if b is None:
             return
+        if self.launched[b] and self._active():
+            raise RuntimeError('GradReducer: a gradient arrived for bucket %d after its collective was issued (structure key %r: '
+                               'the learned gradient counts do not describe this batch)' % (b, self.key))
         self.counts[id(p)] = self.counts.get(id(p), 0) + 1
+        if self.flat[self.buckets[b][0]].is_cuda:
+            self.streams[b].add(torch.cuda.current_stream())
         if not self.learning:
             self.pending[b] -= 1
-            if self.overlap and self.pending[b] == 0:
-                self._launch(b)
+            if self.overlap and self.pending[b] == 0 and b == self.next:
+                self._drain()
 
     def finish(self):
-        """Call after backward(): reduces what was not launched from the backward, waits for everything."""
+        """Call after backward(): reduces what was not launched from the backward (descending order), waits for everything."""
         if self.flat and self.flat[0].is_cuda:
             ops.join_side_streams()
-        for b in range(len(self.buckets)):
+            for st in self.streams:
+                st.clear()              # everything is joined into the current stream now
+        for b in range(len(self.buckets) - 1, -1, -1):
             self._launch(b)
+        self.next = -1
         for h in self.handles:
             h.wait()
         self.handles = []
+        if self.flat and self.flat[0].is_cuda and self._active():
+            torch.cuda.current_stream().wait_stream(ops.side_stream('comm'))
         if self.learning:
             self.learned[self.key] = dict(self.counts)
         self.begin(self.key)

@@ -84,7 +84,7 @@ class StepGraph:
         g = torch.cuda.CUDAGraph(keep_graph=True) if MODE == 'replay' else torch.cuda.CUDAGraph()
         dev = torch.cuda.current_device()
         pool = StepGraph._shared_pool.get(dev)          # step graphs replay one at a time on one stream: one private pool for all
-        if pool is None:
+        if pool is None or os.environ.get('EVK_STEP_GRAPH_SHARED_POOL', '1') == '0':
             pool = StepGraph._shared_pool[dev] = torch.cuda.graph_pool_handle()
         try:
             with torch.cuda.graph(g, pool=pool, capture_error_mode='relaxed'):
@@ -96,12 +96,14 @@ class StepGraph:
             warnings.warn('step graph capture failed (%r); running eagerly' % (e,))
             torch.cuda.synchronize()
             return self.fn()
-        self.keep = ops.CAPTURE_KEEPALIVE[keep0:]
+        self.keep = ops.CAPTURE_KEEPALIVE[keep0:]          # pinned staging buffers the graph's upload kernels read: freed with this object
+        del ops.CAPTURE_KEEPALIVE[keep0:]
         if MODE == 'replay':
             plan = H.lib.evk_replay_build(C.c_void_p(g.raw_cuda_graph()), 16)
             if not plan:
                 import warnings
                 self.failed = RuntimeError(H.lib.evk_last_error().decode())
+                self.keep = None
                 warnings.warn('step replay plan failed (%s); running eagerly' % self.failed)
                 return self.fn()
             self.plan = plan

@@ -296,7 +296,11 @@ def multiview_fusion(x, patient_ids, batch_size, sdpa, ln2):
         if len(sib):
             groups.setdefault(len(sib), []).append((i, sib))
     if not groups:
-        return x[:batch_size].contiguous()
+        if x.shape[0] == batch_size:
+            return x
+        # (index_select, not x[:batch_size]: the backward of a leading-rows slice is a device-to-device memcpy into a zero buffer, which a
+        # captured step cannot replay -- ops.pitched_copy)
+        return x.index_select(0, torch.arange(batch_size, device=x.device))
     dev = x.device
     xd = x.detach()
     T, D = x.shape[1], x.shape[2]
@@ -719,6 +723,7 @@ class EncoderDecoder(nn.Module):
         main = torch.cuda.current_stream()
         side = ops.side_stream('rm')
         side.wait_stream(main)
+        input_ids.record_stream(side)          # read by this stream's kernels, forward and backward (see _Base._side_branch)
         with torch.cuda.stream(side):
             emb = self.model.embed(input_ids)
             memory = self.model.rm(emb)

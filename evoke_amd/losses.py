@@ -44,13 +44,13 @@ def _split(x):
 
 
 def _pad_last(x, mult):
+    """zero-pad the last dimension to a multiple of `mult`.  Built with cat (a kernel): a slice assignment into the padded buffer is
+    a copy between row-pitched views, which torch issues as a memcpy -- a node the step replayer cannot re-issue (ops.pitched_copy)."""
     n = x.shape[-1]
     p = (n + mult - 1) // mult * mult
     if p == n:
         return x.contiguous()
-    out = x.new_zeros(*x.shape[:-1], p)
-    out[..., :n] = x
-    return out
+    return torch.cat([x, x.new_zeros(*x.shape[:-1], p - n)], dim=-1)
 
 
 def _mm_nt(a, b):
@@ -75,9 +75,7 @@ def _mm_nn(a, b):
     Sp = ah.shape[2]
     bp = _pad_last(b, 8)
     if Sp != S:
-        t = bp.new_zeros(G, Sp, bp.shape[2])
-        t[:, :S] = bp
-        bp = t
+        bp = torch.cat([bp, bp.new_zeros(G, Sp - S, bp.shape[2])], dim=1)          # (cat, not slice assignment: see _pad_last)
     bh, bl = _split(bp)
     A = torch.cat([ah, ah, al], dim=2).contiguous()
     Bm = torch.cat([bh, bl, bh], dim=1).contiguous()
@@ -137,13 +135,13 @@ def matmul_nt(a, b):
     """a (.., M, K) @ b (.., N, K)^T in ~f32 accuracy on the bf16 MFMA kernel."""
     two = a.dim() == 2
     out = _MatmulNT.apply(a.unsqueeze(0) if two else a, b.unsqueeze(0) if two else b)
-    return out[0] if two else out
+    return out.squeeze(0) if two else out          # (squeeze is a view both ways; out[0] back-propagates through a zero-fill + memcpy)
 
 
 def matmul_nn(a, b):
     two = a.dim() == 2
     out = _MatmulNN.apply(a.unsqueeze(0) if two else a, b.unsqueeze(0) if two else b)
-    return out[0] if two else out
+    return out.squeeze(0) if two else out
 
 
 # ----------------------------------------------------------------------------------------------------

@@ -37,13 +37,18 @@ class _Base(nn.Module):
         return fc_feats, att_feats
 
     @staticmethod
-    def _side_branch(name, fn):
-        """Run fn() on a side HIP stream (after everything queued so far); returns (result, stream or None)."""
+    def _side_branch(name, fn, uses=()):
+        """Run fn() on a side HIP stream (after everything queued so far); returns (result, stream or None).  `uses`: the input tensors
+        of the branch -- the caching allocator must know that the side stream reads them (forward AND backward, which autograd replays on
+        this stream), or a block freed during the backward can be handed out again while the branch's last kernels still read it."""
         if not ops.SIDE_STREAMS_ENABLED[0]:
             return fn(), None
         main = torch.cuda.current_stream()
         side = ops.side_stream(name)
         side.wait_stream(main)
+        for t in uses:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(side)
         with torch.cuda.stream(side):
             out = fn()
         return out, side
@@ -124,7 +129,7 @@ class FineTune(_Base):
             # the loaders hand the indication tokens over on the CPU (trainer_v0401.py:430): pinned ring + copy stream, never a
             # pageable copy on the compute stream (that one blocks the host until the stream has drained)
             inc_ids, inc_masks = _to_device_async(inc_ids, device), _to_device_async(inc_masks, device)
-            y, side = self._side_branch('text', lambda: self.text_head(self.text_encoder(input_ids=inc_ids, attention_mask=inc_masks)))
+            y, side = self._side_branch('text', lambda: self.text_head(self.text_encoder(input_ids=inc_ids, attention_mask=inc_masks)), uses=(inc_ids, inc_masks))
         _, x = self._image_tokens(images, patient_ids, batch_size)
         enc_mask = torch.ones(x.shape[:2], dtype=torch.long, device=device)
         enc_mask.evk_all_ones = True          # host-side knowledge of the mask content (no .all() readback downstream)
@@ -165,7 +170,7 @@ class FineTune(_Base):
         x, enc_mask = self.encoder_states(images, patient_ids, report_ids.shape[0], inc_ids, inc_masks)
         ret = self.text_decoder_forward(report_ids, report_masks, x, enc_mask, mode=mode, **kw)
         if mode == 'train':
-            ret = ops.scale_loss(ret)
+            ret = ops.scale_loss(ret, self)
             return {'lm': ret, 'all_loss': ret}
         return [ret[0], ret[1]]
 
@@ -189,7 +194,7 @@ class Pretrain(_Base):
 
     def obtain_text_embeds(self, input_ids, attention_mask):
         t = self.text_head(self.text_encoder(input_ids=input_ids, attention_mask=attention_mask))
-        return t[:, 0, :], t[:, 1:, :]
+        return ops.split_first_token(t)
 
     def multi_pos_contra_images_v0401(self, global_image_embed, patient_ids):
         return losses.multi_pos_contra_images(global_image_embed, patient_ids, self.args['region_temp'], self.gather)
@@ -204,12 +209,12 @@ class Pretrain(_Base):
         device = images.device
         b = radgraph_ids.shape[0]
         rid, rmask = radgraph_ids.to(device), radgraph_masks.to(device)
-        (t_fc, t_att), side = self._side_branch('text', lambda: self.obtain_text_embeds(rid, rmask))
+        (t_fc, t_att), side = self._side_branch('text', lambda: self.obtain_text_embeds(rid, rmask), uses=(rid, rmask))
         fc, tok = self._image_tokens(images, patient_ids, b)
         mul_pos_loss = torch.tensor([0.0])
         if self.args['is_multiview_learning']:
             mul_pos_loss = self.multi_pos_contra_images_v0401(fc, patient_ids)
-        v_fc, v_att = tok[:, 0, :], tok[:, 1:, :]
+        v_fc, v_att = ops.split_first_token(tok)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
             t_fc.record_stream(torch.cuda.current_stream())
@@ -220,4 +225,4 @@ class Pretrain(_Base):
         if self.args['is_multiview_learning']:
             all_loss = all_loss + mul_pos_loss
         return {'sen_image_loss': torch.tensor([0.0]), 'sen_text_loss': sen_text_loss, 'instance_loss': instance_loss,
-                'multiview_loss': mul_pos_loss, 'all_loss': ops.scale_loss(all_loss)}
+                'multiview_loss': mul_pos_loss, 'all_loss': ops.scale_loss(all_loss, self)}

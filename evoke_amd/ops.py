@@ -79,21 +79,91 @@ def loss_scale_value(device=None):
 
 class _ScaleGrad(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, scale):
+    def forward(ctx, x, scale, owner):
         ctx.save_for_backward(scale)
+        ctx.owner = owner
         return x.view_as(x)
 
     @staticmethod
     def backward(ctx, g):
         scale, = ctx.saved_tensors
-        return g * scale, None
+        owner = ctx.owner() if ctx.owner is not None else None
+        if owner is not None:
+            _unowned_backward_begin(owner, g.device)
+        return g * scale, None, None
 
 
-def scale_loss(loss):
+def scale_loss(loss, owner=None):
+    """`loss` with a backward that multiplies the gradient seed by the current loss scale.  owner = the model (nn.Module) the loss
+    belongs to: parameters of it that no FusedOptimizer has re-homed get their gradients UNSCALED when the backward pass ends, so the
+    reference's own step (trainer_v0401.py:432-435: backward -> clip_grad_value_ -> torch.optim step) sees true gradients."""
     if not (torch.is_tensor(loss) and loss.requires_grad and loss.is_cuda):
         return loss
     sc = loss_scaler(loss.device)
-    return _ScaleGrad.apply(loss, sc.state[0]) if sc is not None else loss
+    if sc is None:
+        return loss
+    import weakref
+    return _ScaleGrad.apply(loss, sc.state[0], weakref.ref(owner) if owner is not None else None)
+
+
+def grads_owned(p):
+    """True when a live FusedOptimizer holds p's gradient in its flat buffers (it divides the loss scale out itself)."""
+    ref = getattr(p, '_evk_optimizer', None)
+    return ref is not None and ref() is not None
+
+
+_chunk_tables = {}
+GRAD_CHUNK = 1 << 16
+
+
+def _chunk_table(grads):
+    """device table of {pointer, element count} pieces for evk_grads_multi, cached on the buffers' addresses"""
+    import numpy as np
+    key = tuple((g.data_ptr(), g.numel()) for g in grads)
+    ent = _chunk_tables.get(key)
+    if ent is None:
+        rows = []
+        for ptr_, n in key:
+            for o in range(0, n, GRAD_CHUNK):
+                rows.append((ptr_ + 4 * o, min(GRAD_CHUNK, n - o)))
+        tab = np.zeros(len(rows), dtype=np.dtype([('p', np.uint64), ('n', np.int32), ('pad', np.int32)]))
+        tab['p'] = [r[0] for r in rows]
+        tab['n'] = [r[1] for r in rows]
+        dev = torch.from_numpy(tab.view(np.uint8).copy()).to(grads[0].device)
+        if len(_chunk_tables) >= 8:
+            _chunk_tables.pop(next(iter(_chunk_tables)))
+        ent = _chunk_tables[key] = (dev, len(rows))
+    return ent
+
+
+def _grads_multi(grads, mode, scaler):
+    for g in grads:
+        if g.dtype != torch.float32 or not g.is_cuda or not (g.is_contiguous() or g.is_contiguous(memory_format=torch.channels_last)):
+            raise RuntimeError('evoke_amd: parameter gradients are dense f32 device tensors; got %s %s' % (g.dtype, tuple(g.stride())))
+    tab, n = _chunk_table(grads)
+    H.check(H.lib.evk_grads_multi(H.ptr(tab), n, mode, H.ptr(scaler.state), H.stream()), 'grads_multi')
+
+
+def _unowned_backward_begin(owner, device):
+    """Called when the backward pass of a scaled loss starts (from the root node).  Parameters whose gradients no FusedOptimizer owns:
+    gradients already present (accumulation over several backward calls) go back under the scale, and an engine callback unscales
+    everything -- after an inf / NaN scan whose verdict zeroes all of them and backs the scale off -- when the pass has finished."""
+    params = [p for p in owner.parameters() if p.requires_grad and not grads_owned(p)]
+    if not params:
+        return
+    scaler = loss_scaler(device)
+    old = [p.grad for p in params if p.grad is not None and p.grad.is_cuda]
+    if old:
+        _grads_multi(old, 2, scaler)
+
+    def finish():
+        join_side_streams()
+        grads = [p.grad for p in params if p.grad is not None and p.grad.is_cuda]
+        if grads:
+            _grads_multi(grads, 0, scaler)
+            _grads_multi(grads, 1, scaler)
+        scaler.update()
+    torch.autograd.Variable._execution_engine.queue_callback(finish)
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -144,6 +214,31 @@ def pitched_copy(x):
     replayer (csrc/replay.hip) refuses the plan.  An elementwise kernel does the same copy and keeps the step replayable; autograd sees
     a multiplication by one."""
     return x if x.is_contiguous() else torch.mul(x, 1)
+
+
+class _SplitFirst(torch.autograd.Function):
+    """(x[:, 0, :], x[:, 1:, :]) as two contiguous tensors.  The plain slices are views whose backward writes each gradient into a
+    zero tensor through a slice copy (memcpy nodes in a captured step, see pitched_copy); here the forward is two elementwise copies
+    and the backward ONE concatenation."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = x.shape
+        return torch.mul(x[:, 0, :], 1), torch.mul(x[:, 1:, :], 1)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        B, T, D = ctx.shape
+        if ga is None:
+            ga = gb.new_zeros(B, D)
+        if gb is None:
+            gb = ga.new_zeros(B, T - 1, D)
+        return torch.cat([ga.unsqueeze(1), gb], 1)
+
+
+def split_first_token(x):
+    """x (B, T, D) -> global token (B, D), local tokens (B, T-1, D) (...v0623_large_res.py:260, 387-388)"""
+    return _SplitFirst.apply(x)
 
 
 def set_shadow_fresh(p, sh):
@@ -827,7 +922,7 @@ class _Embedding(torch.autograd.Function):
         D = table.shape[1]
         out = _e(*ids.shape, D, device=table.device)
         H.check(H.lib.evk_embedding_fwd(H.ptr(table), H.ptr(ids), H.ptr(pos), H.ptr(extra), H.ptr(out), H.BF16, rows, D, L,
-                                        C.c_float(scale), H.stream()), 'embedding_fwd')
+                                        C.c_float(scale), table.shape[0], H.stream()), 'embedding_fwd')
         ctx.save_for_backward(ids)
         ctx.table, ctx.pos, ctx.extra, ctx.scale, ctx.padding_idx = table, pos, extra, scale, padding_idx
         return out
@@ -842,18 +937,18 @@ class _Embedding(torch.autograd.Function):
         st = H.stream()
         if table.requires_grad:
             H.check(H.lib.evk_embedding_bwd(H.ptr(dout), H.dt(dout), H.ptr(ids), H.ptr(grad_buffer(table)), rows, D,
-                                            C.c_float(ctx.scale), ctx.padding_idx, st), 'embedding_bwd')
+                                            C.c_float(ctx.scale), ctx.padding_idx, table.shape[0], st), 'embedding_bwd')
             grad_done(table)
         if pos is not None and pos.requires_grad:
             pid = torch.arange(L, device=ids.device).repeat(rows // L)
             H.check(H.lib.evk_embedding_bwd(H.ptr(dout), H.dt(dout), H.ptr(pid), H.ptr(grad_buffer(pos)), rows, D,
-                                            C.c_float(1.0), -1, st), 'embedding_bwd')
+                                            C.c_float(1.0), -1, pos.shape[0], st), 'embedding_bwd')
             grad_done(pos)
         if extra is not None and extra.requires_grad:
             zid = torch.zeros(rows, dtype=torch.long, device=ids.device)
             # `extra` is row 0 of a (types, D) table: accumulate into that row
             H.check(H.lib.evk_embedding_bwd(H.ptr(dout), H.dt(dout), H.ptr(zid), H.ptr(grad_buffer(extra)), rows, D,
-                                            C.c_float(1.0), -1, st), 'embedding_bwd')
+                                            C.c_float(1.0), -1, extra.shape[0], st), 'embedding_bwd')
             grad_done(extra)
         return None, None, None, None, None, None
 

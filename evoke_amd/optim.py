@@ -52,13 +52,14 @@ class FusedOptimizer(torch.optim.Optimizer):
         self._touched = set()
         # Per-parameter step counts live ON THE DEVICE (st['steps'], int32 per parameter): a step that the dynamic loss scaler
         # skips (non-finite gradient anywhere) must not advance them and the host never reads the skip decision back.
-        # `_hist[id(p)]` is a host-side signature of the SET of optimizer steps the parameter took part in: parameters with
-        # equal signatures have equal device step counts and may share one fused launch.
-        self._hist = {}
         self.world = 1              # ranks whose gradients the all-reduce SUMS into the flat buffers (set by GradReducer)
-        self._last_touched = []
         self._step_zeroes = False       # True once a step() with in-kernel gradient zeroing has run (CUDA, world == 1)
         ops.register_grad_callback(self._on_grad)
+        import weakref
+        me = weakref.ref(self)
+        for g in self.param_groups:
+            for p in g['params']:
+                p._evk_optimizer = me          # ops.grads_owned: this optimizer divides the loss scale out of p.grad itself
         for g in self.param_groups:
             ps = g['params']
             dev = ps[0].device
@@ -80,7 +81,9 @@ class FusedOptimizer(torch.optim.Optimizer):
                 p.data = v
                 p.grad = _view_like(fg[o:o + n], p)
             st = dict(p=fp, g=fg, m=torch.zeros_like(fp), v=torch.zeros_like(fp), vmax=torch.zeros_like(fp) if self.amsgrad else None,
-                      shadow=sh, offsets=offs, steps=torch.zeros(len(ps), dtype=torch.int32, device=dev))
+                      shadow=sh, offsets=offs, steps=torch.zeros(len(ps), dtype=torch.int32, device=dev),
+                      offs_dev=torch.tensor(offs, dtype=torch.int64, device=dev), coef=torch.zeros(4 * len(ps), dtype=torch.float32, device=dev),
+                      hp=torch.zeros(8, dtype=torch.float32, device=dev), hp_host=None, masks={})
             self.flat.append(st)
             if sh is not None:
                 H.check(H.lib.evk_cast(H.ptr(fp), H.F32, H.ptr(sh), H.BF16, tot, H.stream()), 'cast')
@@ -118,7 +121,6 @@ class FusedOptimizer(torch.optim.Optimizer):
     def load_state_dict(self, sd):
         if len(sd['param_groups']) != len(self.param_groups):
             raise ValueError('loaded state dict has a different number of parameter groups')
-        self._hist = {}
         for g, st, lg in zip(self.param_groups, self.flat, sd['param_groups']):
             counts = [0] * len(g['params'])
             if len(lg['params']) != len(g['params']):
@@ -139,7 +141,6 @@ class FusedOptimizer(torch.optim.Optimizer):
                         view.zero_()
                 if ent is not None:
                     counts[pi] = int(float(ent['step']))
-                    self._hist[id(p)] = ('loaded', counts[pi])
             st['steps'].copy_(torch.tensor(counts, dtype=torch.int32))
 
     def flat_grads(self):
@@ -154,65 +155,78 @@ class FusedOptimizer(torch.optim.Optimizer):
                 st['g'].zero_()
             self._touched.clear()
 
+    def _hp_tuple(self, g):
+        b1, b2 = g['betas']
+        return (float(g['lr']), float(b1), float(b2), float(g['eps']), float(g['weight_decay']), float(self.clip_value or 0.0), 0.0, 0.0)
+
+    def sync_hparams(self):
+        """Per-group hyper-parameters live in a small device buffer the update kernel reads (lr schedulers, load_state_dict and plain
+        `group['lr'] = x` change the HOST dict): upload what changed.  Called by step() and, for a captured step, before every replay
+        (a capture cannot upload, it only records the pointer)."""
+        for g, st in zip(self.param_groups, self.flat):
+            hp = self._hp_tuple(g)
+            if st.get('hp_host') != hp:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError('FusedOptimizer: hyper-parameters changed inside a stream capture; call sync_hparams() before capturing')
+                import numpy as np
+                st['hp'].copy_(ops.upload(np.asarray(hp, dtype=np.float32), st['hp'].device))
+                st['hp_host'] = hp
+
+    def _touched_mask(self, g, st):
+        """device uint8 mask of the group's parameters that received a gradient this step (cached per distinct set: a step kind
+        always touches the same parameters)"""
+        bits = bytes(1 if id(p) in self._touched else 0 for p in g['params'])
+        if not any(bits):
+            return None
+        m = st['masks'].get(bits)
+        if m is None:
+            import numpy as np
+            m = ops.upload(np.frombuffer(bits, dtype=np.uint8).copy(), st['p'].device).clone()
+            if not torch.cuda.is_current_stream_capturing():      # a tensor born inside a capture belongs to the graph's pool
+                st['masks'][bits] = m
+        return m
+
     @torch.no_grad()
     def step(self, closure=None):
         """torch.optim semantics: parameters that received no gradient this step are skipped (no weight decay, no
-        step-count increment) -- e.g. the BERT pooler always, visual_self_atten_layers on indication batches.  Runs of
-        consecutive updated parameters with the same step history share one fused launch.  fp16 storage: the gradients carry
-        the loss scale; a non-finite gradient anywhere (after the all-reduce, so every rank sees it) skips the whole step."""
+        step-count increment) -- e.g. the BERT pooler always, visual_self_atten_layers on indication batches -- and every parameter
+        is updated with ITS OWN step count (bias corrections / RAdam rectification per parameter, evaluated on the device).  One
+        launch pair per group.  fp16 storage: the gradients carry the loss scale; a non-finite gradient anywhere (after the
+        all-reduce, so every rank sees it) skips the whole step."""
         self.steps += 1
         ops.WEIGHT_EPOCH[0] += 1
         on_gpu = bool(self.flat) and self.flat[0]['p'].is_cuda
-        if on_gpu:
-            ops.join_side_streams()
-        scaler = ops.loss_scaler(self.flat[0]['p'].device) if on_gpu else None
+        if not on_gpu:
+            raise RuntimeError('FusedOptimizer.step: the update runs in libevoke_hip.so; parameters must live on the GPU')
+        ops.join_side_streams()
+        scaler = ops.loss_scaler(self.flat[0]['p'].device)
         sstate = H.ptr(scaler.state) if scaler is not None else None
         if scaler is not None:
             for st in self.flat:
                 scaler.check(st['g'])
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_hparams()
         inv_world = 1.0 / float(self.world)
         for g, st in zip(self.param_groups, self.flat):
-            b1, b2 = g['betas']
-            ps, offs = g['params'], st['offsets']
-            total = st['p'].numel()
-            runs, cur = [], None
-            for i, p in enumerate(ps):
-                if id(p) not in self._touched:
-                    cur = None
-                    continue
-                h = self._hist[id(p)] = hash((self._hist.get(id(p), 0), self.steps))
-                end = offs[i + 1] if i + 1 < len(ps) else total
-                if cur is not None and cur[2] == h and cur[1] == offs[i]:
-                    cur[1] = end
-                    cur[4] += 1
-                else:
-                    cur = [offs[i], end, h, i, 1]
-                    runs.append(cur)
-            for a, b, _, i0, cnt in runs:
-                es, eb = 4 * a, 2 * a
-                step_ptr = st['steps'].data_ptr() + 4 * i0
-                H.check(H.lib.evk_optim_step_dyn(st['p'].data_ptr() + es, st['g'].data_ptr() + es, st['m'].data_ptr() + es,
-                                                 st['v'].data_ptr() + es, (st['vmax'].data_ptr() + es) if st['vmax'] is not None else None,
-                                                 (st['shadow'].data_ptr() + eb) if st['shadow'] is not None else None, b - a, self.kind,
-                                                 float(g['lr']), b1, b2, g['eps'], g['weight_decay'], float(self.clip_value or 0.0), step_ptr,
-                                                 sstate, inv_world, int(self.world == 1), H.stream()), 'optim_step')
-                H.check(H.lib.evk_optim_bump(step_ptr, cnt, sstate, H.stream()), 'optim_bump')
+            mask = self._touched_mask(g, st)
+            if mask is None:
+                continue
+            H.check(H.lib.evk_optim_group_step(H.ptr(st['p']), H.ptr(st['g']), H.ptr(st['m']), H.ptr(st['v']), H.ptr(st['vmax']), H.ptr(st['shadow']),
+                                               st['p'].numel(), self.kind, H.ptr(st['hp']), H.ptr(st['offs_dev']), len(g['params']),
+                                               H.ptr(st['steps']), H.ptr(mask), H.ptr(st['coef']), sstate, inv_world, int(self.world == 1),
+                                               H.stream()), 'optim_group_step')
         if scaler is not None:
             scaler.update()
-        self._last_touched = [p for g in self.param_groups for p in g['params'] if id(p) in self._touched]
-        self._step_zeroes = on_gpu and self.world == 1
+        self._step_zeroes = self.world == 1
         self._touched.clear()
 
     def replay_hook(self):
         """Host bookkeeping of a step that was just captured in a HIP graph (evoke_amd/graph.py): the returned function is called
-        after every replay and folds the replayed step into the step-history signatures of the parameters it updated (their
-        device step counts advanced inside the graph), so that later eager steps still merge only parameters with equal counts."""
-        touched = list(self._last_touched)
-
+        after every replay.  The optimizer kernel rewrote the parameters through raw pointers, so everything keyed on the weights'
+        epoch (inference-time caches of derived weights, ops.WEIGHT_EPOCH) must see a new epoch, exactly as after an eager step()."""
         def hook():
             self.steps += 1
-            for p in touched:
-                self._hist[id(p)] = hash((self._hist.get(id(p), 0), self.steps))
+            ops.WEIGHT_EPOCH[0] += 1
         return hook
 
 

@@ -106,7 +106,7 @@ class Trainer:
                 ops.advance_seed_epoch()
                 opt.zero_grad()
                 if red is not None:
-                    red.begin(kind)
+                    red.begin(D.batch_structure(kind, pids))
                 if task == 'finetune':
                     ret = model(static[0], static[1], static[2], pids, *static[3:5], mode='train')
                 else:
@@ -123,6 +123,8 @@ class Trainer:
         static, sg = ent
         for dst, src in zip(static, tens):
             dst.copy_(src, non_blocking=True)
+        if hasattr(self.optimizer, 'sync_hparams'):
+            self.optimizer.sync_hparams()           # lr scheduler / load_state_dict since the capture: the kernels read a device buffer
         return sg()
 
     def train_step(self, batch, kind=None):
@@ -141,7 +143,7 @@ class Trainer:
         if self.task == 'finetune':
             has_inc = len(batch) >= 6
             if self.reducer is not None:
-                self.reducer.begin(kind or ('inc' if has_inc else 'no_inc'))
+                self.reducer.begin(D.batch_structure(kind or ('inc' if has_inc else 'no_inc'), batch[3]))
             ids, masks = batch[1].to(dev), batch[2].to(dev)
             if has_inc:
                 ret = self.model(images, ids, masks, batch[3], batch[4], batch[5], mode='train')
@@ -149,7 +151,7 @@ class Trainer:
                 ret = self.model(images, ids, masks, batch[3], mode='train')
         else:
             if self.reducer is not None:
-                self.reducer.begin(kind or 'pretrain')
+                self.reducer.begin(D.batch_structure(kind or 'pretrain', batch[3]))
             ret = self.model(images, batch[1].to(dev), batch[2].to(dev), batch[3])
         loss = ret['all_loss']
         loss.backward()              # never pre-divided by world: the reducer SUMS, the optimizer kernel applies 1/world

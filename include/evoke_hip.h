@@ -358,9 +358,10 @@ int evk_act_bwd(const void* dy, const void* ref, void* dx, int64_t n, int32_t ac
  * (HF BertSelfOutput / BertOutput: dense -> dropout -> + residual, bert_model.py:359-362,437-440)               */
 int evk_dropout(const void* x, const void* resid, void* y, int64_t n, float p, uint64_t seed, evk_stream_t stream);
 int evk_embedding_fwd(const float* table, const int64_t* ids, const float* pos, const float* extra, void* out, int out_dtype,
-                      int64_t rows, int32_t D, int32_t L, float scale, evk_stream_t stream);
+                      int64_t rows, int32_t D, int32_t L, float scale, int64_t table_rows, evk_stream_t stream);
+/* ids outside [0, table_rows) are skipped in both directions (forward: the table term is 0): never a wild access */
 int evk_embedding_bwd(const void* dout, int d_dtype, const int64_t* ids, float* dtable, int64_t rows, int32_t D, float scale,
-                      int64_t padding_idx, evk_stream_t stream);
+                      int64_t padding_idx, int64_t table_rows, evk_stream_t stream);
 int evk_colsum(const void* x, float* out, int64_t M, int32_t N, int64_t ld, evk_stream_t stream);
 /* fused clip_grad_value_ + optimizer step + bf16 shadow refresh over a flat buffer (trainer_v0401.py:262,434;
  * optimizers.py:17-53).  kind 0 = torch.optim.RAdam, kind 1 = torch.optim.Adam (vmax != NULL -> amsgrad)      */
@@ -412,9 +413,27 @@ int evk_optim_step_dyn(float* p, float* g, float* m, float* v, float* vmax, void
                        float beta1, float beta2, float eps, float weight_decay, float clip, const int32_t* step_dev,
                        const float* scale_state, float inv_world, int32_t zero_grad, evk_stream_t stream);
 int evk_optim_bump(int32_t* step_dev, int32_t count, const float* scale_state, evk_stream_t stream);
+/* One optimizer step of a whole parameter group (modules/optimizers.py:27-46 groups, flat buffers) in two launches, with EVERYTHING
+ * that can change between steps read from device memory, so that a step captured in a HIP graph never bakes it in:
+ *   hp_dev      float[8]: lr, beta1, beta2, eps, weight_decay, clip value (torch lr schedulers / load_state_dict rewrite the buffer);
+ *   offsets_dev int64[n_params]: first element of each parameter in the flat buffers (multiples of 8), ascending;
+ *   steps_dev   int32[n_params]: torch.optim's state['step'] PER PARAMETER -- bias corrections and RAdam's rectification are evaluated
+ *               per parameter, a parameter that sat out some steps (statically unused branch of that step kind) keeps its own count;
+ *   touched_dev uint8[n_params]: 1 = the parameter received a gradient this step (others are left alone: no decay, no count);
+ *   coef_dev    float[4 n_params] scratch.   Overflow verdict / loss scale / world as evk_optim_step_dyn. */
+int evk_optim_group_step(float* p, float* g, float* m, float* v, float* vmax, void* shadow, int64_t n, int32_t kind, const float* hp_dev,
+                         const int64_t* offsets_dev, int32_t n_params, int32_t* steps_dev, const unsigned char* touched_dev, float* coef_dev,
+                         const float* scale_state, float inv_world, int32_t zero_grad, evk_stream_t stream);
 int evk_grad_nonfinite(const float* g, int64_t n, float* scale_state, evk_stream_t stream);
 int evk_loss_scale_update(float* scale_state, float growth, float backoff, int32_t interval, float min_scale, float max_scale,
                           evk_stream_t stream);
+/* Gradients of a model whose parameters NO fused optimizer owns -- the reference's own step, modules/trainer_v0401.py:432-435
+ * `loss.backward(); clip_grad_value_(model.parameters(), 0.1); optimizer.step()` with a torch.optim optimizer (modules/optimizers.py:
+ * 27-46): the gradients must leave backward() UNSCALED.  chunk_table = device array of {float* g; int32 n; int32 pad} (one entry per
+ * <= 65536-element piece of a parameter's f32 gradient tensor, any number of tensors).  mode 0: state[2] = 1 when any element is
+ * inf / NaN;  mode 1: g *= 1 / state[0], or g = 0 everywhere when state[2] is set (an overflowed step surfaces as zero gradients);
+ * mode 2: g *= state[0] (gradients left over from an earlier backward are brought back under the scale before accumulation). */
+int evk_grads_multi(const void* chunk_table, int32_t n_chunks, int32_t mode, float* scale_state, evk_stream_t stream);
 
 /* ---- relational memory runner (rm.hip): RelationalMemory.forward / forward_step, encoder_decoder.py:274-300 ------
  * The host loop over tokens lives in the library (5 GEMM launches + 2 fused kernels per token forward, BPTT backward,

@@ -1,6 +1,6 @@
 """Which Python lines issue device-to-device copies of NON-contiguous tensors in one training step?  (torch turns row-pitched ones into
 hipMemcpy2DAsync, which a stream capture records as a memcpy node the step replayer cannot re-issue -- csrc/replay.hip.)
-usage: python tools/find_strided_copies.py"""
+usage: python tools/find_strided_copies.py [finetune|pretrain] [B views res L Li]"""
 import collections
 import sys
 import traceback
@@ -8,16 +8,18 @@ import torch
 sys.path.insert(0, '.')
 import bench
 from evoke_amd import distributed as D, ops, optim
-from evoke_amd.model_pretrain_finetune import FineTune
+from evoke_amd.model_pretrain_finetune import FineTune, Pretrain
 from tests.helpers import load_tokenizer
 
+TASK = sys.argv[1] if len(sys.argv) > 1 else 'finetune'
+SHAPE = [int(v) for v in sys.argv[2:7]] if len(sys.argv) >= 7 else [32, 2, 384, 100, 30]
 dev = torch.device('cuda', 0)
-args = bench.make_args('finetune')
-model = FineTune(args, load_tokenizer(), 'mimic_cxr').to(dev)
+args = bench.make_args(TASK)
+model = (FineTune if TASK == 'finetune' else Pretrain)(args, load_tokenizer(), 'mimic_cxr').to(dev)
 model.train()
 opt = optim.build_two_stage_optimizer(args, model, clip_value=0.1)
 red = D.GradReducer.for_optimizer(opt)
-batch = bench.synth_batch('finetune', 32, 2, 384, 100, 30, dev, 1000)
+batch = bench.synth_batch(TASK, SHAPE[0], SHAPE[1], SHAPE[2], SHAPE[3], SHAPE[4], dev, 1000)
 seen = collections.Counter()
 
 
@@ -54,8 +56,11 @@ def wrap(name):
 def step():
     ops.advance_seed_epoch()
     opt.zero_grad()
-    red.begin('finetune')
-    loss = model(batch['images'], batch['ids'], batch['masks'], batch['pids'], batch['inc'], batch['inc_masks'], mode='train')['all_loss']
+    red.begin(TASK)
+    if TASK == 'finetune':
+        loss = model(batch['images'], batch['ids'], batch['masks'], batch['pids'], batch['inc'], batch['inc_masks'], mode='train')['all_loss']
+    else:
+        loss = model(batch['images'], batch['ids'], batch['masks'], batch['pids'])['all_loss']
     loss.backward()
     red.finish()
     opt.step()
