@@ -33,7 +33,7 @@ MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md, chip-level para
 
 
 def make_args(task):
-    from tests.helpers import ARGS
+    from evoke_amd.config import ARGS
     a = dict(ARGS)
     a.update(task=task, optim='RAdam', pt_lr=5e-6, ft_lr=5e-5, weight_decay=1e-4, amsgrad=True)
     return a
@@ -122,7 +122,7 @@ def decode_record(model, a, rank, world, dev, with_cpu):
     step (the decoder-step weights once + per hypothesis the self-attention cache up to t, the cross-attention
     K/V of the 144 patches and the 1536-wide memory row, in 16-bit) / measured step time (HIP events around the replays)."""
     from evoke_amd import decode as DEC, hip as H, metrics
-    from tests.helpers import load_tokenizer
+    from evoke_amd.config import load_default_tokenizer as load_tokenizer
     beam, B, L = a.beam, a.decode_batch, 100
     model.eval()
     model.args['beam_size'], model.args['max_seq_len'] = beam, L
@@ -195,7 +195,7 @@ def decode_cpu_baseline(model, a, dev, beam, L):
     reports against the oracle's (evoke_amd/metrics.py)."""
     from evoke_amd import metrics
     from oracle import beam as OB, functional as O
-    from tests.helpers import load_tokenizer
+    from evoke_amd.config import load_default_tokenizer as load_tokenizer
     threads = max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get('EVK_CPU_THREADS', '16'))))
     torch.set_num_threads(threads)
     Bc = 2
@@ -206,19 +206,29 @@ def decode_cpu_baseline(model, a, dev, beam, L):
     # (0.02 ... 0.7 from run to run); the CPU timing does not depend on the weights.
     from evoke_amd.model_pretrain_finetune import FineTune
     from oracle import spec as S
-    from tests.helpers import load_procedural
+    from evoke_amd.config import load_state_by_key as load_procedural
     pm = FineTune(dict(model.args), load_tokenizer(), 'mimic_cxr')
-    load_procedural(pm, S.finetune_spec(V), device=dev)
+    load_procedural(pm, S.procedural_state(S.finetune_spec(V)), device=dev)
     pm.eval()
+    from evoke_amd import decode as DEC
+    picks = []          # the engine's own selection per position: (Bc, beam) flat candidate indices (parent beam * (V+1) + word), engine beam order
+
+    def watch(t, logp, beam_sum):
+        nb = 1 if t == 0 else beam
+        cand = (beam_sum[:, :nb].unsqueeze(-1) + logp.view(Bc, nb, logp.shape[-1])[:, :, :V + 1]).reshape(Bc, -1)
+        picks.append(cand.topk(beam, dim=1).indices.cpu())
+
     with torch.no_grad():
-        hip_seq = pm(b['images'].to(dev), b['ids'].to(dev), b['masks'].to(dev), b['pids'], b['inc'], b['inc_masks'], mode='inference')[1].cpu()
+        xs, ms = pm.encoder_states(b['images'].to(dev), b['pids'], Bc, b['inc'], b['inc_masks'])
+        hip_seq = DEC.beam_search(pm.text_decoder, xs, ms, dict(pm.args, beam_size=beam, max_seq_len=L), step_hook=watch).cpu()
     P = {k: (v.detach().float() if v.is_floating_point() else v.detach()).cpu() for k, v in pm.state_dict().items() if not k.endswith('position_ids')}
     del pm
     cfg = dict(O.DEFAULT_CFG, max_seq_len=L, beam_size=beam)
     t0 = time.time()
     with torch.no_grad():
         x, m = O.finetune_encoder_states(P, b['images'], b['pids'], Bc, b['inc'], b['inc_masks'], cfg, O.Ctx())
-        ref_seq = OB.beam_search(P, x, m, cfg, V - 2, V - 1)
+        trace = []
+        ref_seq = OB.beam_search(P, x, m, cfg, V - 2, V - 1, trace=trace)
     dt = time.time() - t0
     tok = load_tokenizer()
     same_seq, same_tok = metrics.token_agreement(hip_seq.tolist(), ref_seq.tolist())
@@ -238,17 +248,43 @@ def decode_cpu_baseline(model, a, dev, beam, L):
         while k < min(len(hs), len(rs)) and hs[k] == rs[k]:
             k += 1
         pref.append(k)
-    par = dict(identical_sequences=same_seq, token_agreement=same_tok, bleu4_vs_oracle=bl[3], studies=Bc, common_prefix_tokens=pref,
+    # where do the two searches part, and how close was that decision for the REFERENCE arithmetic?  Both searches are replayed as sets of
+    # hypotheses (token tuples); at the first position where the sets differ, the oracle's own scores of the candidates say how far
+    # apart the last candidate it selected and the first one it rejected were (its decision margin) and where the engine's pick ranked
+    V1 = V + 1
+    first_div = []
+    for s_ in range(Bc):
+        eng, ref, rec_ = [()], [()], None
+        for t in range(L):
+            e_new = [eng[int(f) // V1] + (int(f) % V1,) for f in picks[t][s_]]
+            flat = trace[t]['flat'][s_].tolist()
+            r_all = [ref[f // V1] + (f % V1,) for f in flat]
+            r_new = r_all[:beam]
+            if set(e_new) != set(r_new):
+                sc = trace[t]['score'][s_].tolist()
+                rank_of = {h: i for i, h in enumerate(r_all)}
+                odd = [h for h in e_new if h not in set(r_new)]
+                ranks = [rank_of.get(h, -1) for h in odd]
+                gap = max([sc[beam - 1] - sc[r] for r in ranks if r >= 0] or [sc[beam - 1] - sc[-1]])
+                rec_ = dict(position=t, oracle_margin_selected_vs_rejected=round(sc[beam - 1] - sc[beam], 5),
+                            oracle_score_gap_to_engine_pick=round(gap, 5), engine_pick_oracle_rank=ranks)
+                break
+            eng, ref = e_new, r_new
+        first_div.append(rec_)
+    par = dict(first_divergent_decision=first_div, identical_sequences=same_seq, token_agreement=same_tok, bleu4_vs_oracle=bl[3], studies=Bc, common_prefix_tokens=pref,
                oracle_logprob_of_engine_sequences=sc_h, oracle_logprob_of_oracle_sequences=sc_r,
                note='engine (16-bit) vs CPU oracle (fp32) on the same inputs and the procedural weights of the golden fixtures, beam %d, %d positions; '
                     'an untrained network never emits [EOS] and its logit gaps are tiny, so once one near-tie resolves differently the rest of the '
-                    'sequence differs -- common_prefix_tokens says where; the <= 40-position golden cases are token-exact (tests)' % (beam, L))
+                    'sequence differs -- first_divergent_decision gives, per study, the position at which the two searches first select different hypothesis sets, '
+                    'the oracle (fp32) margin between its last selected and first rejected candidate there, and the oracle score gap to what the engine '
+                    'picked instead (None = the searches never part); the <= 40-position golden cases are token-exact and the 100-position golden is '
+                    'followed decision by decision in tests/test_model_gpu.py' % (beam, L))
     return base, par
 
 
 def bench_decode(a, rank, world, dev):
     from evoke_amd.model_pretrain_finetune import FineTune
-    from tests.helpers import load_tokenizer
+    from evoke_amd.config import load_default_tokenizer as load_tokenizer
     torch.manual_seed(9233)
     model = FineTune(make_args('test'), load_tokenizer(), 'mimic_cxr').to(dev).eval()
     rec = decode_record(model, a, rank, world, dev, with_cpu=(world == 1 and not a.no_cpu_baseline))
@@ -289,7 +325,7 @@ def main():
 
     from evoke_amd import hip as H, ops, optim
     from evoke_amd.model_pretrain_finetune import FineTune, Pretrain
-    from tests.helpers import load_tokenizer
+    from evoke_amd.config import load_default_tokenizer as load_tokenizer
     torch.manual_seed(9233)
     ops.manual_seed(9233 + rank)
     if a.workload == 'decode':

@@ -161,9 +161,21 @@ __device__ __forceinline__ void bn_finalize_channel(const FinP& p, int c, float 
 
 // second reduction stage of the gate statistics a data-gradient GEMM epilogue wrote (gemm.hip: gatestats): 8 channels per block
 // rows = 2: (sum g, sum g*z) -> sum_gx through z = gamma*xhat + beta;  rows = 3 (invstd given): (sum g, -, sum g*(x - mean)) -> sum_gx = invstd * row 2
+// Ill-conditioned channels: the identity xhat = (z - beta) / gamma is evaluated on the 16-bit STORED z, whose rounding (2^-11 |z| in
+// fp16) is divided by gamma -- a relative error of ~2^-11 |beta / gamma| in sum g*xhat, i.e. noise for the near-dead channels an
+// ImageNet-pretrained resnet101 has (|gamma| << |beta|).  A block that owns such a channel (|beta| > EVK_GATE_RATIO |gamma|) recomputes
+// sum g*xhat exactly from the gated gradient and the layer's raw convolution output, xhat = (y - mean) * invstd, for its 8 channels:
+// no extra launch, no cost for well-conditioned layers, one strided pass over two tensors for the rare block that needs it.
+#ifdef EVK_STORE_F16
+#define EVK_GATE_RATIO 16.f
+#else
+#define EVK_GATE_RATIO 2.f
+#endif
+struct GateExact { const bf16_t* dz; const bf16_t* y; const float* mean; const float* istd; long M; };
 __global__ __launch_bounds__(256) void bn_bwd_sums_from_gate_kernel(const float* __restrict__ part, int nblk, const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta, float* __restrict__ sum_g, float* __restrict__ sum_gx,
-                                                                    float* dbeta_acc, float* dgamma_acc, int C, int rows, const float* __restrict__ invstd) {
+                                                                    float* dbeta_acc, float* dgamma_acc, int C, int rows, const float* __restrict__ invstd,
+                                                                    const GateExact ex) {
   __shared__ float red[16][17];
   const int j = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int c = blockIdx.x * 8 + (j & 7);
@@ -188,9 +200,45 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_from_gate_kernel(const float*
     for (int q = 0; q < 16; ++q) { sg += red[q][threadIdx.x]; sgz += red[q][threadIdx.x + 8]; }
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
     const float sgx = invstd ? sgz * invstd[c] : (g != 0.f ? (sgz - b * sg) / g : 0.f);
-    sum_g[c] = sg; sum_gx[c] = sgx;
+    const bool ill = !invstd && ex.dz && fabsf(b) > EVK_GATE_RATIO * fabsf(g);
+    sum_g[c] = sg;
     if (dbeta_acc) dbeta_acc[c] += sg;
-    if (dgamma_acc) dgamma_acc[c] += sgx;
+    if (!ill) {
+      sum_gx[c] = sgx;
+      if (dgamma_acc) dgamma_acc[c] += sgx;
+    }
+    red[0][threadIdx.x] = ill ? 1.f : 0.f;          // (everything of red[][] has been consumed by these 8 threads' own columns)
+  }
+  if (invstd || !ex.dz) return;
+  __syncthreads();
+  bool any = false;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) any |= red[0][q] != 0.f;
+  if (!any) return;
+  // exact sums for this block's 8 channels: 256 threads stride over the M rows, 16 bytes of each tensor per row
+  const int c8 = blockIdx.x * 8;
+  float mu[8], is[8], xa[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { mu[q] = ex.mean[c8 + q]; is[q] = ex.istd[c8 + q]; xa[q] = 0.f; }
+  for (long r = threadIdx.x; r < ex.M; r += 256) {
+    float gv[8], yv[8];
+    unpack8(*reinterpret_cast<const uint4*>(ex.dz + r * C + c8), gv);
+    unpack8(*reinterpret_cast<const uint4*>(ex.y + r * C + c8), yv);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) xa[q] += gv[q] * ((yv[q] - mu[q]) * is[q]);
+  }
+  __shared__ float ex_red[4][8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const float w = wave_sum(xa[q]);
+    if ((threadIdx.x & 63) == 0) ex_red[threadIdx.x >> 6][q] = w;
+  }
+  const bool mine = threadIdx.x < 8 && red[0][threadIdx.x] != 0.f;
+  __syncthreads();
+  if (mine) {
+    const float exact = (ex_red[0][threadIdx.x] + ex_red[1][threadIdx.x]) + (ex_red[2][threadIdx.x] + ex_red[3][threadIdx.x]);
+    sum_gx[c8 + threadIdx.x] = exact;
+    if (dgamma_acc) dgamma_acc[c8 + threadIdx.x] += exact;
   }
 }
 
@@ -555,11 +603,15 @@ int evk_bn_finalize(const float* sum, const float* sumsq, const float* gamma, co
 }
 
 int evk_bn_bwd_sums_from_gate_partials(const float* part, int32_t nblk, const float* gamma, const float* beta, float* sum_g, float* sum_gx,
-                                       float* dbeta_acc, float* dgamma_acc, int32_t C, evk_stream_t stream) {
+                                       float* dbeta_acc, float* dgamma_acc, int32_t C, const void* dz, const void* y, const float* mean,
+                                       const float* invstd, int64_t M, evk_stream_t stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   EVK_REQUIRE(part && sum_g && sum_gx && nblk > 0 && C > 0 && C % 8 == 0, "bn_bwd_sums_from_gate_partials: bad args");
+  EVK_REQUIRE(!dz || (y && mean && invstd && M > 0 && ((reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(y)) & 15) == 0),
+              "bn_bwd_sums_from_gate_partials: the exact fallback needs dz, y (16-byte aligned), mean, invstd and M");
   ProfScope ps(EVK_FAM_REDUCE, s);
-  hipLaunchKernelGGL(bn_bwd_sums_from_gate_kernel, dim3(C / 8), dim3(256), 0, s, part, (int)nblk, gamma, beta, sum_g, sum_gx, dbeta_acc, dgamma_acc, (int)C, 2, nullptr);
+  const GateExact ex{(const bf16_t*)dz, (const bf16_t*)y, mean, invstd, (long)M};
+  hipLaunchKernelGGL(bn_bwd_sums_from_gate_kernel, dim3(C / 8), dim3(256), 0, s, part, (int)nblk, gamma, beta, sum_g, sum_gx, dbeta_acc, dgamma_acc, (int)C, 2, nullptr, ex);
   return evk_check_launch("bn_bwd_sums_from_gate_partials");
 }
 
@@ -569,7 +621,7 @@ int evk_bn_bwd_sums_from_xstat_partials(const float* part, int32_t nblk, const f
   EVK_REQUIRE(part && invstd && sum_g && sum_gx && nblk > 0 && C > 0 && C % 8 == 0, "bn_bwd_sums_from_xstat_partials: bad args");
   ProfScope ps(EVK_FAM_REDUCE, s);
   hipLaunchKernelGGL(bn_bwd_sums_from_gate_kernel, dim3(C / 8), dim3(256), 0, s, part, (int)nblk, nullptr, nullptr, sum_g, sum_gx, dbeta_acc, dgamma_acc, (int)C, 3,
-                     invstd);
+                     invstd, GateExact{nullptr, nullptr, nullptr, nullptr, 0});
   return evk_check_launch("bn_bwd_sums_from_xstat_partials");
 }
 

@@ -131,7 +131,8 @@ int bn_backward_from_gate(const Ctx& c, int i, const void* dz, int nblk) {
   float* st = c.at<float>(pr.stats);
   float* sums = c.at<float>(pr.sums);
   const int C = pr.C;
-  TRY(evk_bn_bwd_sums_from_gate_partials(c.at<float>(c.P->part), nblk, l.gamma, l.beta, sums, sums + C, l.dbeta, l.dgamma, C, c.s));
+  TRY(evk_bn_bwd_sums_from_gate_partials(c.at<float>(c.P->part), nblk, l.gamma, l.beta, sums, sums + C, l.dbeta, l.dgamma, C, dz, c.at(pr.y),
+                                         st + 4 * C, st + 5 * C, pr.M, c.s));
   const float* sg = c.training ? sums : c.at<float>(c.P->zeros);
   const float* sgx = c.training ? sums + C : c.at<float>(c.P->zeros);
   return evk_bn_bwd_apply(dz, c.at(pr.z), c.at(pr.y), st + 2 * C, st + 4 * C, st + 5 * C, sg, sgx, c.at(pr.dy), nullptr, pr.M, C, 0, c.s);

@@ -318,9 +318,14 @@ int evk_bn_finalize(const float* sum, const float* sumsq, const float* gamma, co
  * the epilogue of the data-gradient GEMM that produced g gated by z > 0 (evk_conv2d_dgrad_gated_stats), z = relu(gamma*xhat + beta)
  * the layer's own forward output.  Where the gate is open xhat = (z - beta) / gamma, so sum_g = sum g and sum_gx = (sum g*z - beta *
  * sum g) / gamma (0 for gamma == 0, where dx vanishes anyway); dbeta_acc += sum_g, dgamma_acc += sum_gx when given.
+ * That identity divides the rounding of the 16-bit stored z by gamma: channels with |beta| > 16 |gamma| (2 |gamma| in the bf16 build)
+ * -- the near-dead channels of an ImageNet-pretrained resnet101 -- are recomputed exactly inside the same launch from dz (the gated
+ * gradient the producing GEMM wrote, [M][C]) and y (the layer's raw convolution output), xhat = (y - mean) * invstd; pass dz = NULL to
+ * switch the fallback off.
  * Replaces evk_bn_bwd_reduce_acc for bn1 / bn2 of every bottleneck (nn.BatchNorm2d backward, torchvision resnet101). */
 int evk_bn_bwd_sums_from_gate_partials(const float* part, int32_t nblk, const float* gamma, const float* beta, float* sum_g, float* sum_gx,
-                                       float* dbeta_acc, float* dgamma_acc, int32_t C, evk_stream_t stream);
+                                       float* dbeta_acc, float* dgamma_acc, int32_t C, const void* dz, const void* y, const float* mean,
+                                       const float* invstd, int64_t M, evk_stream_t stream);
 /* the same second stage for the [3][C] partial rows of evk_conv2d_dgrad_gated_xstat: sum_g = sum of row 0, sum_gx = invstd * sum of row 2
  * (row 2 already carries x - mean) */
 int evk_bn_bwd_sums_from_xstat_partials(const float* part, int32_t nblk, const float* invstd, float* sum_g, float* sum_gx,

@@ -355,6 +355,40 @@ def run_gpt2():
     return out
 
 
+def run_manifest(tmp, tokenizer):
+    """Key / shape / dtype manifests of the imported reference's FineTune.state_dict(), of the optimizer modules/optimizers.py builds
+    for it after one step (torch.optim.RAdam, two groups), and of the HF GPT2LMHeadModel(add_cross_attention) state_dict as a
+    cvt2distilgpt2 checkpoint stores it (prefix decoder.encoder_decoder.decoder., language_model.py:215-220)."""
+    import gzip
+    from transformers import GPT2Config, GPT2LMHeadModel
+    from models.model_pretrain_finetune_v0623_large_res import FineTune
+    from modules.optimizers import build_two_stage_optimizer
+    from evoke_amd import checkpoint as CK
+    args = make_args(tmp, tokenizer)
+    args.update(task='finetune', optim='RAdam', pt_lr=5e-6, ft_lr=5e-5, weight_decay=1e-4, amsgrad=True)
+    model = FineTune(args, tokenizer, 'iu_xray')
+    opt = build_two_stage_optimizer(args, model)
+    inp = make_inputs(CASES['ft224_nomv'], tokenizer.get_vocab_size())
+    inp2 = make_inputs(CASES['ft224_noinc'], tokenizer.get_vocab_size())
+    for b in (inp, inp2):              # an indication and a no-indication step: every branch receives optimizer state
+        ret = model(b['images'], b['ids'], b['masks'], np.array(b['patient_ids']), b.get('inc_ids'), b.get('inc_masks'), mode='train')
+        ret['all_loss'].backward()
+        opt.step()
+        opt.zero_grad()
+    V = tokenizer.get_vocab_size()
+    cfg = GPT2Config(vocab_size=V, n_embd=GPT2_DIMS['d'], n_layer=GPT2_DIMS['layers'], n_head=GPT2_DIMS['heads'], add_cross_attention=True,
+                     is_decoder=True)
+    gsd = GPT2LMHeadModel(cfg).state_dict()
+    out = {'finetune_state_dict': CK.manifest(model.state_dict()), 'finetune_optimizer': CK.optimizer_manifest(opt.state_dict()),
+           'n_named_parameters': len(list(model.named_parameters())),
+           'cvt2distilgpt2_decoder': [('decoder.encoder_decoder.decoder.' + k, s, d) for k, s, d in CK.manifest(gsd)]}
+    with gzip.open(os.path.join(HERE, 'manifest_finetune.json.gz'), 'wt') as f:
+        json.dump(out, f)
+    print('manifest_finetune.json.gz written: %d state_dict entries, optimizer groups %s, %d optimizer states, %d decoder keys'
+          % (len(out['finetune_state_dict']), [g['n_params'] for g in out['finetune_optimizer']['param_groups']],
+             len(out['finetune_optimizer']['state']), len(out['cvt2distilgpt2_decoder'])))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default='')
@@ -370,6 +404,8 @@ def main():
     if only is None or 'kat' in only:
         json.dump(run_kat(tmp, tokenizer), open(os.path.join(HERE, 'kat.json'), 'w'), indent=1)
         print('kat.json written')
+    if only is None or 'manifest' in only:
+        run_manifest(tmp, tokenizer)
     if only is None or 'gpt2' in only:
         np.savez_compressed(os.path.join(HERE, 'gpt2.npz'), **run_gpt2())
         print('gpt2.npz written')

@@ -14,13 +14,7 @@ NO_F16_GRADS = 'fp16-storage build: this unit-level backward is not loss-scaled 
 GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
 V = 1444
 
-ARGS = dict(
-    resnet_checkpoint='', text_checkpoint=None, fusion_checkpoint=None, vocab_size=V, encoder_hidden_size=768,
-    encoder_num_hidden_layers=6, output_dim=2048, fusion_num_heads=8, sk_fusion_num_layers=1, max_seq_len=100,
-    is_multiview_learning=True, is_add_indication=True, instance_temp=0.5, region_temp=0.5, num_layers=3, d_model=512,
-    d_ff=512, d_vf=2048, num_heads=8, dropout=0.0, drop_prob_lm=0.5, use_bn=0, rm_num_slots=3, rm_num_heads=8,
-    rm_d_model=512, sample_method='beam_search', beam_size=3, temperature=1.0, sample_n=1, group_size=1,
-    output_logsoftmax=1, decoding_constraint=0, block_trigrams=1, length_penalty='', diversity_lambda=0.5, suppress_UNK=0)
+from evoke_amd.config import ARGS  # noqa: E402,F401  (the package owns the default argument dictionary; tests start from it)
 
 
 def load_tokenizer():

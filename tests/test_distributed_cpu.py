@@ -97,3 +97,80 @@ def test_reducer_single_process_is_identity():
     assert torch.equal(flat, torch.arange(10, dtype=torch.float32))
     assert D.gather_rows(torch.ones(2, 3), ['x', 'y'])[0].shape == (2, 3)
     ops.clear_grad_callbacks()
+
+
+def _order_worker(rank, world, port, q, mode):
+    """Two ranks whose batches differ in STRUCTURE: rank 0's studies have sibling views (the multi-view attention parameters receive
+    gradients), rank 1's have none (they receive nothing); gradients also arrive in a different order on the two ranks.  The reducer
+    must issue the same collective sequence on both (descending bucket index), must not hang, and every bucket must hold the sum of
+    the shards."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from evoke_amd import distributed as D, ops
+    D.init_distributed('gloo')
+    try:
+        n = 4096
+        names = ['trunk', 'multiview_attention', 'fusion', 'decoder']
+        ps = [torch.nn.Parameter(torch.zeros(n)) for _ in names]
+        flat = torch.zeros(4 * n)
+        red = D.GradReducer([flat], [[(p, i * n, n) for i, p in enumerate(ps)]], bucket_bytes=4 * n, mode=mode)
+        assert len(red.buckets) == 4
+        out = []
+        for step in range(3):
+            pids = ['a', 'b', 'a'] if rank == 0 else ['c', 'd', 'e']          # rank 1: no study has two views
+            key = D.batch_structure('inc', pids)
+            red.begin(key)
+            flat.zero_()
+            # backward order: decoder, fusion, (multi-view attention only with siblings), trunk -- rank 1 sees fusion before decoder
+            order = [3, 2, 1, 0] if rank == 0 else [2, 3, 0]
+            for i in order:
+                flat[i * n:(i + 1) * n] = float((rank + 1) * (i + 1) * (step + 1))
+                red.on_grad(ps[i])
+            issued_before_finish = list(red.issued)
+            red.finish()
+            want = [sum((r + 1) * (i + 1) * (step + 1) for r in range(world) if not (r == 1 and i == 1)) for i in range(4)]
+            got = [float(flat[i * n]) for i in range(4)]
+            same = all(bool((flat[i * n:(i + 1) * n] == flat[i * n]).all()) for i in range(4))
+            out.append((key, issued_before_finish, got, want, same))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+        ops.clear_grad_callbacks()
+
+
+def _run_order(mode):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_order_worker, args=(r, 2, port, q, mode)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_reducer_fixed_order_with_different_batch_structures_gloo():
+    res = _run_order('allreduce')
+    assert res[0][0][0] == ('inc', True) and res[1][0][0] == ('inc', False)         # the structure keys differ across ranks
+    for rank in (0, 1):
+        for step, (key, early, got, want, same) in enumerate(res[rank]):
+            assert same and got == want, (rank, step, got, want)
+            assert early == sorted(early, reverse=True), early                      # never bucket b before bucket b + 1
+            if step == 0:
+                assert early == []                                                  # first step of a structure: learned, reduced at finish()
+    # once the counts are learned both ranks overlap all four buckets with their backward, in the same order: rank 1 has learned, for
+    # ITS structure, that bucket 1 (multi-view attention) receives nothing and sends its zeros as soon as buckets 3 and 2 have gone out;
+    # its early 'fusion' gradient (bucket 2 before bucket 3) waits for bucket 3
+    assert res[0][2][1] == [3, 2, 1, 0]
+    assert res[1][2][1] == [3, 2, 1, 0]
+
+
+def test_reducer_direct_and_16bit_sync_modes_gloo():
+    for mode in ('direct', '16bit'):
+        res = _run_order(mode)
+        for rank in (0, 1):
+            for step, (key, early, got, want, same) in enumerate(res[rank]):
+                assert same and got == want, (mode, rank, step, got, want)

@@ -440,6 +440,11 @@ def test_conv_fwd_stats_and_dgrad_add():
         close(dx.float(), (xr.grad.permute(0, 2, 3, 1) + skip.float()).cpu(), 2e-2, 2e-2, 'dgrad + skip')
 
 
+def helpers_f16():
+    from tests.helpers import F16_BUILD
+    return F16_BUILD
+
+
 def test_dgrad_gate_statistics_give_the_batchnorm_backward_sums():
     """evk_conv2d_dgrad_gated_stats + evk_bn_bwd_sums_from_gate_partials: the data-gradient GEMM's epilogue accumulates sum(g) and
     sum(g*z) of its ReLU-gated output per channel (z = relu(gamma*xhat + beta), the gate tensor), from which the batch-norm backward
@@ -463,7 +468,7 @@ def test_dgrad_gate_statistics_give_the_batchnorm_backward_sums():
         sums = torch.empty(2, Ci, device='cuda')
         dbeta, dgamma = torch.ones(Ci, device='cuda'), torch.ones(Ci, device='cuda')
         H.check(H.lib.evk_bn_bwd_sums_from_gate_partials(H.ptr(part), nblk.value, H.ptr(gamma), H.ptr(beta), H.ptr(sums[0]), H.ptr(sums[1]),
-                                                         H.ptr(dbeta), H.ptr(dgamma), Ci, H.stream()))
+                                                         H.ptr(dbeta), H.ptr(dgamma), Ci, None, None, None, None, 0, H.stream()))
         xr = torch.zeros(N, Ci, Hh, Hh, device='cuda', requires_grad=True)
         torch.nn.functional.conv2d(xr, w.float().permute(0, 3, 1, 2), stride=stride, padding=k // 2).backward(dy.float().permute(0, 3, 1, 2))
         gref = (xr.grad.permute(0, 2, 3, 1) * (z.float() > 0)).reshape(-1, Ci)
@@ -475,6 +480,58 @@ def test_dgrad_gate_statistics_give_the_batchnorm_backward_sums():
         close(sums[0], want_g, 5e-3, 5e-3 * scale, 'sum g')
         close(sums[1], want_gx, 5e-3, 1e-2 * scale, 'sum g*xhat')
         close(dbeta - 1, want_g, 5e-3, 5e-3 * scale, 'dbeta acc')
+
+
+@pytest.mark.parametrize('tiny', [1e-2, 1e-4, 1e-6])
+def test_gate_statistics_fall_back_to_exact_sums_for_near_dead_channels(tiny):
+    """ImageNet-pretrained resnet101 has batch-norm channels with |gamma| << |beta|.  There xhat = (z - beta) / gamma amplifies the 16-bit
+    rounding of the stored z by |beta / gamma| and the gate-statistic dgamma would be noise; evk_bn_bwd_sums_from_gate_partials recomputes
+    such channels exactly (from the gated gradient and the raw convolution output) inside the same launch.  Channels 0-7 and 40-47 get
+    gamma = `tiny` with beta = 0.5; the rest stay well conditioned.  Against an f32 batch-norm backward; the fallback switched off (dz =
+    NULL) must show the error it removes."""
+    import ctypes as C
+    from evoke_amd import hip as H
+    torch.manual_seed(7)
+    N, Hh, Ci, Co = 2, 24, 64, 128
+    M = N * Hh * Hh
+    g = H.conv_geom(N, Hh, Hh, Ci, Co, 1, 1, 1, 0)
+    w = (torch.randn(Co, 1, 1, Ci, device='cuda') * 0.05).to(BF)
+    dy = (torch.randn(N, Hh, Hh, Co, device='cuda') * 0.3).to(BF)
+    gamma, beta = 0.5 + torch.rand(Ci, device='cuda'), 0.3 * torch.randn(Ci, device='cuda')
+    dead = list(range(0, 8)) + list(range(40, 48))
+    gamma[dead], beta[dead] = tiny, 0.5
+    y = (torch.randn(N, Hh, Hh, Ci, device='cuda') * 1.7 + 0.4).to(BF)          # the layer's raw convolution output
+    yf = y.float().reshape(-1, Ci)
+    mean, var = yf.mean(0), yf.var(0, unbiased=False)
+    invstd = (var + 1e-5).rsqrt()
+    xhat = (yf - mean) * invstd
+    z = torch.relu(gamma * xhat + beta).reshape(N, Hh, Hh, Ci).to(BF)
+    dx = torch.empty(N, Hh, Hh, Ci, device='cuda', dtype=BF)
+    nb = H.lib.evk_conv_stats_bytes(M, Ci)
+    part = torch.empty(nb // 4, device='cuda')
+    nblk = C.c_int32(0)
+    H.check(H.lib.evk_conv2d_dgrad_gated_stats(H.ptr(dy), H.ptr(w), None, H.ptr(z), H.ptr(dx), C.byref(g), H.ptr(part), nb, C.byref(nblk), H.stream()))
+    gated = dx.float().reshape(-1, Ci)                                             # what the fallback reads
+    want = (gated * xhat).sum(0)
+    scale = float((gated.abs() * xhat.abs()).sum(0).max())
+
+    def run(fallback):
+        sums = torch.empty(2, Ci, device='cuda')
+        dgamma = torch.zeros(Ci, device='cuda')
+        args = (H.ptr(dx), H.ptr(y), H.ptr(mean), H.ptr(invstd), M) if fallback else (None, None, None, None, 0)
+        H.check(H.lib.evk_bn_bwd_sums_from_gate_partials(H.ptr(part), nblk.value, H.ptr(gamma), H.ptr(beta), H.ptr(sums[0]), H.ptr(sums[1]), None,
+                                                         H.ptr(dgamma), Ci, *args, H.stream()))
+        assert torch.equal(sums[1], dgamma)
+        return dgamma
+
+    got, raw = run(True), run(False)
+    err = ((got - want).abs() / scale).cpu()
+    err_raw = ((raw - want).abs() / scale).cpu()
+    print('\n[near-dead BN channels, gamma = %g] relative error of dgamma: with the exact fallback %.2e (dead) %.2e (others); without %.2e (dead)'
+          % (tiny, float(err[dead].max()), float(err.max()), float(err_raw[dead].max())))
+    assert float(err[dead].max()) <= 2e-3 and float(err.max()) <= 1e-2
+    if not helpers_f16() or tiny <= 1e-4:
+        assert float(err_raw[dead].max()) > 10 * float(err[dead].max())           # the failure mode the fallback exists for
 
 
 def test_native_trunk_matches_module_walk():

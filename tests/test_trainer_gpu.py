@@ -312,12 +312,14 @@ def test_reference_order_step_with_a_torch_optimizer_follows_the_oracle():
     print('\n[reference-order step] oracle %s\n                       engine %s\n   max |grad| before the clip: oracle %s engine %s (loss scale %g)'
           % (['%.5f' % v for v in want], ['%.5f' % v for v in got], ['%.3f' % v for v in want_gmax], ['%.3f' % v for v in got_gmax],
              ops.loss_scale_value()))
+    from tests.helpers import F16_BUILD
+    loss_tol, step_tol, g_tol = (2e-3, 0.10, 0.15) if F16_BUILD else (6e-2, 0.5, 0.4)      # bf16 storage: its train-mode tolerances (test_model_gpu.py)
     for a, b in zip(got, want):
-        assert abs(a - b) <= 2e-3, (got, want)
+        assert abs(a - b) <= loss_tol, (got, want)
     for i in range(3):
-        assert abs((got[i] - got[i + 1]) - (want[i] - want[i + 1])) <= 0.1 * abs(want[i] - want[i + 1]), (got, want)
+        assert abs((got[i] - got[i + 1]) - (want[i] - want[i + 1])) <= step_tol * abs(want[i] - want[i + 1]), (got, want)
     for a, b in zip(got_gmax, want_gmax):
-        assert abs(a - b) <= 0.15 * b, (got_gmax, want_gmax)
+        assert abs(a - b) <= g_tol * b, (got_gmax, want_gmax)
 
 
 def test_unowned_gradients_overflow_surfaces_as_zero_gradients():
