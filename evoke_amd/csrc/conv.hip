@@ -55,6 +55,38 @@ __global__ void stem_unpack_wgrad_kernel(const float* __restrict__ dwp, float* _
   dw[i] += dwp[((co * 7 + kh) * 8 + kw) * 4 + c];
 }
 
+// Weights of a convolution as its DATA GRADIENT reads them: wt[ci][KH-1-kh][KW-1-kw][co] = w[co][kh][kw][ci].  With them the data gradient
+// of a stride-1 "same" convolution is itself a forward convolution of dy (dx = conv(dy, wt), pad K-1-p), i.e. the K-contiguous
+// A_CONV / B_PLAIN main loop instead of the gather + K-strided one.  One launch transposes every layer of a table: a workgroup moves
+// one 32 x 32 (co, ci) tile of one tap through LDS.
+struct FlipTab { const bf16_t* w[32]; bf16_t* wt[32]; int Co[32], Ci[32], T[32], KW[32], first[33]; int n; };
+__global__ __launch_bounds__(256) void conv_flip_weights_kernel(const FlipTab t) {
+  __shared__ bf16_t tile[32][34];
+  int l = 0;
+  while (l + 1 < t.n && (int)blockIdx.x >= t.first[l + 1]) ++l;
+  const int Co = t.Co[l], Ci = t.Ci[l], T = t.T[l];
+  int r = blockIdx.x - t.first[l];
+  const int tiles_ci = (Ci + 31) / 32, tiles_co = (Co + 31) / 32;
+  const int tci = r % tiles_ci; r /= tiles_ci;
+  const int tco = r % tiles_co;
+  const int tap = r / tiles_co;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const bf16_t* w = t.w[l];
+  bf16_t* wt = t.wt[l];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int co = tco * 32 + ty + 8 * j, ci = tci * 32 + tx;
+    tile[ty + 8 * j][tx] = (co < Co && ci < Ci) ? w[((long)co * T + tap) * Ci + ci] : (bf16_t)0;
+  }
+  __syncthreads();
+  const int ftap = T - 1 - tap;            // (KH-1-kh) * KW + (KW-1-kw)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ci = tci * 32 + ty + 8 * j, co = tco * 32 + tx;
+    if (ci < Ci && co < Co) wt[((long)ci * T + ftap) * Co + co] = tile[tx][ty + 8 * j];
+  }
+}
+
 void stem_geom(evk_conv_geom* g, int N, int H, int W) {
   const int Hp = H + 6, Wp = W + 8;
   g->N = N; g->Hi = Hp; g->Wi = W / 2; g->Ci = 32;
@@ -166,6 +198,56 @@ int evk_conv2d_dgrad_gated_stats(const void* dy, const void* w, const void* resi
     d.gatestats = part;
   }
   d.g = *g;
+  return evk_gemm_launch(&d, stream);
+}
+
+int evk_conv_flip_weights(const void* const* w, void* const* wt, const int32_t* Co, const int32_t* Ci, const int32_t* KH, const int32_t* KW,
+                          int32_t n_layers, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(w && wt && Co && Ci && KH && KW && n_layers > 0, "conv_flip_weights: bad args");
+  for (int base = 0; base < n_layers; base += 32) {
+    FlipTab t{};
+    t.n = n_layers - base < 32 ? n_layers - base : 32;
+    int tot = 0;
+    for (int l = 0; l < t.n; ++l) {
+      const int i = base + l;
+      EVK_REQUIRE(w[i] && wt[i] && Co[i] > 0 && Ci[i] > 0 && KH[i] > 0 && KW[i] > 0, "conv_flip_weights: bad layer %d", i);
+      t.w[l] = (const bf16_t*)w[i]; t.wt[l] = (bf16_t*)wt[i]; t.Co[l] = Co[i]; t.Ci[l] = Ci[i]; t.T[l] = KH[i] * KW[i]; t.KW[l] = KW[i];
+      t.first[l] = tot;
+      tot += t.T[l] * ((Co[i] + 31) / 32) * ((Ci[i] + 31) / 32);
+    }
+    t.first[t.n] = tot;
+    ProfScope ps(EVK_FAM_ELTWISE, s);
+    hipLaunchKernelGGL(conv_flip_weights_kernel, dim3(tot), dim3(256), 0, s, t);
+    if (int e = evk_check_launch("conv_flip_weights")) return e;
+  }
+  return EVK_OK;
+}
+
+int evk_conv2d_dgrad_flipped_gated_stats(const void* dy, const void* wt, const void* resid, const void* gate, void* dx, const evk_conv_geom* g,
+                                         float* part, int64_t part_bytes, int32_t* nblk, evk_stream_t stream) {
+  if (int e = check_geom(g)) return e;
+  EVK_REQUIRE(g->stride_h == 1 && g->stride_w == 1 && g->KH == 2 * g->pad_h + 1 && g->KW == 2 * g->pad_w + 1 && g->Co % 8 == 0 && g->Ci % 8 == 0,
+              "conv dgrad (flipped weights): stride 1, pad = (K - 1) / 2, channels %% 8");
+  const int T = g->KH * g->KW;
+  evk_gemm d{};
+  d.A = dy; d.B = wt; d.C = dx;
+  d.M = g->N * g->Hi * g->Wi; d.N = g->Ci; d.K = T * g->Co;
+  d.a_mode = EVK_A_CONV; d.b_mode = EVK_B_PLAIN;
+  d.lda = g->Co; d.ldb = d.K; d.ldc = g->Ci;
+  d.batch_outer = d.batch_inner = 1; d.alpha = 1.f; d.c_dtype = EVK_BF16;
+  if (resid) { d.resid = resid; d.ldr = g->Ci; d.r_dtype = EVK_BF16; }
+  if (gate) { d.relu_gate = gate; d.ldg = g->Ci; }
+  if (part) {
+    EVK_REQUIRE(gate && nblk && part_bytes >= evk_conv_stats_bytes(d.M, g->Ci), "conv dgrad: gate statistics need a gate and a large enough buffer");
+    *nblk = stats_rows(d.M, g->Ci);
+    d.gatestats = part;
+  }
+  // the convolution the GEMM gathers: input = dy (N, Ho, Wo, Co), output = dx (N, Hi, Wi, Ci), same kernel size, stride 1, pad K - 1 - p
+  d.g = *g;
+  d.g.Hi = g->Ho; d.g.Wi = g->Wo; d.g.Ci = g->Co; d.g.Ho = g->Hi; d.g.Wo = g->Wi; d.g.Co = g->Ci;
+  d.g.pad_h = g->KH - 1 - g->pad_h; d.g.pad_w = g->KW - 1 - g->pad_w;
+  d.g.sN = (int64_t)g->Ho * g->Wo * g->Co; d.g.sH = (int64_t)g->Wo * g->Co; d.g.sW = g->Co;
   return evk_gemm_launch(&d, stream);
 }
 

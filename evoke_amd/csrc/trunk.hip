@@ -24,6 +24,7 @@ struct Plan {
   std::vector<int> has_down;  // per block
   int N, H, W;
   long xpad, wp, dwp, pooled, pool_idx, red, slab, zeros, part, gbuf[6];
+  std::vector<long> wflip;   // per pair: offset of the flipped / transposed 16-bit weights (stride-1 3x3 convolutions), or -1
   long gcap, slab_bytes, red_bytes, part_bytes;
   long total;
 };
@@ -98,6 +99,12 @@ int make_plan(const evk_trunk_cfg* cfg, int N, int H, int W, Plan& P) {
   P.zeros = take(2 * 2048 * 4);
   P.part_bytes = part;
   P.part = take(part);
+  P.wflip.assign(P.pairs.size(), -1);
+  for (size_t i = 1; i < P.pairs.size(); ++i) {
+    const evk_conv_geom& g = P.pairs[i].g;
+    if (g.KH == 3 && g.KW == 3 && g.stride_h == 1 && g.stride_w == 1 && g.pad_h == 1 && g.pad_w == 1)
+      P.wflip[i] = take((long)g.Co * 9 * g.Ci * 2);
+  }
   P.total = off;
   return EVK_OK;
 }
@@ -272,6 +279,15 @@ int evk_trunk_backward(const evk_trunk_cfg* cfg, const evk_trunk_layer* layers, 
   static const bool gate_stats = [] { const char* e = getenv("EVK_BN_GATE_STATS"); return !e || atoi(e) != 0; }();
   static const bool x_stats = [] { const char* e = getenv("EVK_BN_XSTATS"); return !e || atoi(e) != 0; }();
   int nbz = 0;                           // > 0: the kernel that produced gZ left bn3's backward sums of the current block in P.part
+  static const bool flip_on = [] { const char* e = getenv("EVK_DGRAD_FLIP"); return !e || atoi(e) != 0; }();
+  if (flip_on) {        // flipped / transposed weights of every stride-1 3x3 convolution, one launch (evk_conv_flip_weights)
+    std::vector<const void*> ws_; std::vector<void*> wt_; std::vector<int32_t> co_, ci_, k_;
+    for (size_t i = 1; i < P.pairs.size(); ++i)
+      if (P.wflip[i] >= 0) {
+        ws_.push_back(layers[i].w); wt_.push_back(c.at(P.wflip[i])); co_.push_back(P.pairs[i].g.Co); ci_.push_back(P.pairs[i].g.Ci); k_.push_back(3);
+      }
+    if (!ws_.empty()) TRY(evk_conv_flip_weights(ws_.data(), wt_.data(), co_.data(), ci_.data(), k_.data(), k_.data(), (int32_t)ws_.size(), stream));
+  }
 
   auto wgrad = [&](int i, const void* xin) -> int {
     if (!layers[i].dw) return EVK_OK;
@@ -315,8 +331,12 @@ int evk_trunk_backward(const evk_trunk_cfg* cfg, const evk_trunk_layer* layers, 
     TRY(wgrad(i + 2, c.at(P.pairs[i + 1].z)));
     if (gs1) TRY(bn_backward_from_gate(c, i + 1, S1, nb1));
     else TRY(bn_backward(c, i + 1, S1, nullptr, 0));
-    TRY(evk_conv2d_dgrad_gated_stats(c.at(P.pairs[i + 1].dy), layers[i + 1].w, nullptr, c.at(P.pairs[i].z), S2, &P.pairs[i + 1].g,
-                                     gs0 ? part : nullptr, P.part_bytes, &nb0, stream));
+    if (flip_on && P.wflip[i + 1] >= 0)
+      TRY(evk_conv2d_dgrad_flipped_gated_stats(c.at(P.pairs[i + 1].dy), c.at(P.wflip[i + 1]), nullptr, c.at(P.pairs[i].z), S2, &P.pairs[i + 1].g,
+                                               gs0 ? part : nullptr, P.part_bytes, &nb0, stream));
+    else
+      TRY(evk_conv2d_dgrad_gated_stats(c.at(P.pairs[i + 1].dy), layers[i + 1].w, nullptr, c.at(P.pairs[i].z), S2, &P.pairs[i + 1].g,
+                                       gs0 ? part : nullptr, P.part_bytes, &nb0, stream));
     TRY(wgrad(i + 1, c.at(P.pairs[i].z)));
     if (gs0) TRY(bn_backward_from_gate(c, i, S2, nb0));
     else TRY(bn_backward(c, i, S2, nullptr, 0));

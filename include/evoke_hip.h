@@ -140,6 +140,16 @@ int evk_conv2d_dgrad(const void* dy, const void* w, void* dx, const evk_conv_geo
 int evk_conv2d_dgrad_add(const void* dy, const void* w, const void* resid, void* dx, const evk_conv_geom* g, evk_stream_t stream);
 /* dx = relu'(gate) * (dgrad(dy, w) + resid): also applies the ReLU gate of the tensor dx belongs to (gate = that tensor's
  * post-ReLU forward value), so the batch-norm backward that consumes dx needs no mask pass                          */
+/* Data gradient of a stride-1 "same" convolution (torchvision Bottleneck.conv2 of every non-strided block, as driven by
+ * modules/visual_extractor.py:27-43) as a FORWARD convolution of dy with the weights flipped and transposed,
+ * wt[ci][KH-1-kh][KW-1-kw][co] = w[co][kh][kw][ci] (16-bit, same element count as w): the K-contiguous main loop of evk_conv2d_fwd
+ * instead of the gather + K-strided one (layer3: 87 instead of 123 us alone, 167 with the gate epilogue).  evk_conv_flip_weights
+ * produces wt for a whole table of layers in one launch (w / wt: arrays of n_layers device pointers in HOST memory);
+ * evk_conv2d_dgrad_flipped_gated_stats = evk_conv2d_dgrad_gated_stats with wt in place of w (g = the geometry of the forward conv). */
+int evk_conv_flip_weights(const void* const* w, void* const* wt, const int32_t* Co, const int32_t* Ci, const int32_t* KH, const int32_t* KW,
+                          int32_t n_layers, evk_stream_t stream);
+int evk_conv2d_dgrad_flipped_gated_stats(const void* dy, const void* wt, const void* resid, const void* gate, void* dx, const evk_conv_geom* g,
+                                         float* part, int64_t part_bytes, int32_t* nblk, evk_stream_t stream);
 /* Weight-stationary kernel for the short-K pointwise convolutions (conv1x1.hip): y[M][N] = x[M][K] . w[N][K]^T with the weights
  * held in registers for the whole launch and only the pixel tiles streaming (torchvision Bottleneck conv3 forward: planes -> 4 planes;
  * the data gradient of conv1 is the same shape with the transposed weights; conv1 forward / conv3 data gradient at K = 512, 1024).

@@ -482,6 +482,47 @@ def test_dgrad_gate_statistics_give_the_batchnorm_backward_sums():
         close(dbeta - 1, want_g, 5e-3, 5e-3 * scale, 'dbeta acc')
 
 
+def test_flipped_weight_data_gradient_matches_the_gather_kernel_and_torch():
+    """evk_conv_flip_weights + evk_conv2d_dgrad_flipped_gated_stats: the data gradient of a stride-1 3x3 convolution run as a forward
+    convolution of dy with flipped / transposed weights -- against the gather formulation (evk_conv2d_dgrad_gated_stats: same gate, same
+    statistics) and f32 torch, on shapes with ragged row tiles and several layers in one flip launch."""
+    import ctypes as C
+    from evoke_amd import hip as H
+    torch.manual_seed(9)
+    shapes = [(2, 24, 256, 256), (3, 10, 64, 64), (1, 31, 128, 128), (2, 12, 512, 512)]
+    ws = [(torch.randn(co, 3, 3, ci, device='cuda') * 0.05).to(BF) for (_, _, ci, co) in shapes]
+    wts = [torch.empty(ci, 3, 3, co, device='cuda', dtype=BF) for (_, _, ci, co) in shapes]
+    n = len(shapes)
+    arr = lambda vals, ty: (ty * n)(*vals)          # noqa: E731
+    H.check(H.lib.evk_conv_flip_weights(arr([H.ptr(w) for w in ws], C.c_void_p), arr([H.ptr(w) for w in wts], C.c_void_p),
+                                        arr([s[3] for s in shapes], C.c_int32), arr([s[2] for s in shapes], C.c_int32), arr([3] * n, C.c_int32),
+                                        arr([3] * n, C.c_int32), n, H.stream()))
+    for (N, Hh, Ci, Co), w, wt in zip(shapes, ws, wts):
+        assert torch.equal(wt, w.flip(1, 2).permute(3, 1, 2, 0).contiguous()), 'flip kernel'
+        g = H.conv_geom(N, Hh, Hh, Ci, Co, 3, 3, 1, 1)
+        M = N * Hh * Hh
+        dy = (torch.randn(N, Hh, Hh, Co, device='cuda') * 0.3).to(BF)
+        z = torch.relu(torch.randn(N, Hh, Hh, Ci, device='cuda')).to(BF)
+        nb = H.lib.evk_conv_stats_bytes(M, Ci)
+        outs = []
+        for flipped in (False, True):
+            dx = torch.empty(N, Hh, Hh, Ci, device='cuda', dtype=BF)
+            part = torch.zeros(nb // 4, device='cuda')
+            nblk = C.c_int32(0)
+            fn = H.lib.evk_conv2d_dgrad_flipped_gated_stats if flipped else H.lib.evk_conv2d_dgrad_gated_stats
+            H.check(fn(H.ptr(dy), H.ptr(wt if flipped else w), None, H.ptr(z), H.ptr(dx), C.byref(g), H.ptr(part), nb, C.byref(nblk), H.stream()))
+            sums = part[:nblk.value * 2 * Ci].view(nblk.value, 2, Ci).sum(0)
+            outs.append((dx, sums))
+        xr = torch.zeros(N, Ci, Hh, Hh, device='cuda', requires_grad=True)
+        torch.nn.functional.conv2d(xr, w.float().permute(0, 3, 1, 2), stride=1, padding=1).backward(dy.float().permute(0, 3, 1, 2))
+        gref = xr.grad.permute(0, 2, 3, 1) * (z.float() > 0)
+        scale = float(gref.abs().reshape(-1, Ci).sum(0).max())
+        close(outs[1][0].float(), gref.cpu(), 2e-2, 2e-2, 'flipped dgrad vs torch')
+        close(outs[1][0].float(), outs[0][0].float().cpu(), 1e-2, 1e-2, 'flipped vs gather dgrad')
+        close(outs[1][1][0], gref.reshape(-1, Ci).sum(0).cpu(), 5e-3, 5e-3 * scale, 'sum g')
+        close(outs[1][1][1], (gref * z.float()).reshape(-1, Ci).sum(0).cpu(), 5e-3, 1e-2 * scale, 'sum g*z')
+
+
 @pytest.mark.parametrize('tiny', [1e-2, 1e-4, 1e-6])
 def test_gate_statistics_fall_back_to_exact_sums_for_near_dead_channels(tiny):
     """ImageNet-pretrained resnet101 has batch-norm channels with |gamma| << |beta|.  There xhat = (z - beta) / gamma amplifies the 16-bit
