@@ -135,17 +135,26 @@ def decode_record(model, a, rank, world, dev, with_cpu):
     # Replicas: no rank waits for another inside the measurement.  A rank that fails reports an infinite time, and the ONE collective
     # (max over ranks) sits outside the guarded region so that every rank reaches it whatever happened -- a barrier inside would hang
     # the whole job on a single rank's exception.
-    n = max(2, min(a.steps, 4))
+    n = max(2, min(a.steps, 8))
     step_ms, dt, err = [], float('inf'), None
+    pipelined = os.environ.get('EVK_DECODE_PIPELINE', '1') != '0'
+    depth = max(1, int(os.environ.get('EVK_DECODE_DEPTH', '2'))) if pipelined else 1
     try:
         for _ in range(max(1, min(a.warmup, 2))):
             step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(n):
-            seq = step()
-            ev0, ev1, cnt = DEC.stats['step_events']
-            step_ms.append((ev0, ev1, cnt))
+        if pipelined:
+            # the serving loop: encoders of batch k+1 overlap the decode of batch k (FineTune.generate_pipelined); same per-batch results
+            tup = (b['images'], b['ids'], b['masks'], b['pids'], b['inc'], b['inc_masks'])
+            for _, seq in model.generate_pipelined([tup] * n, mode='inference', depth=depth):
+                ev0, ev1, cnt = DEC.stats['step_events']
+                step_ms.append((ev0, ev1, cnt))
+        else:
+            for _ in range(n):
+                seq = step()
+                ev0, ev1, cnt = DEC.stats['step_events']
+                step_ms.append((ev0, ev1, cnt))
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     except Exception as e:          # noqa: BLE001
@@ -167,7 +176,7 @@ def decode_record(model, a, rank, world, dev, with_cpu):
     t_mean = (L - 1) / 2.0
     state_bytes = (t_mean * 3 * 2 * 512 + 144 * 3 * 2 * 512 + 1536) * 2.0
     alg_bytes = 2.0 * w_params + R * state_bytes
-    ach = alg_bytes / (per_step_ms * 1e-3) / 1e9
+    ach = depth * alg_bytes / (per_step_ms * 1e-3) / 1e9          # `depth` searches in flight: each of their steps moves alg_bytes
     rec = {
         'metric': 'decode tokens/sec (beam search, %d^2)' % a.res, 'value': B * L * n * world / dt, 'unit': 'tokens/s', 'steps': n,
         'ms_per_batch': 1e3 * dt / n, 'higher_is_better': True, 'dtype': H.STORE,
@@ -175,10 +184,11 @@ def decode_record(model, a, rank, world, dev, with_cpu):
                                'incremental decoder state, visual extractor + fusion included, V=%d, random-init weights'
                                % (a.res, beam, B, a.views, L, V), 'parallelism': 'replicas x%d' % world,
                    'mean_generated_len': float((seq != 0).sum(1).float().mean().item()), 'hip_graph_step': DEC.stats.get('graph'),
+                   'pipelined_encoders': pipelined, 'searches_in_flight': depth,
                    'fused_beam_bookkeeping': DEC.stats.get('fused_bookkeeping')},
         'roofline': {'bound': 'hbm', 'kernel': 'per-token decode step (HIP graph: RM step, 3 decoder layers, logits, log-softmax, beam step)',
                      'achieved': ach, 'peak': 8000.0, 'unit': 'GB/s', 'frac': ach / 8000.0, 'traffic': None,
-                     'algorithmic_bytes_per_step': alg_bytes, 'step_ms': per_step_ms, 'hypotheses': R,
+                     'algorithmic_bytes_per_step': alg_bytes, 'step_ms': per_step_ms, 'hypotheses': R, 'searches_in_flight': depth,
                      'note': 'the step is launch-latency bound (~100 dependent kernels of a few us), not bandwidth bound'},
     }
     if with_cpu:

@@ -75,14 +75,16 @@ __global__ __launch_bounds__(256) void dropout_kernel(const bf16_t* __restrict__
 // out[r][:] = table[ids[r]][:] * scale + (pos ? pos[r % L][:] : 0) + (extra ? extra[:] : 0)
 __global__ __launch_bounds__(256) void embedding_fwd_kernel(const float* __restrict__ table, const long long* __restrict__ ids,
                                                             const float* __restrict__ pos, const float* __restrict__ extra,
-                                                            void* __restrict__ out, int out_f32, long rows, int D, int L, float scale, long long table_rows) {
+                                                            void* __restrict__ out, int out_f32, long rows, int D, int L, float scale, long long table_rows,
+                                                            const long long* __restrict__ pos0_dev) {
   const long total = rows * D;
+  const long pos0 = pos0_dev ? pos0_dev[0] : 0;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long r = i / D;
     const int c = (int)(i - r * D);
     const long long id = ids[r];
     float v = (id >= 0 && id < table_rows) ? table[id * D + c] * scale : 0.f;        // an id outside the table must not become a wild read
-    if (pos) v += pos[(r % L) * D + c];
+    if (pos) v += pos[((r % L) + pos0) * D + c];
     if (extra) v += extra[c];
     stx(out, out_f32, i, v);
   }
@@ -493,12 +495,12 @@ int evk_dropout(const void* x, const void* resid, void* y, int64_t n, float p, u
 }
 
 int evk_embedding_fwd(const float* table, const int64_t* ids, const float* pos, const float* extra, void* out, int out_dtype,
-                      int64_t rows, int32_t D, int32_t L, float scale, int64_t table_rows, evk_stream_t stream) {
+                      int64_t rows, int32_t D, int32_t L, float scale, int64_t table_rows, const int64_t* pos0_dev, evk_stream_t stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   EVK_REQUIRE(table && ids && out && rows > 0 && D > 0 && L > 0 && table_rows > 0, "embedding_fwd: bad args");
   ProfScope ps(EVK_FAM_ELTWISE, s);
   hipLaunchKernelGGL(embedding_fwd_kernel, dim3(ew_blocks(rows * D)), dim3(256), 0, s, table, (const long long*)ids, pos, extra, out,
-                     out_dtype == EVK_F32, (long)rows, D, L, scale, (long long)table_rows);
+                     out_dtype == EVK_F32, (long)rows, D, L, scale, (long long)table_rows, (const long long*)pos0_dev);
   return evk_check_launch("embedding_fwd");
 }
 

@@ -29,7 +29,44 @@ _FUSED_APPEND = [os.environ.get('EVK_DECODE_FUSED_APPEND', '1') != '0']  # K / V
 _FUSED_LN = [os.environ.get('EVK_DECODE_FUSED_LN', 'off')]
 _SPLIT_CLN = [os.environ.get('EVK_DECODE_SPLIT_CLN', '1') != '0']       # first conditional-norm MLP layer as two launches (see cln_deltas)
 _FUSED_BOOK = [os.environ.get('EVK_DECODE_FUSED_BOOK', '1') != '0']      # beam bookkeeping as one kernel per token (csrc/beam.hip)
+_REPLAYER = [os.environ.get('EVK_DECODE_REPLAYER', '1') != '0']      # re-issue the captured step with csrc/replay.hip instead of hipGraphLaunch
 stats = {}                       # facts about the last beam_search call (bench.py reads the per-token step time from here)
+_PLANS = []                      # (plan, graph, event recorded after the last replay): destroyed once the GPU has passed the event
+
+
+_cap_streams = {}
+_pools = {}
+_last_graph = {}                 # device -> the most recent captured graph: keeps the shared memory pool referenced between batches
+
+
+def _capture_stream(dev, kind='capture'):
+    key = (torch.device(dev).index, kind)
+    st = _cap_streams.get(key)
+    if st is None:
+        st = _cap_streams[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
+def _graph_pool(dev, slot=0):
+    """ONE private memory pool for the per-token graphs of every generate call on a device: a fresh pool per capture means a
+    hipMalloc per batch (and a hipFree when the graph dies), and those synchronise the whole device -- which serialises the decode of
+    batch k behind the encoders of batch k+1 that FineTune.generate_pipelined runs on another stream."""
+    key = (torch.device(dev).index, slot)          # (searches in flight at the same time replay concurrently: a pool each)
+    if key not in _pools:
+        _pools[key] = torch.cuda.graph_pool_handle()
+    return _pools[key]
+
+
+def _reap_plans(force=False):
+    keep = []
+    for plan, graph, ev in _PLANS:
+        if force or ev.query():
+            if force:
+                ev.synchronize()
+            H.lib.evk_replay_destroy(plan)
+        else:
+            keep.append((plan, graph, ev))
+    _PLANS[:] = keep
 
 
 def _topk(x, k):
@@ -140,22 +177,36 @@ class _FusedDecodeWeights:
         return out
 
 
+def _fused_weights(model):
+    """_FusedDecodeWeights of `model`, rebuilt only when a parameter of the decoder changed (torch version counters + the optimizer's
+    weight epoch: ops.WEIGHT_EPOCH) -- 28 MB of concatenations per generate call otherwise"""
+    ps = [p for p in model.decoder.parameters()]
+    key = (ops.WEIGHT_EPOCH[0], tuple(p._version for p in ps), ps[0].device, ps[0].data_ptr())
+    hit = getattr(model, '_evk_fused_decode', None)
+    if hit is None or hit[0] != key:
+        hit = (key, _FusedDecodeWeights(model))
+        model._evk_fused_decode = hit
+    return hit[1]
+
+
 class _DecoderState:
     """Incremental state of R = batch*beam hypotheses."""
 
-    def __init__(self, dec, enc, src_mask, max_len):
+    def __init__(self, dec, enc, src_mask, max_len, cross_kv=None, rows=None):
+        """cross_kv: ([K per layer], [V per layer]) already projected from `enc` (the session computes them once for both the first,
+        B-row step and the R-row steps); rows: hypothesis count of the self-attention caches / memory (default: enc rows)."""
         model = dec.model
         self.dec, self.model = dec, model
-        R, d = enc.shape[0], model.d_model
+        R, d = (enc.shape[0] if rows is None else rows), model.d_model
         self.enc, self.src_mask = enc, src_mask
         self.mem = model.rm.init_memory(R, enc.device)
         self.t = 0
         self.anc = self.rows = None      # cache row table of the graph-mode steps (step_static)
-        self.fused = _FusedDecodeWeights(model)
+        self.fused = _fused_weights(model)
         self.kc, self.vc, self.ks, self.vs = [], [], [], []
-        for layer in model.decoder.layers:
-            self.kc.append(layer.src_attn.linears[1](enc))
-            self.vc.append(layer.src_attn.linears[2](enc))
+        for i, layer in enumerate(model.decoder.layers):
+            self.kc.append(layer.src_attn.linears[1](enc) if cross_kv is None else cross_kv[0][i])
+            self.vc.append(layer.src_attn.linears[2](enc) if cross_kv is None else cross_kv[1][i])
             self.ks.append(torch.zeros(R, max_len, d, dtype=BF16, device=enc.device))
             self.vs.append(torch.zeros(R, max_len, d, dtype=BF16, device=enc.device))
 
@@ -189,7 +240,7 @@ class _DecoderState:
             self.ks[i].copy_(self.ks[i].index_select(0, ix))
             self.vs[i].copy_(self.vs[i].index_select(0, ix))
 
-    def step_static(self, it, pos, kmask):
+    def step_static(self, it, pos, kmask, out=None, seed_rows=True):
         """step() with the position held in a device tensor `pos` (1,) and self-attention over the whole cache under the key
         mask `kmask` (R, max_len; 1 for positions <= pos): no host-side shape depends on the step index, so the launch
         sequence can be captured once in a HIP graph and replayed."""
@@ -199,12 +250,13 @@ class _DecoderState:
             R_, S_ = self.ks[0].shape[0], self.ks[0].shape[1]
             self.rows = torch.arange(R_, dtype=torch.int32, device=pos.device).view(R_, 1)
             self.anc = self.rows.expand(R_, S_).contiguous()
-        if self.anc is not None:
+        if self.anc is not None and seed_rows:
             self.anc.index_copy_(1, pos, self.rows)      # this step's K / V are written to the hypothesis's own cache row
-        pe = model.tgt_embed[1].pe[0].index_select(0, pos)
-        emb = ops.embedding(it.view(-1, 1).contiguous(), model.tgt_embed[0].lut.weight, pos=pe, scale=math.sqrt(model.d_model))
+        # the positional row is picked on the device (pos is a device scalar inside the captured step)
+        emb = ops.embedding(it.view(-1, 1).contiguous(), model.tgt_embed[0].lut.weight, pos=model.tgt_embed[1].pe[0], scale=math.sqrt(model.d_model),
+                            pos0=pos)
         memory, new_mem = model.rm.run(emb, self.mem)
-        self.mem.copy_(new_mem)
+        ops.copy_kernel(self.mem, new_mem)
         fw, d = self.fused, model.d_model
         deltas = fw.cln_deltas(memory)
         x = emb
@@ -246,12 +298,17 @@ class _DecoderState:
             else:
                 x = ff(fw.norm(3 * i + 2, x, deltas), resid=x)
         fn, lg = model.decoder.norm, self.dec.logit
+        V1 = lg.weight.shape[0]
         if ln_ok and _FUSED_LN[0] in ('all', 'final'):
-            V1 = lg.weight.shape[0]
             logits = fw.ln_linear(x, fn.gamma, fn.beta, fn.eps, ops.shadow(lg.weight, pad_rows=(V1 % 8 != 0)), lg.bias, V1, out_f32=True)
         else:
-            logits = self.dec.logit(fn(x), out_f32=True)
-        return ops.log_softmax(logits.view(logits.shape[0], -1), self.dec.vocab_size + 1)
+            # straight into a persistent f32 buffer whose pad columns were zeroed once (no per-step fill)
+            Np = (V1 + 7) // 8 * 8
+            if getattr(self, 'logits_buf', None) is None or self.logits_buf.shape[0] != x.shape[0]:
+                self.logits_buf = torch.zeros(x.shape[0], Np, dtype=F32, device=x.device)
+            ops.gemm(fn(x).view(-1, d), ops.shadow(lg.weight, pad_rows=(V1 != Np)), self.logits_buf, x.shape[0], V1, d, lda=d, ldb=d, ldc=Np, bias=lg.bias)
+            logits = self.logits_buf
+        return ops.log_softmax(logits.view(logits.shape[0], -1), self.dec.vocab_size + 1, out=out)
 
     def step(self, it):
         """it (R,) token ids at position self.t -> f32 log-probs (R, V+1) of the next token."""
@@ -281,11 +338,241 @@ class _DecoderState:
         return ops.log_softmax(logits.view(logits.shape[0], -1), self.dec.vocab_size + 1)
 
 
+class _BeamSession:
+    """Everything a beam search over B samples x `beam` hypotheses x max_len positions owns on the device -- self-attention caches, cache
+    row tables, cross-attention K / V, relational memory, beam bookkeeping arrays, the log-probability buffer -- allocated ONCE and kept
+    on the decoder, together with the captured per-token launch sequence and its replay plan.  A generate call then only refills the
+    buffers (cross K / V of the new batch, the first position's state) and replays: no allocation, no capture, no plan build per batch
+    (13 ms of host time per 64-study batch otherwise, during which the decode stream sits idle)."""
+
+    def __init__(self, dec, B, beam, max_len, S, dev, slot=0):
+        model = dec.model
+        self.slot = slot
+        d, nl = model.d_model, len(model.decoder.layers)
+        R = B * beam
+        self.dec, self.B, self.beam, self.max_len, self.R = dec, B, beam, max_len, R
+        self.kc = [torch.empty(B, S, d, dtype=BF16, device=dev) for _ in range(nl)]
+        self.vc = [torch.empty(B, S, d, dtype=BF16, device=dev) for _ in range(nl)]
+        self.st = None                    # R-row decoder state, built on first use (needs an encoder output for its geometry)
+        self.beam_seq = torch.zeros(B, beam, max_len, dtype=torch.long, device=dev)
+        self.beam_sum = torch.zeros(B, beam, dtype=F32, device=dev)
+        self.best_p = torch.empty(B, dtype=F32, device=dev)
+        self.best_seq = torch.empty(B, max_len, dtype=torch.long, device=dev)
+        self.words = torch.empty(R, dtype=torch.long, device=dev)
+        self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.pos = torch.ones(1, dtype=torch.long, device=dev)
+        self.logp_buf = torch.empty(R, dec.vocab_size + 1, dtype=F32, device=dev)
+        self.base = torch.arange(B, device=dev).unsqueeze(1)
+        self.graph = self.plan = None
+        self.fused_key = None
+
+    def __del__(self):
+        if getattr(self, 'plan', None) is not None:
+            try:
+                torch.cuda.synchronize()
+                H.lib.evk_replay_destroy(self.plan)
+            except Exception:          # noqa: BLE001 -- interpreter shutdown
+                pass
+
+    def _book_kernel(self, last):
+        """one launch (csrc/beam.hip): top-beam, sequence / cache-row-table / relational-memory reorder in place, finished-beam tracking,
+        -1000 penalty, next input tokens -- and, between steps, the position counter's increment and the row table's next column"""
+        dec, st, lp = self.dec, self.st, self.logp_buf
+        H.check(H.lib.evk_beam_step(H.ptr(lp), lp.shape[-1], dec.vocab_size + 1, self.beam, self.B, self.max_len, H.ptr(self.pos), dec.eos_idx,
+                                    int(last), H.ptr(self.beam_sum), H.ptr(self.beam_seq), H.ptr(self.best_p), H.ptr(self.best_seq),
+                                    H.ptr(self.words), H.ptr(st.mem), st.mem[0].numel(), H.ptr(st.anc), st.anc.shape[1],
+                                    None if last else H.ptr(self.pos), H.ptr(self.ticket), H.stream()), 'beam_step')
+
+    def _body(self):
+        """positions 1 .. max_len-2: bookkeeping at position `pos` (which also advances it), then the decoder step that writes pos + 1"""
+        self._book_kernel(False)
+        self.st.step_static(self.words, self.pos, None, out=self.logp_buf, seed_rows=False)
+
+    def run(self, enc, src_mask, return_scores=False, step_hook=None):
+        it = self.run_iter(enc, src_mask, return_scores, step_hook)
+        try:
+            while True:
+                next(it)
+        except StopIteration as e:
+            return e.value
+
+    def run_iter(self, enc, src_mask, return_scores=False, step_hook=None):
+        """run() as a generator that yields after every issued token step: a scheduler that drives several sessions (one per HIP stream)
+        round-robin keeps all their launch queues fed (FineTune.generate_pipelined) -- issuing one session's ~6k launches in one go
+        blocks the host at the GPU's pace, because a launch queue is finite."""
+        dec, B, beam, max_len, R = self.dec, self.B, self.beam, self.max_len, self.R
+        dev, V1 = enc.device, dec.vocab_size + 1
+        hook = step_hook if step_hook is not None else (lambda *a: None)
+        model = dec.model
+        # cross-attention K / V of this batch, into the session's buffers (the captured step reads them there)
+        for i, layer in enumerate(model.decoder.layers):
+            ops.copy_kernel(self.kc[i], layer.src_attn.linears[1](enc))
+            ops.copy_kernel(self.vc[i], layer.src_attn.linears[2](enc))
+        fused = _fused_weights(model)
+        if self.st is None or self.fused_key is not fused:
+            # (re)build the R-row state around the session's buffers; derived weights changed -> the captured step is stale as well
+            self.st = _DecoderState(dec, enc, src_mask, max_len, cross_kv=(self.kc, self.vc), rows=R)
+            self.fused_key = fused
+            if self.plan is not None:
+                _PLANS.append((self.plan, self.graph, torch.cuda.Event()))
+                _PLANS[-1][2].record()
+            self.graph = self.plan = None
+        st = self.st
+        st.enc, st.src_mask = enc, src_mask
+        # ---- position 0: B rows, eagerly (modules/att_model.py:118-124: one decoder call with [BOS], then the features are tiled x beam)
+        st0 = _DecoderState(dec, enc, src_mask, 1, cross_kv=(self.kc, self.vc))
+        logp0 = st0.step(torch.full((B,), dec.bos_idx, dtype=torch.long, device=dev))            # (B, V+1)
+        self.beam_seq.zero_()
+        self.beam_sum.zero_()
+        self.best_p.fill_(-float('inf'))
+        self.best_seq.fill_(dec.pad_idx)
+        hook(0, logp0, self.beam_sum)
+        ys, ix = _topk(logp0.view(B, -1)[:, :V1].contiguous(), beam)
+        word_ix = ix % V1                                                   # one source hypothesis per sample: the flat index IS the word
+        state_ix = self.base.expand(B, beam).reshape(-1)                    # hypothesis r of sample b starts from sample b's state
+        self.beam_seq[:, :, 0] = word_ix
+        self.beam_sum.copy_(ys)
+        last = max_len == 1
+        is_end = torch.ones_like(word_ix, dtype=torch.bool) if last else (word_ix == dec.eos_idx)
+        p_end = torch.where(is_end, self.beam_sum, torch.full_like(self.beam_sum, -float('inf')))
+        pv, pi = p_end.max(dim=1)
+        better = pv > self.best_p
+        cand_seq = self.beam_seq.gather(1, pi.view(B, 1, 1).expand(-1, 1, max_len))[:, 0]
+        self.best_seq.copy_(torch.where(better.unsqueeze(1), cand_seq, self.best_seq))
+        self.best_p.copy_(torch.where(better, pv, self.best_p))
+        self.beam_sum.sub_(1000.0 * is_end.to(F32))
+        if max_len > 1:
+            # the B -> B*beam expansion: every hypothesis inherits its sample's memory and position-0 keys / values
+            ops.copy_kernel(st.mem, st0.mem.index_select(0, state_ix).contiguous())
+            for i in range(len(st.ks)):
+                st.ks[i][:, :1] = st0.ks[i][:, :1].index_select(0, state_ix)
+                st.vs[i][:, :1] = st0.vs[i][:, :1].index_select(0, state_ix)
+            self.pos.fill_(1)
+            self.ticket.zero_()
+            if st.anc is not None:
+                st.anc.copy_(st.rows.expand_as(st.anc))
+            self.words.copy_(word_ix.reshape(-1))
+            st.step_static(self.words, self.pos, None, out=self.logp_buf)       # writes position 1 (and builds the row table on first use)
+            if st.anc is None:
+                raise RuntimeError('beam session needs the cache row table (head dim 64, max_seq_len <= 256)')
+            hook(1, self.logp_buf, self.beam_sum)
+            n_body = max_len - 2
+            done = 0
+            cur = torch.cuda.current_stream()
+            if self.graph is None and n_body > 3 and _GRAPH_ENABLED[0]:
+                side = _capture_stream(dev, ('warm', self.slot))
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):                           # warm-up iterations (real steps) off the launching stream
+                    self._body()
+                    hook(2, self.logp_buf, self.beam_sum)
+                    self._body()
+                    hook(3, self.logp_buf, self.beam_sum)
+                cur.wait_stream(side)
+                done = 2
+                try:
+                    # captured by hand (capture_begin / capture_end on a side stream), not through torch.cuda.graph(): the context manager
+                    # opens with a DEVICE-WIDE synchronize, which would make this decode wait for the next batch's encoders
+                    graph = torch.cuda.CUDAGraph(keep_graph=_REPLAYER[0])
+                    cap = _capture_stream(dev, ('capture', self.slot))
+                    cap.wait_stream(cur)
+                    with torch.cuda.stream(cap):
+                        graph.capture_begin(pool=_graph_pool(dev, self.slot))
+                        try:
+                            self._body()
+                        finally:
+                            graph.capture_end()
+                    cur.wait_stream(cap)
+                    self.graph = graph
+                except Exception as e:                                   # stay on the HIP path, just without the graph
+                    import warnings
+                    warnings.warn('decode: HIP graph capture failed (%s); running the steps eagerly' % e)
+                    self.graph = None
+                if self.graph is not None and _REPLAYER[0]:
+                    # the library's own replayer (csrc/replay.hip): plain launches, ~3 us of host time per node (hipGraphLaunch: 7-12 us)
+                    plan = H.lib.evk_replay_build(C.c_void_p(self.graph.raw_cuda_graph()), 16)
+                    if not plan:
+                        import warnings
+                        warnings.warn('decode: replay plan refused (%s); using hipGraphLaunch' % H.lib.evk_last_error().decode())
+                        if hasattr(self.graph, 'instantiate'):
+                            self.graph.instantiate()
+                    self.plan = plan or None
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            for it_ in range(done, n_body):
+                if self.plan is not None:
+                    H.check(H.lib.evk_replay_run(self.plan, H.stream()), 'replay_run')
+                elif self.graph is not None:
+                    self.graph.replay()
+                else:
+                    self._body()
+                if step_hook is not None:
+                    step_hook(it_ + 2, self.logp_buf, self.beam_sum)       # body number it_ wrote the log-probabilities of position it_ + 2
+                yield it_
+            ev1.record()
+            stats['step_events'] = (ev0, ev1, max(0, n_body - done))      # per-token step time = elapsed / count (bench.py)
+            stats['graph'] = self.graph is not None
+            stats['replayer'] = self.plan is not None
+            stats['fused_bookkeeping'] = True
+            self._book_kernel(True)                                      # t = max_len - 1: every live beam is closed
+            _reap_plans()
+        seq = self.best_seq.clone()
+        if return_scores:
+            return seq, self.best_p.clone()
+        return seq
+
+
+import weakref  # noqa: E402
+
+_SESSIONS = weakref.WeakKeyDictionary()          # decoder module -> {geometry: _BeamSession}
+
+
+def _session_ok(dec, args, enc):
+    model = dec.model
+    h = model.decoder.layers[0].self_attn.h
+    return (_INDIRECT[0] and _FUSED_BOOK[0] and _FUSED_APPEND[0] and _GRAPH_ENABLED[0] and model.d_model // h == 64 and
+            int(args['max_seq_len']) <= 256 and os.environ.get('EVK_DECODE_SESSION', '1') != '0')
+
+
 @torch.no_grad()
-def beam_search(dec, enc_states, enc_mask, args, return_scores=False, step_hook=None):
+def beam_search(dec, enc_states, enc_mask, args, return_scores=False, step_hook=None, slot=0, as_iterator=False):
     """-> (B, max_seq_len) int64 token ids padded with [PAD] (= AttModel._sample_beam with sample_n = 1).
     step_hook(t, logp, beam_sum): test instrument, called on the launching stream right before the bookkeeping of position t consumes
-    `logp` (f32, one row of >= V+1 log-probabilities per live hypothesis; may be edited in place) with the running sums (B, beam)."""
+    `logp` (f32, one row of >= V+1 log-probabilities per live hypothesis; may be edited in place) with the running sums (B, beam).
+    slot: which of the decoder's persistent sessions to use (searches that are in flight at the same time need different slots);
+    as_iterator: return a generator that yields after every issued token step and returns the result (see _BeamSession.run_iter)."""
+    if not _session_ok(dec, args, enc_states):
+        if as_iterator:
+            raise NotImplementedError('stepwise beam search needs the session path')
+        return _beam_search_legacy(dec, enc_states, enc_mask, args, return_scores, step_hook)
+    was_training = dec.training
+    dec.eval()
+    try:
+        beam, max_len = int(args.get('beam_size', 3)), int(args['max_seq_len'])
+        if args.get('group_size', 1) != 1 or args.get('sample_n', 1) != 1:
+            raise NotImplementedError('diverse beam search (group_size > 1) is not on the path')
+        if beam < 1 or beam > 8 or beam > dec.vocab_size + 1:
+            raise ValueError('beam_size must be in [1, 8]')
+        enc, src_mask = dec.encode(enc_states, enc_mask)
+        B, S, dev = enc.shape[0], enc.shape[1], enc.device
+        key = (B, beam, max_len, S, dev.index, src_mask is None, slot)
+        sessions = _SESSIONS.setdefault(dec, {})
+        ses = sessions.pop(key, None)
+        if ses is None:
+            ses = _BeamSession(dec, B, beam, max_len, S, dev, slot)
+            while len(sessions) >= 6:                   # a few batch geometries / slots at most (each holds its caches: 6 x R x max_len x 512 x 2 B)
+                sessions.pop(next(iter(sessions)))
+        sessions[key] = ses
+        if as_iterator:
+            return ses.run_iter(enc, src_mask, return_scores, step_hook)
+        return ses.run(enc, src_mask, return_scores, step_hook)
+    finally:
+        dec.train(was_training)
+
+
+@torch.no_grad()
+def _beam_search_legacy(dec, enc_states, enc_mask, args, return_scores=False, step_hook=None):
+    """beam_search without the persistent session (head dims other than 64, max_seq_len > 256, or the debugging switches): every call
+    allocates its state and captures its own graph."""
     was_training = dec.training
     dec.eval()
     try:
@@ -335,13 +622,16 @@ def beam_search(dec, enc_states, enc_mask, args, return_scores=False, step_hook=
 
         words = torch.empty(B * beam, dtype=torch.long, device=dev)
 
+        ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+
         def book_kernel(last):
             """book(None, last) as ONE launch (csrc/beam.hip): top-beam, sequence / cache-row-table / relational-memory reorder in
-            place, finished-beam tracking, -1000 penalty, next input tokens."""
+            place, finished-beam tracking, -1000 penalty, next input tokens -- and, between steps, the position counter's increment and
+            the row-table column of the next position."""
             lp = logp[0]
             H.check(H.lib.evk_beam_step(H.ptr(lp), lp.shape[-1], V1, beam, B, max_len, H.ptr(pos), dec.eos_idx, int(last), H.ptr(beam_sum),
                                         H.ptr(beam_seq), H.ptr(best_p), H.ptr(best_seq), H.ptr(words), H.ptr(st.mem), st.mem[0].numel(),
-                                        H.ptr(st.anc), st.anc.shape[1], H.stream()), 'beam_step')
+                                        H.ptr(st.anc), st.anc.shape[1], None if last else H.ptr(pos), H.ptr(ticket), H.stream()), 'beam_step')
             return words
 
         nb = 1
@@ -364,17 +654,20 @@ def beam_search(dec, enc_states, enc_mask, args, return_scores=False, step_hook=
 
             def body():
                 """steps 1 .. max_len-2: bookkeeping at position `pos`, then the decoder step that writes position pos+1."""
-                w_ = book_kernel(False) if fused_book else book(None, False)
-                pos.add_(1)
+                if fused_book:
+                    w_ = book_kernel(False)              # (advances pos and seeds the row table's next column itself)
+                else:
+                    w_ = book(None, False)
+                    pos.add_(1)
                 kmask = (ar <= pos).expand(R, -1).to(torch.uint8).contiguous() if st.anc is None else None
-                logp_buf.copy_(st.step_static(w_.reshape(-1), pos, kmask))
+                st.step_static(w_.reshape(-1), pos, kmask, out=logp_buf, seed_rows=not fused_book)
 
             n_body = max_len - 2                                         # iterations t = 1 .. max_len-2
-            graph = None
+            graph = plan = None
             done = 0
             if n_body > 3 and _GRAPH_ENABLED[0]:
                 cur = torch.cuda.current_stream()
-                side = torch.cuda.Stream(device=dev)
+                side = _capture_stream(dev, 'warm')
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):                           # warm-up iterations (real steps) off the default stream
                     body()
@@ -384,17 +677,40 @@ def beam_search(dec, enc_states, enc_mask, args, return_scores=False, step_hook=
                 cur.wait_stream(side)
                 done = 2
                 try:
-                    graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph):
-                        body()
+                    # captured by hand (capture_begin / capture_end on a side stream) rather than through torch.cuda.graph(): the context
+                    # manager opens with a DEVICE-WIDE synchronize, which would make this decode wait for the next batch's encoders that
+                    # FineTune.generate_pipelined has just queued on another stream
+                    graph = torch.cuda.CUDAGraph(keep_graph=_REPLAYER[0])
+                    cap = _capture_stream(dev)
+                    pool = _graph_pool(dev)
+                    cap.wait_stream(cur)
+                    with torch.cuda.stream(cap):
+                        graph.capture_begin(pool=pool)
+                        try:
+                            body()
+                        finally:
+                            graph.capture_end()
+                    cur.wait_stream(cap)
                 except Exception as e:                                   # stay on the HIP path, just without the graph
                     import warnings
                     warnings.warn('decode: HIP graph capture failed (%s); running the steps eagerly' % e)
                     graph = None
+                if graph is not None and _REPLAYER[0]:
+                    # hipGraphLaunch costs 7-12 us of HOST time per node on ROCm 7.2 -- ~0.45 ms for this ~60-kernel step, exactly the
+                    # step time that was measured: the replays were host-bound.  The library's own replayer (csrc/replay.hip) walks the
+                    # captured graph once and re-issues it with plain launches (~3 us per node).
+                    plan = H.lib.evk_replay_build(C.c_void_p(graph.raw_cuda_graph()), 16)
+                    if not plan:
+                        import warnings
+                        warnings.warn('decode: replay plan refused (%s); using hipGraphLaunch' % H.lib.evk_last_error().decode())
+                        graph.instantiate() if hasattr(graph, 'instantiate') else None
+                    plan = plan or None
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
             for it_ in range(done, n_body):
-                if graph is not None:
+                if plan is not None:
+                    H.check(H.lib.evk_replay_run(plan, H.stream()), 'replay_run')
+                elif graph is not None:
                     graph.replay()
                 else:
                     body()
@@ -403,6 +719,13 @@ def beam_search(dec, enc_states, enc_mask, args, return_scores=False, step_hook=
             ev1.record()
             stats['step_events'] = (ev0, ev1, max(0, n_body - done))      # per-token step time = elapsed / count (bench.py)
             stats['graph'] = graph is not None
+            stats['replayer'] = plan is not None
+            if graph is not None:
+                _last_graph[torch.device(dev).index] = graph
+            if plan is not None:
+                _PLANS.append((plan, graph, torch.cuda.Event()))
+                _PLANS[-1][2].record()
+                _reap_plans()
             if fused_book:
                 book_kernel(True)                                        # t = max_len - 1: every live beam is closed
             else:

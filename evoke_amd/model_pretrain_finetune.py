@@ -160,6 +160,100 @@ class FineTune(_Base):
             return [gen_texts, gt_texts]
         return [[t if len(t) > 0 else NO_FINDING for t in gen_texts], output]
 
+    @torch.no_grad()
+    def generate_pipelined(self, batches, mode='inference', depth=None):
+        """forward(..., mode=mode) over a sequence of batches, as a generator of its return values, with the device kept busy across
+        batches.  The decode of a batch is a chain of ~100 x ~56 small dependent kernels: latency bound, most of the GPU idles while it
+        runs, and the host can only issue it at the GPU's pace (a launch queue is finite).  So `depth` batches are decoded at the same time,
+        each on its own high-priority HIP stream with its own persistent beam session, the host issuing their token steps round-robin;
+        the visual extractor / fusion / text encoders of the following batch are queued on a further stream in between.  Per batch the
+        kernels, their order and therefore the results are exactly those of forward() (tests/test_model_gpu.py).  batches: iterable of
+        (images, report_ids, report_masks, patient_ids, inc_ids, inc_masks); r2gen decoder only.  depth: EVK_DECODE_DEPTH or 2."""
+        import os
+        from collections import deque
+        if mode not in ('sample', 'inference'):
+            raise ValueError
+        if self.decoder_kind != 'r2gen':
+            raise NotImplementedError('generate_pipelined: the r2gen decoder backend')
+        from .decode import beam_search
+        depth = max(1, int(depth if depth is not None else os.environ.get('EVK_DECODE_DEPTH', '2')))
+        was_training = self.training
+        self.eval()
+        cur = torch.cuda.current_stream()
+        enc_s = torch.cuda.Stream()
+        dec_s = [torch.cuda.Stream(priority=-1) for _ in range(depth)]     # the decode chains are latency bound: their small kernels go first
+        for st in [enc_s] + dec_s:
+            st.wait_stream(cur)
+
+        def encode(batch):
+            images, report_ids, report_masks, patient_ids, inc_ids, inc_masks = batch
+            with torch.cuda.stream(enc_s):
+                x, enc_mask = self.encoder_states(images, patient_ids, report_ids.shape[0], inc_ids, inc_masks)
+                ev = torch.cuda.Event()
+                ev.record(enc_s)
+            return x, enc_mask, ev, report_ids
+
+        def start(enc, slot):
+            """-> [slot, generator of the stepwise search, report ids, result or None]"""
+            x, enc_mask, ev, report_ids = enc
+            with torch.cuda.stream(dec_s[slot]):
+                dec_s[slot].wait_event(ev)
+                x.record_stream(dec_s[slot])
+                enc_mask.record_stream(dec_s[slot])
+                try:
+                    gen = beam_search(self.text_decoder, x, enc_mask, self.args, slot=slot, as_iterator=True)
+                    return [slot, gen, report_ids, None]
+                except NotImplementedError:              # no session path for this geometry: the whole search in one go
+                    return [slot, None, report_ids, beam_search(self.text_decoder, x, enc_mask, self.args)]
+
+        def advance(job):
+            """issue the next token step of a job; True when the search has been issued completely"""
+            if job[1] is None:
+                return True
+            with torch.cuda.stream(dec_s[job[0]]):
+                try:
+                    next(job[1])
+                    return False
+                except StopIteration as e:
+                    job[3] = e.value
+                    job[1] = None
+                    return True
+
+        def finish(job):
+            seq, report_ids = job[3], job[2]
+            with torch.cuda.stream(dec_s[job[0]]):
+                ids = seq.cpu()                      # waits for that decode stream only
+            gen_texts = self.tokenizer.decode_batch(ids.tolist())
+            gen_texts = [t if len(t) > 0 else NO_FINDING for t in gen_texts]
+            if mode == 'sample':
+                return [gen_texts, self.tokenizer.decode_batch(report_ids.cpu().tolist())]
+            return [gen_texts, seq]
+
+        try:
+            it = iter(batches)
+            jobs = deque()                           # in flight, oldest first
+            free = list(range(depth))
+            exhausted = False
+            while True:
+                while not exhausted and free:        # fill the free slots: encoders of the next batch, then its search joins the rotation
+                    batch = next(it, None)
+                    if batch is None:
+                        exhausted = True
+                        break
+                    jobs.append(start(encode(batch), free.pop(0)))
+                if not jobs:
+                    break
+                for job in list(jobs):               # one token step of every search in flight
+                    advance(job)
+                while jobs and jobs[0][1] is None:   # results leave in batch order
+                    job = jobs.popleft()
+                    yield finish(job)
+                    free.append(job[0])
+        finally:
+            for st in [enc_s] + dec_s:
+                cur.wait_stream(st)
+            self.train(was_training)
+
     def forward(self, images, report_ids, report_masks, patient_ids, inc_ids=None, inc_masks=None, mode='train'):
         if mode not in ('train', 'sample', 'inference'):
             raise ValueError

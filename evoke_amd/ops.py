@@ -241,6 +241,17 @@ def split_first_token(x):
     return _SplitFirst.apply(x)
 
 
+def copy_kernel(dst, src):
+    """dst[...] = src for two contiguous device tensors of one dtype and size, as a KERNEL (a word copy through evk_cast).  torch's
+    copy_ of such a pair is hipMemcpyAsync, which a stream capture records as a memcpy node -- and ROCm 7.2 does not report those nodes'
+    parameters back, so a captured launch sequence that is to be re-issued by the library's own replayer must not contain one."""
+    nb = dst.numel() * dst.element_size()
+    if dst.dtype != src.dtype or nb != src.numel() * src.element_size() or not (dst.is_contiguous() and src.is_contiguous()) or nb % 4:
+        return dst.copy_(src)
+    H.check(H.lib.evk_cast(H.ptr(src), H.F32, H.ptr(dst), H.F32, nb // 4, H.stream()), 'copy')
+    return dst
+
+
 def set_shadow_fresh(p, sh):
     """Used by the fused optimizer, which writes the bf16 shadow itself."""
     _shadows[id(p)] = (sh, p._version, p)
@@ -917,12 +928,12 @@ def attention(q, k, v, heads, mask=None, causal=False, p_drop=0.0, training=Fals
 # ----------------------------------------------------------------------------------------------------
 class _Embedding(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, ids, table, pos, extra, scale, padding_idx):
+    def forward(ctx, ids, table, pos, extra, scale, padding_idx, pos0=None):
         rows, L = ids.numel(), ids.shape[-1]
         D = table.shape[1]
         out = _e(*ids.shape, D, device=table.device)
         H.check(H.lib.evk_embedding_fwd(H.ptr(table), H.ptr(ids), H.ptr(pos), H.ptr(extra), H.ptr(out), H.BF16, rows, D, L,
-                                        C.c_float(scale), table.shape[0], H.stream()), 'embedding_fwd')
+                                        C.c_float(scale), table.shape[0], H.ptr(pos0), H.stream()), 'embedding_fwd')
         ctx.save_for_backward(ids)
         ctx.table, ctx.pos, ctx.extra, ctx.scale, ctx.padding_idx = table, pos, extra, scale, padding_idx
         return out
@@ -950,13 +961,13 @@ class _Embedding(torch.autograd.Function):
             H.check(H.lib.evk_embedding_bwd(H.ptr(dout), H.dt(dout), H.ptr(zid), H.ptr(grad_buffer(extra)), rows, D,
                                             C.c_float(1.0), -1, extra.shape[0], st), 'embedding_bwd')
             grad_done(extra)
-        return None, None, None, None, None, None
+        return None, None, None, None, None, None, None
 
 
-def embedding(ids, table, pos=None, extra=None, scale=1.0, padding_idx=-1):
+def embedding(ids, table, pos=None, extra=None, scale=1.0, padding_idx=-1, pos0=None):
     """out[r] = table[ids[r]]*scale + pos[r % L] + extra[0]; `pos` is a (>=L, D) table, `extra` a (types, D) table (row 0 used)."""
     assert ids.dtype == torch.long and ids.is_contiguous()
-    return _Embedding.apply(ids, table, pos, extra, float(scale), int(padding_idx))
+    return _Embedding.apply(ids, table, pos, extra, float(scale), int(padding_idx), pos0)
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -994,9 +1005,11 @@ def nll_loss(logits, target, wmask, V):
     return _NllLoss.apply(logits, target.contiguous(), wmask.contiguous(), V)
 
 
-def log_softmax(logits, V):
+def log_softmax(logits, V, out=None):
     """f32 [rows, ld] -> f32 log-probs [rows, V] (decode path, no autograd)."""
     rows, ld = _rows(logits), logits.shape[-1]
-    out = _e(rows, V, dtype=F32, device=logits.device)
+    if out is None:
+        out = _e(rows, V, dtype=F32, device=logits.device)
+    assert out.dtype == F32 and out.is_contiguous() and tuple(out.shape) == (rows, V)
     H.check(H.lib.evk_log_softmax_nll_fwd(H.ptr(logits), H.ptr(out), None, None, None, None, rows, V, ld, V, H.stream()), 'log_softmax')
     return out

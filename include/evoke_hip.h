@@ -302,10 +302,13 @@ int evk_topk_rows(const float* x, float* vals, int64_t* idx, int64_t rows, int32
  * being written.  In place: beam_sum [B][beam], beam_seq [B][beam][max_len], best_p [B], best_seq [B][max_len], and the
  * per-hypothesis state rows that follow their hypothesis -- mem [B*beam][mem_row] (16-bit relational memory) and anc
  * [B*beam][anc_cols] (self-attention cache row table), either may be NULL.  words [B*beam] receives the next input tokens.
- * force_end != 0 at the last position (every live beam is closed).  Ties -> lowest flat index. */
+ * force_end != 0 at the last position (every live beam is closed).  Ties -> lowest flat index.
+ * pos_advance (optional, may be `pos` itself) with ticket (one zero-initialised int32 in device memory, left at zero): after the
+ * bookkeeping the kernel seeds column pos + 1 of the row table with each hypothesis's own row and the LAST workgroup to finish writes
+ * *pos_advance = pos + 1 -- the loop counter of the captured decode step advances without a launch of its own. */
 int evk_beam_step(const float* logp, int32_t ld, int32_t V1, int32_t beam, int32_t B, int32_t max_len, const int64_t* pos, int32_t eos,
                   int32_t force_end, float* beam_sum, int64_t* beam_seq, float* best_p, int64_t* best_seq, int64_t* words, void* mem,
-                  int32_t mem_row, int32_t* anc, int32_t anc_cols, evk_stream_t stream);
+                  int32_t mem_row, int32_t* anc, int32_t anc_cols, int64_t* pos_advance, int32_t* ticket, evk_stream_t stream);
 /* F.normalize(p=2, eps=1e-12) rows, f32 */
 int evk_l2norm_fwd(const float* x, float* y, float* nrm, int64_t rows, int32_t D, evk_stream_t stream);
 int evk_l2norm_bwd(const float* dy, const float* y, const float* nrm, float* dx, int64_t rows, int32_t D, evk_stream_t stream);
@@ -373,7 +376,9 @@ int evk_act_bwd(const void* dy, const void* ref, void* dx, int64_t n, int32_t ac
  * (HF BertSelfOutput / BertOutput: dense -> dropout -> + residual, bert_model.py:359-362,437-440)               */
 int evk_dropout(const void* x, const void* resid, void* y, int64_t n, float p, uint64_t seed, evk_stream_t stream);
 int evk_embedding_fwd(const float* table, const int64_t* ids, const float* pos, const float* extra, void* out, int out_dtype,
-                      int64_t rows, int32_t D, int32_t L, float scale, int64_t table_rows, evk_stream_t stream);
+                      int64_t rows, int32_t D, int32_t L, float scale, int64_t table_rows, const int64_t* pos0_dev, evk_stream_t stream);
+/* pos0_dev (optional): device scalar added to the position index, pos[(r % L) + *pos0_dev] -- the decode step embeds one token per
+ * hypothesis at a position only the device knows (modules/encoder_decoder.py:226-243 PositionalEncoding at the current step) */
 /* ids outside [0, table_rows) are skipped in both directions (forward: the table term is 0): never a wild access */
 int evk_embedding_bwd(const void* dout, int d_dtype, const int64_t* ids, float* dtable, int64_t rows, int32_t D, float scale,
                       int64_t padding_idx, int64_t table_rows, evk_stream_t stream);

@@ -694,3 +694,28 @@ def test_bf16_storage_build_passes_the_gpu_suite():
     tail = '\n'.join((r.stdout + r.stderr).splitlines()[-30:])
     print(tail)
     assert r.returncode == 0, tail
+
+
+def test_pipelined_generation_equals_per_batch_inference():
+    """FineTune.generate_pipelined (encoders of batch k+1 on a second stream while batch k is decoded) returns, batch for batch, exactly
+    what forward(mode='inference') returns: three different batches (different images, view structure and indications)."""
+    from evoke_amd.model_pretrain_finetune import FineTune
+    from oracle import spec as S
+    args = dict(ARGS, max_seq_len=24, beam_size=3)
+    model = FineTune(args, load_tokenizer(), 'iu_xray')
+    load_procedural(model, S.finetune_spec(V))
+    model.eval()
+    batches = []
+    for k, name in enumerate(('beam224', 'ft224_inc', 'beam224_b4')):
+        inp = make_inputs(CASES[name], V)
+        batches.append((inp['images'].cuda() * (1.0 + 0.1 * k), inp['ids'].cuda(), inp['masks'].cuda(), np.array(inp['patient_ids']), inp['inc_ids'],
+                        inp['inc_masks']))
+    with torch.no_grad():
+        want = [model(*b, mode='inference') for b in batches]
+        got = list(model.generate_pipelined(batches, mode='inference'))
+        again = list(model.generate_pipelined(batches, mode='sample'))
+    assert len(got) == 3
+    for (wt, ws), (gt, gs), (st, sg) in zip(want, got, again):
+        assert torch.equal(ws.cpu(), gs.cpu()), 'pipelined generation changed the token ids'
+        assert wt == gt == st
+        assert isinstance(sg, list) and len(sg) == len(gt)

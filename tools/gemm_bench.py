@@ -72,6 +72,11 @@ CASES = [
     ('gemm 4608x512x512 NT', lambda: gemm_case(4608, 512, 512, 0, 0), 2 * 4608 * 512 * 512),
     ('gemm 960x768x768 NT', lambda: gemm_case(960, 768, 768, 0, 0), 2 * 960 * 768 * 768),
     ('gemm 3200x1536x512 NT', lambda: gemm_case(3200, 1536, 512, 0, 0), 2 * 3200 * 512 * 1536),
+    ('gemm 768x512x512 NT (rm decode)', lambda: gemm_case(768, 512, 512, 0, 0), 2 * 768 * 512 * 512),
+    ('gemm 768x1024x512 NT (rm decode)', lambda: gemm_case(768, 1024, 512, 0, 0), 2 * 768 * 512 * 1024),
+    ('gemm 256x4608x1536 NT (cln mlp 1)', lambda: gemm_case(256, 4608, 1536, 0, 0), 2 * 256 * 4608 * 1536),
+    ('gemm 256x512x512 NT (decode proj)', lambda: gemm_case(256, 512, 512, 0, 0), 2 * 256 * 512 * 512),
+    ('gemm 256x1448x512 NT (logits)', lambda: gemm_case(256, 1448, 512, 0, 0), 2 * 256 * 1448 * 512),
     ('gemm 96x512x512 NT (skinny)', lambda: gemm_case(96, 512, 512, 0, 0), 2 * 96 * 512 * 512),
 ]
 
