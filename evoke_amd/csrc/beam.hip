@@ -25,6 +25,7 @@ struct BeamP {
   long long* words;                   // [B*beam] out: tokens fed to the next decoder step
   bf16_t* mem; int mem_row;           // relational-memory state [B*beam][mem_row] (in place) or null
   int* anc; int anc_cols;             // cache row table [B*beam][anc_cols] (in place) or null
+  bf16_t* mem2;                       // optional second state row per hypothesis (same geometry as mem)
   long long* pos_out; int* ticket;    // advance: the LAST workgroup to finish writes *pos_out = pos + 1 (every workgroup has read pos by then)
 };
 
@@ -114,6 +115,16 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const BeamP p) {
       gm[i] = l_mem[(win_i[j] / p.V1) * mw + c];
     }
   }
+  if (p.mem2) {                         // second state: through the same staging buffer, after the first has left it
+    __syncthreads();
+    uint32_t* gm = reinterpret_cast<uint32_t*>(p.mem2 + (long)b * beam * p.mem_row);
+    for (int i = tid; i < beam * mw; i += 256) l_mem[i] = gm[i];
+    __syncthreads();
+    for (int i = tid; i < beam * mw; i += 256) {
+      const int j = i / mw, c = i - j * mw;
+      gm[i] = l_mem[(win_i[j] / p.V1) * mw + c];
+    }
+  }
   // ---- 3. finished beams (best p so far; the earlier / lower beam index wins ties), the -1000 penalty, next tokens
   if (tid == 0) {
     float pv = -INFINITY; int pi = -1;
@@ -152,17 +163,18 @@ extern "C" {
 
 int evk_beam_step(const float* logp, int32_t ld, int32_t V1, int32_t beam, int32_t B, int32_t max_len, const int64_t* pos, int32_t eos,
                   int32_t force_end, float* beam_sum, int64_t* beam_seq, float* best_p, int64_t* best_seq, int64_t* words, void* mem,
-                  int32_t mem_row, int32_t* anc, int32_t anc_cols, int64_t* pos_advance, int32_t* ticket, evk_stream_t stream) {
+                  int32_t mem_row, int32_t* anc, int32_t anc_cols, int64_t* pos_advance, int32_t* ticket, void* mem2, evk_stream_t stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   EVK_REQUIRE(logp && pos && beam_sum && beam_seq && best_p && best_seq && words && B > 0 && V1 > 0 && ld >= V1 && max_len > 0, "beam_step: bad args");
   EVK_REQUIRE(beam >= 1 && beam <= KMAX && beam <= V1, "beam_step: beam must be in [1, %d]", KMAX);
   EVK_REQUIRE((!mem || (mem_row > 0 && mem_row % 2 == 0)) && (!anc || anc_cols > 0), "beam_step: bad state geometry");
   EVK_REQUIRE(!pos_advance || ticket, "beam_step: advancing the position needs a (zero-initialised) ticket word");
+  EVK_REQUIRE(!mem2 || mem, "beam_step: mem2 needs mem");
   const size_t lds = (size_t)beam * max_len * 8 + (anc ? (size_t)beam * anc_cols * 4 : 0) + (mem ? (size_t)beam * mem_row * 2 : 0);
   EVK_REQUIRE(lds <= 60000, "beam_step: %zu bytes of per-sample state do not fit the staging buffer", lds);
   BeamP p{logp, ld, V1, beam, max_len, eos, force_end, reinterpret_cast<const long long*>(pos), beam_sum, reinterpret_cast<long long*>(beam_seq),
           best_p, reinterpret_cast<long long*>(best_seq), reinterpret_cast<long long*>(words), (bf16_t*)mem, mem_row, anc, anc_cols,
-          reinterpret_cast<long long*>(pos_advance), ticket};
+          (bf16_t*)mem2, reinterpret_cast<long long*>(pos_advance), ticket};
   ProfScope ps(EVK_FAM_NORM, s);
   hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(256), lds, s, p);
   return evk_check_launch("beam_step");

@@ -695,6 +695,56 @@ int evk_rm_forward(const void* xk, const void* xv, const void* gw, const void* m
   return evk_check_launch("rm_forward");
 }
 
+/* ONE generated token of the relational memory for R hypotheses (RelationalMemory.forward_step, modules/encoder_decoder.py:274-291, as
+ * driven by CaptionModel.beam_search through EncoderDecoder.core): 8 launches, the state updated IN PLACE.
+ *   x [B][512]          the token embeddings of the step (16-bit)
+ *   Wx [2048][512], bx  = [attn.linears.1; attn.linears.2; W] stacked: the three projections of x_t in one product
+ *   mem [B][3][512]     the memory, in / out;  tmem [B][3][512] = tanh(mem), in / out (kept beside it so that the gate product
+ *                       U.tanh(m) needs neither a copy nor an activation pass; the caller re-orders both with the hypotheses)
+ *   out [B][1536]       the memory row the conditional layer norms of the decoder read (= the new memory)
+ *   ws                  >= evk_rm_decode_ws_bytes(B)                                                                         */
+int64_t evk_rm_decode_ws_bytes(int32_t B) {
+  const long R = (long)B * S_;
+  return ((long)B * 2048 + R * 1536 + 4 * R * D_ + R * 2 * D_) * 2 + (long)B * HEADS * S_ * KEYS * 4 + 4096;
+}
+
+int evk_rm_decode_step(const void* x, const void* Wx, const float* bx, void* mem, void* tmem, const void* Wqkv, const float* bqkv, const void* Wo,
+                       const float* bo, const void* W0, const float* b0, const void* W2, const float* b2, const void* U, const float* bU, void* out,
+                       void* ws, int64_t ws_bytes, int32_t B, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(x && Wx && bx && mem && tmem && Wqkv && bqkv && Wo && bo && W0 && b0 && W2 && b2 && U && bU && out && ws && B > 0,
+              "rm_decode_step: null/empty argument");
+  EVK_REQUIRE(ws_bytes >= evk_rm_decode_ws_bytes(B), "rm_decode_step: workspace too small");
+  const long R = (long)B * S_, RD = R * D_;
+  char* p = reinterpret_cast<char*>(ws);
+  auto take = [&](long elems) { bf16_t* r = reinterpret_cast<bf16_t*>(p); p += ((elems * 2 + 255) / 256) * 256; return r; };
+  bf16_t* xp = take((long)B * 2048);
+  bf16_t* qkv = take(R * 1536);
+  bf16_t* a = take(RD); bf16_t* nm1 = take(RD); bf16_t* h1 = take(RD); bf16_t* h2 = take(RD);
+  bf16_t* gu = take(R * 2 * D_);
+  float* P = reinterpret_cast<float*>(p);
+  bf16_t* m = (bf16_t*)mem;
+  bf16_t* tm = (bf16_t*)tmem;
+  if (int e = gemm(x, Wx, xp, B, 2048, D_, EVK_B_PLAIN, D_, bx, nullptr, EVK_ACT_NONE, stream)) return e;        // xk | xv | gates(x)
+  if (int e = gemm(m, Wqkv, qkv, (int)R, 1536, D_, EVK_B_PLAIN, D_, bqkv, nullptr, EVK_ACT_NONE, stream)) return e;
+  AttP ap{qkv, xp, xp + D_, 2048L, P, a, 0.f, 0ULL, nullptr, nullptr, nullptr, nullptr, evk_seed_epoch_ptr()};
+  {
+    ProfScope ps(EVK_FAM_NORM, s);
+    hipLaunchKernelGGL(rm_attn_fwd_kernel, dim3(B), dim3(256), 0, s, ap);
+  }
+  if (int e = gemm(a, Wo, nm1, (int)R, D_, D_, EVK_B_PLAIN, D_, bo, m, EVK_ACT_NONE, stream)) return e;
+  if (int e = gemm(nm1, W0, h1, (int)R, D_, D_, EVK_B_PLAIN, D_, b0, nullptr, EVK_ACT_RELU, stream)) return e;
+  if (int e = gemm(h1, W2, h2, (int)R, D_, D_, EVK_B_PLAIN, D_, b2, nullptr, EVK_ACT_RELU, stream)) return e;
+  if (int e = gemm(tm, U, gu, (int)R, 2 * D_, D_, EVK_B_PLAIN, D_, bU, nullptr, EVK_ACT_NONE, stream)) return e;
+  // every element of m / tm is read and rewritten by the same thread: in place
+  GateP gp{xp + 2 * D_, 2048L, gu, nm1, h2, m, m, tm, (bf16_t*)out, (long)S_ * D_, nullptr, nullptr, nullptr, B};
+  {
+    ProfScope ps(EVK_FAM_ELTWISE, s);
+    hipLaunchKernelGGL(rm_gate_fwd2_kernel, dim3(ew_blocks(RD)), dim3(256), 0, s, gp);
+  }
+  return evk_check_launch("rm_decode_step");
+}
+
 /* Backward through the recurrence (BPTT) with the workspace evk_rm_forward filled.
  *   Wqkvt [512][1536], Wot, W0t, W2t [512][512], Ut [512][1024]: the TRANSPOSED bf16 weights (so every data-gradient
  *   product is the K-contiguous form the latency-optimised small-GEMM kernel takes)

@@ -29,6 +29,7 @@ _FUSED_APPEND = [os.environ.get('EVK_DECODE_FUSED_APPEND', '1') != '0']  # K / V
 _FUSED_LN = [os.environ.get('EVK_DECODE_FUSED_LN', 'off')]
 _SPLIT_CLN = [os.environ.get('EVK_DECODE_SPLIT_CLN', '1') != '0']       # first conditional-norm MLP layer as two launches (see cln_deltas)
 _FUSED_BOOK = [os.environ.get('EVK_DECODE_FUSED_BOOK', '1') != '0']      # beam bookkeeping as one kernel per token (csrc/beam.hip)
+_RM_STEP = [os.environ.get('EVK_DECODE_RM_STEP', '1') != '0']          # relational-memory step as one native call (evk_rm_decode_step)
 _REPLAYER = [os.environ.get('EVK_DECODE_REPLAYER', '1') != '0']      # re-issue the captured step with csrc/replay.hip instead of hipGraphLaunch
 stats = {}                       # facts about the last beam_search call (bench.py reads the per-token step time from here)
 _PLANS = []                      # (plan, graph, event recorded after the last replay): destroyed once the GPU has passed the event
@@ -132,6 +133,14 @@ class _FusedDecodeWeights:
         self.geff, self.beff = geff, beff
         self.qkv_w = [torch.cat([l.self_attn.linears[i].weight.detach() for i in range(3)], 0).to(BF16).contiguous() for l in dec.layers]
         self.qkv_b = [torch.cat([l.self_attn.linears[i].bias.detach() for i in range(3)], 0).float().contiguous() for l in dec.layers]
+        # relational memory: the three projections of the token embedding (keys, values, gates) as one product, q | k | v of the memory as one
+        rm = model.rm
+        lin = rm.attn.linears
+        self.rm_wx = torch.cat([lin[1].weight.detach(), lin[2].weight.detach(), rm.W.weight.detach()], 0).to(BF16).contiguous()      # (2048, 512)
+        self.rm_bx = torch.cat([lin[1].bias.detach(), lin[2].bias.detach(), rm.W.bias.detach()], 0).float().contiguous()
+        self.rm_wqkv = torch.cat([lin[i].weight.detach() for i in range(3)], 0).to(BF16).contiguous()                                 # (1536, 512)
+        self.rm_bqkv = torch.cat([lin[i].bias.detach() for i in range(3)], 0).float().contiguous()
+        self.rm_rest = [(m.weight.detach().to(BF16).contiguous(), m.bias.detach().float().contiguous()) for m in (lin[3], rm.mlp[0], rm.mlp[2], rm.U)]
 
     def cln_deltas(self, memory):
         """memory (R, 1, slots*d) -> (18, R, d) bf16: [2i] = delta gamma, [2i+1] = delta beta of conditional norm i (bias folded out)."""
@@ -202,6 +211,7 @@ class _DecoderState:
         self.mem = model.rm.init_memory(R, enc.device)
         self.t = 0
         self.anc = self.rows = None      # cache row table of the graph-mode steps (step_static)
+        self.tmem = None                 # tanh(memory), kept beside the memory by the session path (evk_rm_decode_step)
         self.fused = _fused_weights(model)
         self.kc, self.vc, self.ks, self.vs = [], [], [], []
         for i, layer in enumerate(model.decoder.layers):
@@ -255,9 +265,21 @@ class _DecoderState:
         # the positional row is picked on the device (pos is a device scalar inside the captured step)
         emb = ops.embedding(it.view(-1, 1).contiguous(), model.tgt_embed[0].lut.weight, pos=model.tgt_embed[1].pe[0], scale=math.sqrt(model.d_model),
                             pos0=pos)
-        memory, new_mem = model.rm.run(emb, self.mem)
-        ops.copy_kernel(self.mem, new_mem)
         fw, d = self.fused, model.d_model
+        if self.tmem is not None and _RM_STEP[0]:
+            # the whole relational-memory step in one native call: 8 launches, memory and tanh(memory) updated in place
+            Rh = emb.shape[0]
+            if getattr(self, 'rm_ws', None) is None:
+                self.rm_ws = torch.empty(H.lib.evk_rm_decode_ws_bytes(Rh), dtype=torch.uint8, device=emb.device)
+                self.rm_out = torch.empty(Rh, 1, self.mem[0].numel(), dtype=BF16, device=emb.device)
+            (wo, bo), (w0, b0), (w2, b2), (wu, bu) = fw.rm_rest
+            H.check(H.lib.evk_rm_decode_step(H.ptr(emb), H.ptr(fw.rm_wx), H.ptr(fw.rm_bx), H.ptr(self.mem), H.ptr(self.tmem), H.ptr(fw.rm_wqkv),
+                                             H.ptr(fw.rm_bqkv), H.ptr(wo), H.ptr(bo), H.ptr(w0), H.ptr(b0), H.ptr(w2), H.ptr(b2), H.ptr(wu), H.ptr(bu),
+                                             H.ptr(self.rm_out), H.ptr(self.rm_ws), self.rm_ws.numel(), Rh, H.stream()), 'rm_decode_step')
+            memory = self.rm_out
+        else:
+            memory, new_mem = model.rm.run(emb, self.mem)
+            ops.copy_kernel(self.mem, new_mem)
         deltas = fw.cln_deltas(memory)
         x = emb
         ln_ok = d == 512 and x.shape[0] <= 4096
@@ -381,7 +403,7 @@ class _BeamSession:
         H.check(H.lib.evk_beam_step(H.ptr(lp), lp.shape[-1], dec.vocab_size + 1, self.beam, self.B, self.max_len, H.ptr(self.pos), dec.eos_idx,
                                     int(last), H.ptr(self.beam_sum), H.ptr(self.beam_seq), H.ptr(self.best_p), H.ptr(self.best_seq),
                                     H.ptr(self.words), H.ptr(st.mem), st.mem[0].numel(), H.ptr(st.anc), st.anc.shape[1],
-                                    None if last else H.ptr(self.pos), H.ptr(self.ticket), H.stream()), 'beam_step')
+                                    None if last else H.ptr(self.pos), H.ptr(self.ticket), H.ptr(st.tmem), H.stream()), 'beam_step')
 
     def _body(self):
         """positions 1 .. max_len-2: bookkeeping at position `pos` (which also advances it), then the decoder step that writes pos + 1"""
@@ -444,6 +466,10 @@ class _BeamSession:
         if max_len > 1:
             # the B -> B*beam expansion: every hypothesis inherits its sample's memory and position-0 keys / values
             ops.copy_kernel(st.mem, st0.mem.index_select(0, state_ix).contiguous())
+            if _RM_STEP[0]:
+                if st.tmem is None:
+                    st.tmem = torch.empty_like(st.mem)
+                H.check(H.lib.evk_act_fwd(H.ptr(st.mem), H.ptr(st.tmem), st.mem.numel(), H.ACT_TANH, H.stream()), 'act_fwd')
             for i in range(len(st.ks)):
                 st.ks[i][:, :1] = st0.ks[i][:, :1].index_select(0, state_ix)
                 st.vs[i][:, :1] = st0.vs[i][:, :1].index_select(0, state_ix)
@@ -631,7 +657,7 @@ def _beam_search_legacy(dec, enc_states, enc_mask, args, return_scores=False, st
             lp = logp[0]
             H.check(H.lib.evk_beam_step(H.ptr(lp), lp.shape[-1], V1, beam, B, max_len, H.ptr(pos), dec.eos_idx, int(last), H.ptr(beam_sum),
                                         H.ptr(beam_seq), H.ptr(best_p), H.ptr(best_seq), H.ptr(words), H.ptr(st.mem), st.mem[0].numel(),
-                                        H.ptr(st.anc), st.anc.shape[1], None if last else H.ptr(pos), H.ptr(ticket), H.stream()), 'beam_step')
+                                        H.ptr(st.anc), st.anc.shape[1], None if last else H.ptr(pos), H.ptr(ticket), None, H.stream()), 'beam_step')
             return words
 
         nb = 1

@@ -181,7 +181,9 @@ class FineTune(_Base):
         self.eval()
         cur = torch.cuda.current_stream()
         enc_s = torch.cuda.Stream()
-        dec_s = [torch.cuda.Stream(priority=-1) for _ in range(depth)]     # the decode chains are latency bound: their small kernels go first
+        # the decode chains are latency bound: their small kernels go first.  (EVK_DECODE_PRIO: comma list of stream priorities)
+        prios = [int(v) for v in os.environ.get('EVK_DECODE_PRIO', '').split(',') if v.strip() != '']
+        dec_s = [torch.cuda.Stream(priority=(prios[i] if i < len(prios) else -1)) for i in range(depth)]
         for st in [enc_s] + dec_s:
             st.wait_stream(cur)
 

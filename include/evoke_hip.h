@@ -308,7 +308,8 @@ int evk_topk_rows(const float* x, float* vals, int64_t* idx, int64_t rows, int32
  * *pos_advance = pos + 1 -- the loop counter of the captured decode step advances without a launch of its own. */
 int evk_beam_step(const float* logp, int32_t ld, int32_t V1, int32_t beam, int32_t B, int32_t max_len, const int64_t* pos, int32_t eos,
                   int32_t force_end, float* beam_sum, int64_t* beam_seq, float* best_p, int64_t* best_seq, int64_t* words, void* mem,
-                  int32_t mem_row, int32_t* anc, int32_t anc_cols, int64_t* pos_advance, int32_t* ticket, evk_stream_t stream);
+                  int32_t mem_row, int32_t* anc, int32_t anc_cols, int64_t* pos_advance, int32_t* ticket, void* mem2, evk_stream_t stream);
+/* mem2 (optional): a second per-hypothesis state of mem_row 16-bit values re-ordered like mem (tanh of the relational memory) */
 /* F.normalize(p=2, eps=1e-12) rows, f32 */
 int evk_l2norm_fwd(const float* x, float* y, float* nrm, int64_t rows, int32_t D, evk_stream_t stream);
 int evk_l2norm_bwd(const float* dy, const float* y, const float* nrm, float* dx, int64_t rows, int32_t D, evk_stream_t stream);
@@ -471,6 +472,16 @@ int evk_rm_forward(const void* xk, const void* xv, const void* gw, const void* m
                    const float* bo, const void* W0, const float* b0, const void* W2, const float* b2, const void* U, const float* bU,
                    void* out, void* m_last, void* ws, int64_t ws_bytes, int32_t B, int32_t L, float p_drop, uint64_t seed,
                    evk_stream_t stream);
+/* ONE generated token of the relational memory for B hypotheses (RelationalMemory.forward_step, modules/encoder_decoder.py:274-291, as
+ * CaptionModel.beam_search drives it through EncoderDecoder.core, :396-404): 8 launches instead of the 13 of evk_rm_forward(L = 1) +
+ * its three hoisted projections, and the state updated IN PLACE.  x [B][512] token embeddings; Wx [2048][512] / bx = attn.linears.1,
+ * attn.linears.2 and W stacked (the three projections of x_t as one product); mem, tmem [B][3][512] = the memory and tanh(memory), in /
+ * out (the caller re-orders both with the hypotheses: evk_beam_step mem / mem2); out [B][1536] = the new memory row for the decoder's
+ * conditional layer norms.  Same kernels and arithmetic as evk_rm_forward: bit-identical results. */
+int64_t evk_rm_decode_ws_bytes(int32_t B);
+int evk_rm_decode_step(const void* x, const void* Wx, const float* bx, void* mem, void* tmem, const void* Wqkv, const float* bqkv, const void* Wo,
+                       const float* bo, const void* W0, const float* b0, const void* W2, const float* b2, const void* U, const float* bU, void* out,
+                       void* ws, int64_t ws_bytes, int32_t B, evk_stream_t stream);
 /* dxk, dxv, dgw are written; the f32 parameter gradients are accumulated (+=); W*t = transposed bf16 weights */
 int evk_rm_backward(const void* dout, const void* xk, const void* xv, const void* Wqkvt, const void* Wot, const void* W0t, const void* W2t,
                     const void* Ut, void* dxk, void* dxv, void* dgw, float* dWqkv, float* dbqkv, float* dWo, float* dbo, float* dW0,
