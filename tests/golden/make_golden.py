@@ -158,7 +158,28 @@ GRAD_KEYS = ['visual_extractor.model.0.weight', 'visual_extractor.model.7.2.conv
              'text_decoder.model.decoder.layers.0.sublayer.1.norm.mlp_gamma.0.weight',
              'text_decoder.model.decoder.layers.2.src_attn.linears.2.weight',
              'text_decoder.model.encoder.layers.0.self_attn.linears.0.weight',
-             'text_decoder.model.tgt_embed.0.lut.weight', 'text_decoder.att_embed.0.weight']
+             'text_decoder.model.tgt_embed.0.lut.weight', 'text_decoder.att_embed.0.weight',
+             # round 3: every stage of the trunk, every transformer family, biases and norm parameters (66 tensors in all)
+             'visual_extractor.model.1.weight', 'visual_extractor.model.1.bias',
+             'visual_extractor.model.4.0.conv1.weight', 'visual_extractor.model.4.0.conv2.weight', 'visual_extractor.model.4.0.downsample.0.weight',
+             'visual_extractor.model.4.2.bn3.weight', 'visual_extractor.model.4.2.bn3.bias',
+             'visual_extractor.model.5.0.conv2.weight', 'visual_extractor.model.5.0.downsample.1.bias', 'visual_extractor.model.5.3.conv1.weight',
+             'visual_extractor.model.6.0.conv1.weight', 'visual_extractor.model.6.0.downsample.0.weight', 'visual_extractor.model.6.5.conv2.weight',
+             'visual_extractor.model.6.11.conv3.weight', 'visual_extractor.model.6.17.bn1.weight', 'visual_extractor.model.6.22.conv2.weight',
+             'visual_extractor.model.6.22.bn2.bias', 'visual_extractor.model.7.0.conv2.weight', 'visual_extractor.model.7.0.downsample.0.weight',
+             'visual_extractor.model.7.1.conv1.weight', 'visual_extractor.model.7.2.bn3.weight',
+             'layer_norm_1.weight', 'layer_norm_1.bias', 'multiview_cross_attention.fc_v.weight', 'multiview_cross_attention.fc_o.weight',
+             'multiview_cross_attention.fc_o.bias', 'visual_head.head.1.weight', 'visual_head.head.3.weight', 'text_head.head.0.weight',
+             'text_encoder.encoder.embeddings.LayerNorm.weight', 'text_encoder.encoder.encoder.layer.0.attention.self.query.weight',
+             'text_encoder.encoder.encoder.layer.2.intermediate.dense.weight', 'text_encoder.encoder.encoder.layer.3.attention.output.dense.bias',
+             'multimodal_fusion_layers.0.attention.self.value.weight', 'multimodal_fusion_layers.0.crossattention.output.dense.weight',
+             'multimodal_fusion_layers.0.intermediate.dense.weight', 'multimodal_fusion_layers.0.output.LayerNorm.weight',
+             'visual_self_atten_layers.0.intermediate.dense.weight', 'visual_self_atten_layers.0.output.dense.bias',
+             'text_decoder.logit.bias', 'text_decoder.model.rm.U.weight', 'text_decoder.model.rm.mlp.0.weight', 'text_decoder.model.rm.attn.linears.3.weight',
+             'text_decoder.model.decoder.layers.0.self_attn.linears.0.weight', 'text_decoder.model.decoder.layers.1.feed_forward.w_1.weight',
+             'text_decoder.model.decoder.layers.1.sublayer.0.norm.gamma', 'text_decoder.model.decoder.layers.2.sublayer.2.norm.mlp_beta.2.weight',
+             'text_decoder.model.encoder.layers.2.feed_forward.w_2.weight', 'text_decoder.model.encoder.norm.gamma',
+             'text_decoder.model.decoder.norm.beta']
 
 
 def run_case(name, case, tmp, tokenizer):
