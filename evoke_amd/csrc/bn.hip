@@ -242,6 +242,31 @@ __global__ __launch_bounds__(256) void bn_bwd_sums_from_gate_kernel(const float*
   }
 }
 
+// Many partial rows, few channels (layer1: 9216 rows of 64-256 columns against 8-32 finalize workgroups): the second reduction stage spent
+// 46-58 us in one dependent row loop per workgroup.  A fully parallel FOLD first adds rows r, r + h, r + 2h, ... into row r, in place
+// (row r is written only by the threads that read it; every other row they read lies beyond h and is never written): the stage that
+// follows walks h = nblk / 16 rows.
+__global__ __launch_bounds__(256) void part_fold_kernel(float* __restrict__ part, int nblk, int h, int ld4) {
+  const long total = (long)h * ld4;                         // float4 elements of the folded rows
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / ld4), c = (int)(i - (long)r * ld4);
+    float4* row = reinterpret_cast<float4*>(part) + c;
+    float4 a = row[(long)r * ld4];
+    for (int q = r + h; q < nblk; q += h) { const float4 t = row[(long)q * ld4]; a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; }
+    row[(long)r * ld4] = a;
+  }
+}
+constexpr int FOLD_MIN_ROWS = 1024, FOLD_FACTOR = 16;
+// folds `part` (nblk rows of ld floats) when it pays; returns the row count the next stage has to walk
+static int maybe_fold(float* part, int nblk, int ld, hipStream_t s) {
+  static const int on = [] { const char* e = getenv("EVK_BN_FOLD"); return e ? atoi(e) : 1; }();
+  if (!on || nblk < FOLD_MIN_ROWS || (ld & 3) || (reinterpret_cast<uintptr_t>(part) & 15)) return nblk;
+  const int h = (nblk + FOLD_FACTOR - 1) / FOLD_FACTOR;
+  const long total = (long)h * (ld / 4);
+  hipLaunchKernelGGL(part_fold_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, s, part, nblk, h, ld / 4);
+  return h;
+}
+
 // colreduce_final + bn_finalize in ONE launch for the training forward of the trunk (two dependent ~5 us launches on the critical
 // path of each of the 104 convolutions otherwise): a block sums the partial rows of 8 channels -- 16 columns: their sums and their
 // sums of squares -- with 16 row-lanes, then 8 threads finish the statistics of those channels.
@@ -611,6 +636,7 @@ int evk_bn_bwd_sums_from_gate_partials(const float* part, int32_t nblk, const fl
               "bn_bwd_sums_from_gate_partials: the exact fallback needs dz, y (16-byte aligned), mean, invstd and M");
   ProfScope ps(EVK_FAM_REDUCE, s);
   const GateExact ex{(const bf16_t*)dz, (const bf16_t*)y, mean, invstd, (long)M};
+  nblk = maybe_fold(const_cast<float*>(part), nblk, 2 * C, s);          // (the partial rows are scratch: consumed here, dead afterwards)
   hipLaunchKernelGGL(bn_bwd_sums_from_gate_kernel, dim3(C / 8), dim3(256), 0, s, part, (int)nblk, gamma, beta, sum_g, sum_gx, dbeta_acc, dgamma_acc, (int)C, 2, nullptr, ex);
   return evk_check_launch("bn_bwd_sums_from_gate_partials");
 }
@@ -620,6 +646,7 @@ int evk_bn_bwd_sums_from_xstat_partials(const float* part, int32_t nblk, const f
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   EVK_REQUIRE(part && invstd && sum_g && sum_gx && nblk > 0 && C > 0 && C % 8 == 0, "bn_bwd_sums_from_xstat_partials: bad args");
   ProfScope ps(EVK_FAM_REDUCE, s);
+  nblk = maybe_fold(const_cast<float*>(part), nblk, 3 * C, s);
   hipLaunchKernelGGL(bn_bwd_sums_from_gate_kernel, dim3(C / 8), dim3(256), 0, s, part, (int)nblk, nullptr, nullptr, sum_g, sum_gx, dbeta_acc, dgamma_acc, (int)C, 3,
                      invstd, GateExact{nullptr, nullptr, nullptr, nullptr, 0});
   return evk_check_launch("bn_bwd_sums_from_xstat_partials");
@@ -632,6 +659,7 @@ int evk_bn_stats_finalize_from_partials(const float* part, int32_t nblk, float* 
   EVK_REQUIRE(part && sum && sumsq && scale && shift && mean && invstd && nblk > 0 && C > 0 && C % 8 == 0 && count > 0, "bn_stats_finalize_from_partials: bad args");
   FinP p{sum, sumsq, gamma, beta, running_mean, running_var, scale, shift, mean, invstd, C, count, momentum, eps, 1};
   ProfScope ps(EVK_FAM_REDUCE, s);
+  nblk = maybe_fold(const_cast<float*>(part), nblk, 2 * C, s);          // (the partial rows are scratch: consumed here, dead afterwards)
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C / 8), dim3(256), 0, s, part, (int)nblk, sum, sumsq, p);
   return evk_check_launch("bn_stats_finalize_from_partials");
 }

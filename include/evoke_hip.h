@@ -328,7 +328,10 @@ int evk_bn_stats_from_partials(const float* part, int32_t nblk, float* sum, floa
 int evk_bn_finalize(const float* sum, const float* sumsq, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float* scale, float* shift, float* mean, float* invstd, int32_t C, float count,
                     float momentum, float eps, int32_t training, evk_stream_t stream);
-/* Batch-norm backward sums without a pass over the gradient: `part` = nblk rows of [2][C] partial sums (sum g, sum g*z) written by
+/* (`part` is SCRATCH for the three *_from_partials entry points: with >= 1024 partial rows they first fold rows r, r + h, r + 2h, ...
+ * into row r in place with a fully parallel launch, h = nblk / 16 -- layer1's 9216 rows of 64-256 columns kept 8-32 workgroups in a
+ * 46-58 us dependent row loop otherwise -- so its contents are undefined afterwards.)
+ * Batch-norm backward sums without a pass over the gradient: `part` = nblk rows of [2][C] partial sums (sum g, sum g*z) written by
  * the epilogue of the data-gradient GEMM that produced g gated by z > 0 (evk_conv2d_dgrad_gated_stats), z = relu(gamma*xhat + beta)
  * the layer's own forward output.  Where the gate is open xhat = (z - beta) / gamma, so sum_g = sum g and sum_gx = (sum g*z - beta *
  * sum g) / gamma (0 for gamma == 0, where dx vanishes anyway); dbeta_acc += sum_g, dgamma_acc += sum_gx when given.
