@@ -407,6 +407,98 @@ def test_optim_step_matches_torch():
         assert float(pd2[7]) == float(p0[7]) and float(m2[7]) == 0.0
 
 
+@pytest.mark.parametrize('kind', [0, 1])
+def test_optim_group_step_per_parameter_counts_and_device_hyperparameters(kind):
+    """evk_optim_group_step through the C ABI: one flat group of five parameters (sizes that are not multiples of the 8-element padding)
+    against torch.optim.RAdam / Adam(amsgrad) run PER PARAMETER: the parameters join in at different steps and sit some steps out (the
+    touched mask), so their step counts differ inside one launch; the learning rate changes half way through by rewriting the device
+    buffer only; a step with the overflow flag set moves nothing and advances no count; gradients arrive scaled by 512 and summed over a
+    world of 2 and are consumed (zeroed) by the kernel."""
+    import ctypes as C
+    from evoke_amd import hip as H
+    sizes = [37, 1024, 8, 4099, 640]
+    offs, tot = [], 0
+    for n in sizes:
+        offs.append(tot)
+        tot += (n + 7) // 8 * 8
+    g = torch.Generator().manual_seed(4)
+    p0 = [torch.randn(n, generator=g) for n in sizes]
+    ref = [torch.nn.Parameter(t.clone()) for t in p0]
+    mk = (lambda ps, lr: torch.optim.RAdam(ps, lr=lr, weight_decay=1e-4)) if kind == 0 else (lambda ps, lr: torch.optim.Adam(ps, lr=lr, weight_decay=1e-4, amsgrad=True))
+    ropt = [mk([q], 5e-3) for q in ref]
+    flat = {k: torch.zeros(tot, device='cuda') for k in ('p', 'g', 'm', 'v', 'vm')}
+    sh = torch.zeros(tot, dtype=BF, device='cuda')
+    for t, o in zip(p0, offs):
+        flat['p'][o:o + t.numel()] = t.cuda()
+    steps = torch.zeros(len(sizes), dtype=torch.int32, device='cuda')
+    offs_dev = torch.tensor(offs, dtype=torch.int64, device='cuda')
+    coef = torch.zeros(4 * len(sizes), device='cuda')
+    hp = torch.tensor([5e-3, 0.9, 0.999, 1e-8, 1e-4, 0.1, 0, 0], dtype=torch.float32, device='cuda')
+    state = torch.tensor([512.0, 0.0, 0.0, 0.0], device='cuda')
+    masks = [[1, 1, 0, 1, 0], [1, 0, 0, 1, 0], [1, 1, 0, 1, 0], [0, 1, 1, 1, 0], [1, 1, 1, 0, 0], [1, 1, 1, 1, 1], [1, 0, 1, 1, 1], [1, 1, 1, 1, 1],
+             [1, 1, 1, 1, 1], [1, 1, 0, 1, 1]]
+    for it, mask in enumerate(masks):
+        if it == 4:                                             # an lr scheduler: only the device buffer changes
+            hp[0] = 1e-3
+            for o in ropt:
+                o.param_groups[0]['lr'] = 1e-3
+        overflow = it == 6
+        state[2] = 1.0 if overflow else 0.0
+        for i, (q, o) in enumerate(zip(ref, offs)):
+            gi = torch.randn(sizes[i], generator=g) * 0.2
+            if mask[i]:
+                flat['g'][o:o + sizes[i]] = (gi * 512.0 * 2.0).cuda()         # loss scale x sum over 2 ranks
+                if not overflow:
+                    q.grad = gi.clamp(-0.1, 0.1)
+                    ropt[i].step()
+        m = torch.tensor(mask, dtype=torch.uint8, device='cuda')
+        H.check(H.lib.evk_optim_group_step(H.ptr(flat['p']), H.ptr(flat['g']), H.ptr(flat['m']), H.ptr(flat['v']), H.ptr(flat['vm']) if kind == 1 else None,
+                                           H.ptr(sh), tot, kind, H.ptr(hp), H.ptr(offs_dev), len(sizes), H.ptr(steps), H.ptr(m), H.ptr(coef), H.ptr(state),
+                                           C.c_float(0.5), 1, H.stream()))
+        assert float(flat['g'].abs().sum()) == 0.0, 'gradients of the touched parameters are consumed'
+    want_steps = [sum(mk_[i] for j, mk_ in enumerate(masks) if j != 6) for i in range(len(sizes))]
+    assert steps.cpu().tolist() == want_steps, (steps.cpu().tolist(), want_steps)
+    assert len(set(want_steps)) > 2                                   # the counts really differ inside the one launch
+    for i, (q, o) in enumerate(zip(ref, offs)):
+        close(flat['p'][o:o + sizes[i]], q.detach(), 2e-5, 2e-6, 'parameter %d (kind %d)' % (i, kind))
+        close(sh[o:o + sizes[i]].float(), q.detach(), 1e-2, 1e-3, 'shadow %d' % i)
+
+
+def test_rm_decode_step_is_bit_identical_to_the_recurrence_runner():
+    """evk_rm_decode_step (one generated token of the relational memory: 8 launches, state in place) against evk_rm_forward with L = 1 fed
+    with the three hoisted projections (what RelationalMemory.run does): same kernels, same arithmetic -> torch.equal on the new memory,
+    on tanh(memory) and on the memory row handed to the decoder, over three consecutive tokens."""
+    import ctypes as C
+    from evoke_amd import hip as H, ops
+    from evoke_amd.layers import RelationalMemory
+    torch.manual_seed(2)
+    rm = RelationalMemory(3, 512, 8).cuda().eval()
+    B = 24
+    lin = rm.attn.linears
+    wx = torch.cat([lin[1].weight, lin[2].weight, rm.W.weight], 0).detach().to(BF).contiguous()
+    bx = torch.cat([lin[1].bias, lin[2].bias, rm.W.bias], 0).detach().float().contiguous()
+    wqkv = torch.cat([lin[i].weight for i in range(3)], 0).detach().to(BF).contiguous()
+    bqkv = torch.cat([lin[i].bias for i in range(3)], 0).detach().float().contiguous()
+    rest = [(m.weight.detach().to(BF).contiguous(), m.bias.detach().float().contiguous()) for m in (lin[3], rm.mlp[0], rm.mlp[2], rm.U)]
+    mem = rm.init_memory(B, 'cuda')
+    mem_b = mem.clone()
+    tmem = torch.empty_like(mem_b)
+    H.check(H.lib.evk_act_fwd(H.ptr(mem_b), H.ptr(tmem), mem_b.numel(), H.ACT_TANH, H.stream()))
+    ws = torch.empty(H.lib.evk_rm_decode_ws_bytes(B), dtype=torch.uint8, device='cuda')
+    out_b = torch.empty(B, 1, 1536, dtype=BF, device='cuda')
+    with torch.no_grad():
+        for t in range(3):
+            emb = (torch.randn(B, 1, 512, device='cuda') * 0.8).to(BF)
+            out_a, mem = rm.run(emb, mem)
+            (wo, bo), (w0, b0), (w2, b2), (wu, bu) = rest
+            H.check(H.lib.evk_rm_decode_step(H.ptr(emb), H.ptr(wx), H.ptr(bx), H.ptr(mem_b), H.ptr(tmem), H.ptr(wqkv), H.ptr(bqkv), H.ptr(wo), H.ptr(bo),
+                                             H.ptr(w0), H.ptr(b0), H.ptr(w2), H.ptr(b2), H.ptr(wu), H.ptr(bu), H.ptr(out_b), H.ptr(ws), ws.numel(), B,
+                                             H.stream()))
+            assert torch.equal(mem.reshape(-1), mem_b.reshape(-1)), 'memory after token %d' % t
+            assert torch.equal(out_a.reshape(-1), out_b.reshape(-1)), 'memory row after token %d' % t
+            assert torch.equal(tmem.float(), torch.tanh(mem_b.float()).to(BF).float()) or (tmem.float() - torch.tanh(mem_b.float())).abs().max() < 2e-3
+
+
 def test_conv_fwd_stats_and_dgrad_add():
     """conv epilogue batch-norm statistics (evk_conv2d_fwd_stats + evk_bn_stats_from_partials) and the fused skip-gradient
     add of the data gradient (evk_conv2d_dgrad_add) against f32 torch convolutions of the same bf16 operands."""
