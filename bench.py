@@ -118,7 +118,7 @@ def decode_record(model, a, rank, world, dev, with_cpu):
     replicas only.  One step = the whole FineTune.forward(mode='inference') of one batch (visual extractor + fusion + beam search);
     every hypothesis is extended for all max_seq_len steps as in the reference (finished beams keep running with -1000), so
     tokens = batch x max_seq_len per step.  Returns the record dict (rank 0) or None.
-    roofline: the per-token decode step (one HIP-graph replay: ~100 kernels) against HBM -- achieved = ALGORITHMIC bytes of one
+    roofline: the per-token decode step (one replay of the captured step: 52 kernels) against HBM -- achieved = ALGORITHMIC bytes of one
     step (the decoder-step weights once + per hypothesis the self-attention cache up to t, the cross-attention
     K/V of the 144 patches and the 1536-wide memory row, in 16-bit) / measured step time (HIP events around the replays)."""
     from evoke_amd import decode as DEC, hip as H, metrics
@@ -186,10 +186,12 @@ def decode_record(model, a, rank, world, dev, with_cpu):
                    'mean_generated_len': float((seq != 0).sum(1).float().mean().item()), 'hip_graph_step': DEC.stats.get('graph'),
                    'pipelined_encoders': pipelined, 'searches_in_flight': depth,
                    'fused_beam_bookkeeping': DEC.stats.get('fused_bookkeeping')},
-        'roofline': {'bound': 'hbm', 'kernel': 'per-token decode step (HIP graph: RM step, 3 decoder layers, logits, log-softmax, beam step)',
+        'roofline': {'bound': 'hbm', 'kernel': 'per-token decode step (captured once, re-issued by csrc/replay.hip: RM step, 3 decoder layers, logits, log-softmax, beam step = 52 launches)',
                      'achieved': ach, 'peak': 8000.0, 'unit': 'GB/s', 'frac': ach / 8000.0, 'traffic': None,
                      'algorithmic_bytes_per_step': alg_bytes, 'step_ms': per_step_ms, 'hypotheses': R, 'searches_in_flight': depth,
-                     'note': 'the step is launch-latency bound (~100 dependent kernels of a few us), not bandwidth bound'},
+                     'note': 'the step is a chain of 52 small dependent kernels; the device retires about one such kernel per 5 us however many streams feed it, so '
+                             '`searches_in_flight` independent searches are decoded at the same time (FineTune.generate_pipelined) and achieved = their '
+                             'algorithmic bytes per measured per-search step time; step_ms is that per-search step time under the overlap'},
     }
     if with_cpu:
         try:
