@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const bf16_t* __restrict__
 __global__ __launch_bounds__(256) void embedding_fwd_kernel(const float* __restrict__ table, const long long* __restrict__ ids,
                                                             const float* __restrict__ pos, const float* __restrict__ extra,
                                                             void* __restrict__ out, int out_f32, long rows, int D, int L, float scale, long long table_rows,
-                                                            const long long* __restrict__ pos0_dev) {
+                                                            const long long* __restrict__ pos0_dev, float* __restrict__ out2) {
   const long total = rows * D;
   const long pos0 = pos0_dev ? pos0_dev[0] : 0;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -87,6 +87,7 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(const float* __restr
     if (pos) v += pos[((r % L) + pos0) * D + c];
     if (extra) v += extra[c];
     stx(out, out_f32, i, v);
+    if (out2) out2[i] = v;
   }
 }
 // dtable[ids[r]][:] += dout[r][:] * scale  (rows with ids == padding_idx are skipped)
@@ -495,12 +496,12 @@ int evk_dropout(const void* x, const void* resid, void* y, int64_t n, float p, u
 }
 
 int evk_embedding_fwd(const float* table, const int64_t* ids, const float* pos, const float* extra, void* out, int out_dtype,
-                      int64_t rows, int32_t D, int32_t L, float scale, int64_t table_rows, const int64_t* pos0_dev, evk_stream_t stream) {
+                      int64_t rows, int32_t D, int32_t L, float scale, int64_t table_rows, const int64_t* pos0_dev, float* out_f32_copy, evk_stream_t stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   EVK_REQUIRE(table && ids && out && rows > 0 && D > 0 && L > 0 && table_rows > 0, "embedding_fwd: bad args");
   ProfScope ps(EVK_FAM_ELTWISE, s);
   hipLaunchKernelGGL(embedding_fwd_kernel, dim3(ew_blocks(rows * D)), dim3(256), 0, s, table, (const long long*)ids, pos, extra, out,
-                     out_dtype == EVK_F32, (long)rows, D, L, scale, (long long)table_rows, (const long long*)pos0_dev);
+                     out_dtype == EVK_F32, (long)rows, D, L, scale, (long long)table_rows, (const long long*)pos0_dev, out_f32_copy);
   return evk_check_launch("embedding_fwd");
 }
 

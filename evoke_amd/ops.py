@@ -928,12 +928,14 @@ def attention(q, k, v, heads, mask=None, causal=False, p_drop=0.0, training=Fals
 # ----------------------------------------------------------------------------------------------------
 class _Embedding(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, ids, table, pos, extra, scale, padding_idx, pos0=None):
+    def forward(ctx, ids, table, pos, extra, scale, padding_idx, pos0=None, out32=None):
         rows, L = ids.numel(), ids.shape[-1]
         D = table.shape[1]
         out = _e(*ids.shape, D, device=table.device)
+        if out32 is not None:
+            assert out32.dtype == F32 and out32.is_contiguous() and out32.numel() == rows * D
         H.check(H.lib.evk_embedding_fwd(H.ptr(table), H.ptr(ids), H.ptr(pos), H.ptr(extra), H.ptr(out), H.BF16, rows, D, L,
-                                        C.c_float(scale), table.shape[0], H.ptr(pos0), H.stream()), 'embedding_fwd')
+                                        C.c_float(scale), table.shape[0], H.ptr(pos0), H.ptr(out32), H.stream()), 'embedding_fwd')
         ctx.save_for_backward(ids)
         ctx.table, ctx.pos, ctx.extra, ctx.scale, ctx.padding_idx = table, pos, extra, scale, padding_idx
         return out
@@ -961,13 +963,14 @@ class _Embedding(torch.autograd.Function):
             H.check(H.lib.evk_embedding_bwd(H.ptr(dout), H.dt(dout), H.ptr(zid), H.ptr(grad_buffer(extra)), rows, D,
                                             C.c_float(1.0), -1, extra.shape[0], st), 'embedding_bwd')
             grad_done(extra)
-        return None, None, None, None, None, None, None
+        return None, None, None, None, None, None, None, None
 
 
-def embedding(ids, table, pos=None, extra=None, scale=1.0, padding_idx=-1, pos0=None):
-    """out[r] = table[ids[r]]*scale + pos[r % L] + extra[0]; `pos` is a (>=L, D) table, `extra` a (types, D) table (row 0 used)."""
+def embedding(ids, table, pos=None, extra=None, scale=1.0, padding_idx=-1, pos0=None, out32=None):
+    """out[r] = table[ids[r]]*scale + pos[r % L] + extra[0]; `pos` is a (>=L, D) table, `extra` a (types, D) table (row 0 used).
+    pos0: device scalar added to the position index; out32: optional f32 buffer that receives the same rows unrounded."""
     assert ids.dtype == torch.long and ids.is_contiguous()
-    return _Embedding.apply(ids, table, pos, extra, float(scale), int(padding_idx), pos0)
+    return _Embedding.apply(ids, table, pos, extra, float(scale), int(padding_idx), pos0, out32)
 
 
 # ----------------------------------------------------------------------------------------------------

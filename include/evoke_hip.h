@@ -380,9 +380,10 @@ int evk_act_bwd(const void* dy, const void* ref, void* dx, int64_t n, int32_t ac
  * (HF BertSelfOutput / BertOutput: dense -> dropout -> + residual, bert_model.py:359-362,437-440)               */
 int evk_dropout(const void* x, const void* resid, void* y, int64_t n, float p, uint64_t seed, evk_stream_t stream);
 int evk_embedding_fwd(const float* table, const int64_t* ids, const float* pos, const float* extra, void* out, int out_dtype,
-                      int64_t rows, int32_t D, int32_t L, float scale, int64_t table_rows, const int64_t* pos0_dev, evk_stream_t stream);
+                      int64_t rows, int32_t D, int32_t L, float scale, int64_t table_rows, const int64_t* pos0_dev, float* out_f32_copy, evk_stream_t stream);
 /* pos0_dev (optional): device scalar added to the position index, pos[(r % L) + *pos0_dev] -- the decode step embeds one token per
- * hypothesis at a position only the device knows (modules/encoder_decoder.py:226-243 PositionalEncoding at the current step) */
+ * hypothesis at a position only the device knows (modules/encoder_decoder.py:226-243 PositionalEncoding at the current step);
+ * out_f32_copy (optional): the same rows unrounded, for the f32 relational memory of the decode step */
 /* ids outside [0, table_rows) are skipped in both directions (forward: the table term is 0): never a wild access */
 int evk_embedding_bwd(const void* dout, int d_dtype, const int64_t* ids, float* dtable, int64_t rows, int32_t D, float scale,
                       int64_t padding_idx, int64_t table_rows, evk_stream_t stream);
@@ -485,6 +486,16 @@ int64_t evk_rm_decode_ws_bytes(int32_t B);
 int evk_rm_decode_step(const void* x, const void* Wx, const float* bx, void* mem, void* tmem, const void* Wqkv, const float* bqkv, const void* Wo,
                        const float* bo, const void* W0, const float* b0, const void* W2, const float* b2, const void* U, const float* bU, void* out,
                        void* ws, int64_t ws_bytes, int32_t B, evk_stream_t stream);
+/* evk_rm_decode_step in f32 (rm_f32.hip): the relational memory is a recurrence over every generated position and, on the fixtures' weights,
+ * an expanding one (1e-6 relative on its weights -> 3e-3 on the log-probabilities of position 99; 16-bit operands -> 0.3-0.5), so everything
+ * that feeds back into it stays f32: x [B][512] f32 token embeddings, mem [B][3][512] f32 in / out, the f32 MASTER weights Wx [2048][512] (=
+ * attn.linears.1 / .2 / W stacked), Wqkv [1536][512], Wo, W0, W2 [512][512], U [1024][512] and biases; products on the f32-input MFMA
+ * (v_mfma_f32_16x16x4_f32: a k-ordered fmaf chain).  out16 [B][1536] = the new memory in the 16-bit storage format for the decoder's
+ * conditional layer norms (that path does not feed back).  8 launches, like the 16-bit step. */
+int64_t evk_rm_decode_f32_ws_bytes(int32_t B);
+int evk_rm_decode_step_f32(const float* x, const float* Wx, const float* bx, float* mem, const float* Wqkv, const float* bqkv, const float* Wo,
+                           const float* bo, const float* W0, const float* b0, const float* W2, const float* b2, const float* U, const float* bU,
+                           void* out16, void* ws, int64_t ws_bytes, int32_t B, evk_stream_t stream);
 /* dxk, dxv, dgw are written; the f32 parameter gradients are accumulated (+=); W*t = transposed bf16 weights */
 int evk_rm_backward(const void* dout, const void* xk, const void* xv, const void* Wqkvt, const void* Wot, const void* W0t, const void* W2t,
                     const void* Ut, void* dxk, void* dxv, void* dgw, float* dWqkv, float* dbqkv, float* dWo, float* dbo, float* dW0,

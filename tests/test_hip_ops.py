@@ -499,6 +499,60 @@ def test_rm_decode_step_is_bit_identical_to_the_recurrence_runner():
             assert torch.equal(tmem.float(), torch.tanh(mem_b.float()).to(BF).float()) or (tmem.float() - torch.tanh(mem_b.float())).abs().max() < 2e-3
 
 
+def test_rm_decode_step_f32_follows_the_fp32_oracle_through_a_long_recurrence():
+    """evk_rm_decode_step_f32 (the decode step's relational memory on the f32-input MFMA, f32 masters, f32 state) against the oracle's
+    rm_step (CPU restatement of modules/encoder_decoder.py:274-291) over 60 consecutive tokens from the same inputs.  The recurrence
+    amplifies rounding (that is why it runs in f32), so the yardstick is the oracle itself: run in float64 it is the truth, run in float32
+    it shows what f32 arithmetic can do; the engine must stay within 4 x the f32 oracle's own distance from the truth (+ 1e-5).  The
+    16-bit row handed to the decoder must be the memory rounded."""
+    from evoke_amd import hip as H
+    from evoke_amd.layers import RelationalMemory
+    from oracle import functional as O
+    torch.manual_seed(6)
+    rm = RelationalMemory(3, 512, 8).cuda().eval()
+    with torch.no_grad():
+        for prm in rm.parameters():                      # a lively recurrence: larger weights than the Xavier init
+            if prm.dim() > 1:
+                prm.mul_(1.6)
+    pre = 'text_decoder.model.rm'
+    names = {'attn.linears.0': rm.attn.linears[0], 'attn.linears.1': rm.attn.linears[1], 'attn.linears.2': rm.attn.linears[2],
+             'attn.linears.3': rm.attn.linears[3], 'mlp.0': rm.mlp[0], 'mlp.2': rm.mlp[2], 'W': rm.W, 'U': rm.U}
+    P = {}
+    for k, m in names.items():
+        P['%s.%s.weight' % (pre, k)] = m.weight.detach().float().cpu()
+        P['%s.%s.bias' % (pre, k)] = m.bias.detach().float().cpu()
+    cfg = dict(O.DEFAULT_CFG)
+    B = 5
+    lin = rm.attn.linears
+    f = lambda t: t.detach().float().contiguous()          # noqa: E731
+    wx, bx = f(torch.cat([lin[1].weight, lin[2].weight, rm.W.weight], 0)), f(torch.cat([lin[1].bias, lin[2].bias, rm.W.bias], 0))
+    wqkv, bqkv = f(torch.cat([lin[i].weight for i in range(3)], 0)), f(torch.cat([lin[i].bias for i in range(3)], 0))
+    rest = [(f(m.weight), f(m.bias)) for m in (lin[3], rm.mlp[0], rm.mlp[2], rm.U)]
+    mem = rm.init_memory(B, 'cuda').float().contiguous()
+    ref = O.rm_init_memory(B, 3, 512).reshape(B, -1)
+    P64 = {k: v.double() for k, v in P.items()}
+    ref64 = ref.double()
+    ws = torch.empty(H.lib.evk_rm_decode_f32_ws_bytes(B), dtype=torch.uint8, device='cuda')
+    out16 = torch.empty(B, 1536, dtype=BF, device='cuda')
+    g = torch.Generator().manual_seed(8)
+    worst = worst32 = 0.0
+    with torch.no_grad():
+        for t in range(60):
+            x = torch.randn(B, 512, generator=g) * 0.9
+            ref = O.rm_step(P, x, ref, cfg, O.Ctx())
+            ref64 = O.rm_step(P64, x.double(), ref64, cfg, O.Ctx())
+            worst32 = max(worst32, float((ref.double() - ref64).abs().max()))
+            xd = x.cuda().contiguous()
+            (wo, bo), (w0, b0), (w2, b2), (wu, bu) = rest
+            H.check(H.lib.evk_rm_decode_step_f32(H.ptr(xd), H.ptr(wx), H.ptr(bx), H.ptr(mem), H.ptr(wqkv), H.ptr(bqkv), H.ptr(wo), H.ptr(bo), H.ptr(w0),
+                                                 H.ptr(b0), H.ptr(w2), H.ptr(b2), H.ptr(wu), H.ptr(bu), H.ptr(out16), H.ptr(ws), ws.numel(), B, H.stream()))
+            err = float((mem.reshape(B, -1).cpu().double() - ref64).abs().max())
+            worst = max(worst, err)
+            assert torch.equal(out16.float().cpu(), mem.reshape(B, -1).to(BF).float().cpu())
+    print('\n[f32 relational memory] max |memory - float64 oracle| over 60 tokens: engine %.2e, float32 oracle %.2e' % (worst, worst32))
+    assert worst <= 4 * worst32 + 1e-5, (worst, worst32)
+
+
 def test_conv_fwd_stats_and_dgrad_add():
     """conv epilogue batch-norm statistics (evk_conv2d_fwd_stats + evk_bn_stats_from_partials) and the fused skip-gradient
     add of the data gradient (evk_conv2d_dgrad_add) against f32 torch convolutions of the same bf16 operands."""

@@ -245,7 +245,8 @@ def test_beam_search_matches_reference(name):
             assert a >= b - 0.05 * max(1.0, abs(b)), (a, b)
 
 
-def test_beam_search_at_100_positions_follows_the_reference_decisions():
+@pytest.mark.parametrize('rm_f32', [False, True])
+def test_beam_search_at_100_positions_follows_the_reference_decisions(rm_f32):
     """BASELINE config 5 at its real decode length (384^2, two views, beam 4, max_seq_len 100) against the imported reference's token
     ids (tests/golden/beam384_b4_L100.npz) and the decision trace the oracle wrote after reproducing those ids bit for bit
     (tests/golden/beam384_b4_L100_trace.npz: the 12 best candidates per position and study, with the reference's running scores).
@@ -259,11 +260,24 @@ def test_beam_search_at_100_positions_follows_the_reference_decisions():
          reference's (<= LOGP_TOL), the engine's own top-beam set must equal the reference's wherever the reference's margin exceeds
          2 x LOGP_TOL, and the forced search must return the reference's ids exactly (bookkeeping, cache row tables, memory re-order).
       2. FREE-RUNNING: the ids must be identical to the reference's up to the first position whose margin is below 2 x LOGP_TOL, and
-         the first divergent decision must be between candidates the reference scored within 2 x LOGP_TOL of each other."""
+         the first divergent decision must be between candidates the reference scored within 2 x LOGP_TOL of each other.
+    rm_f32 = True runs the same test with the relational memory of the decode step in f32 (EVK_DECODE_RM_F32, csrc/rm_f32.hip): the
+    recurrence no longer drifts, so the tolerance is FLAT -- 8e-3 at every one of the 100 positions (measured <= 5.3e-3; the 16-bit
+    recurrence reaches 0.5) -- and the engine's own top-4 set must equal the reference's at >= 98 of the 100 positions of each study."""
     from evoke_amd import decode
     from evoke_amd.model_pretrain_finetune import FineTune
     from oracle import spec as S
     name = 'beam384_b4_L100'
+    saved_rm = decode._RM_F32[0]
+    decode._RM_F32[0] = bool(rm_f32)
+    try:
+        _beam100(decode, FineTune, S, name, rm_f32)
+    finally:
+        decode._RM_F32[0] = saved_rm
+        decode._SESSIONS.clear()
+
+
+def _beam100(decode, FineTune, S, name, rm_f32):
     case, gold, tr = CASES[name], _gold(name), _gold(name + '_trace')
     beam, T, B, V1 = case['beam_size'], case['max_seq_len'], case['B'], V + 1
     inp = make_inputs(case, V)
@@ -280,6 +294,8 @@ def test_beam_search_at_100_positions_follows_the_reference_decisions():
     # operands (tests/golden/make_beam_trace.py::drift16: 4e-3 at position 10, 0.2 - 0.45 at position 99 -- the relational memory is
     # an expanding recurrence on these weights), never below 5e-3 (4e-2 in the bf16 build)
     tol = 4.0 * np.maximum.accumulate(tr['drift16'], axis=0) * (1.0 if F16 else 8.0) + (5e-3 if F16 else 4e-2)
+    if rm_f32 and F16:
+        tol = np.full_like(tol, 8e-3)
     rec = {'err': [], 'same': []}
 
     def forced(t, logp, beam_sum):
@@ -334,6 +350,8 @@ def test_beam_search_at_100_positions_follows_the_reference_decisions():
     assert (err <= tol).all(), 'positions beyond the tolerance: %s' % np.argwhere(err > tol)[:10].tolist()
     bad = ~same & (margin > 2 * tol)
     assert not bad.any(), 'the engine selects another beam set where the reference margin is %s' % margin[bad]
+    if rm_f32 and F16:
+        assert (same.sum(0) >= 98).all(), same.sum(0)
     assert torch.equal(seq_forced.cpu(), want), 'forced search does not return the reference ids: bookkeeping / state re-order differ'
     np.testing.assert_allclose(p_forced.cpu().numpy(), tr['best_p'], atol=2e-2, rtol=0)
     assert torch.equal(seq_free, seq_plain), 'a read-only hook changed the search'
