@@ -233,6 +233,17 @@ def decode_cpu_baseline(model, a, dev, beam, L):
     with torch.no_grad():
         xs, ms = pm.encoder_states(b['images'].to(dev), b['pids'], Bc, b['inc'], b['inc_masks'])
         hip_seq = DEC.beam_search(pm.text_decoder, xs, ms, dict(pm.args, beam_size=beam, max_seq_len=L), step_hook=watch).cpu()
+        # the same search with the relational memory of the decode step in f32 (EVK_DECODE_RM_F32, csrc/rm_f32.hip: no drift at depth)
+        picks16, saved = list(picks), DEC._RM_F32[0]
+        del picks[:]
+        DEC._RM_F32[0] = True
+        DEC._SESSIONS.clear()
+        try:
+            hip_seq32 = DEC.beam_search(pm.text_decoder, xs, ms, dict(pm.args, beam_size=beam, max_seq_len=L), step_hook=watch).cpu()
+        finally:
+            DEC._RM_F32[0] = saved
+            DEC._SESSIONS.clear()
+        picks32 = list(picks)
     P = {k: (v.detach().float() if v.is_floating_point() else v.detach()).cpu() for k, v in pm.state_dict().items() if not k.endswith('position_ids')}
     del pm
     cfg = dict(O.DEFAULT_CFG, max_seq_len=L, beam_size=beam)
@@ -264,26 +275,34 @@ def decode_cpu_baseline(model, a, dev, beam, L):
     # hypotheses (token tuples); at the first position where the sets differ, the oracle's own scores of the candidates say how far
     # apart the last candidate it selected and the first one it rejected were (its decision margin) and where the engine's pick ranked
     V1 = V + 1
-    first_div = []
-    for s_ in range(Bc):
-        eng, ref, rec_ = [()], [()], None
-        for t in range(L):
-            e_new = [eng[int(f) // V1] + (int(f) % V1,) for f in picks[t][s_]]
-            flat = trace[t]['flat'][s_].tolist()
-            r_all = [ref[f // V1] + (f % V1,) for f in flat]
-            r_new = r_all[:beam]
-            if set(e_new) != set(r_new):
-                sc = trace[t]['score'][s_].tolist()
-                rank_of = {h: i for i, h in enumerate(r_all)}
-                odd = [h for h in e_new if h not in set(r_new)]
-                ranks = [rank_of.get(h, -1) for h in odd]
-                gap = max([sc[beam - 1] - sc[r] for r in ranks if r >= 0] or [sc[beam - 1] - sc[-1]])
-                rec_ = dict(position=t, oracle_margin_selected_vs_rejected=round(sc[beam - 1] - sc[beam], 5),
-                            oracle_score_gap_to_engine_pick=round(gap, 5), engine_pick_oracle_rank=ranks)
-                break
-            eng, ref = e_new, r_new
-        first_div.append(rec_)
-    par = dict(first_divergent_decision=first_div, identical_sequences=same_seq, token_agreement=same_tok, bleu4_vs_oracle=bl[3], studies=Bc, common_prefix_tokens=pref,
+
+    def first_divergence(picks):
+        first_div = []
+        for s_ in range(Bc):
+            eng, ref, rec_ = [()], [()], None
+            for t in range(L):
+                e_new = [eng[int(f) // V1] + (int(f) % V1,) for f in picks[t][s_]]
+                flat = trace[t]['flat'][s_].tolist()
+                r_all = [ref[f // V1] + (f % V1,) for f in flat]
+                r_new = r_all[:beam]
+                if set(e_new) != set(r_new):
+                    sc = trace[t]['score'][s_].tolist()
+                    rank_of = {h: i for i, h in enumerate(r_all)}
+                    odd = [h for h in e_new if h not in set(r_new)]
+                    ranks = [rank_of.get(h, -1) for h in odd]
+                    gap = max([sc[beam - 1] - sc[r] for r in ranks if r >= 0] or [sc[beam - 1] - sc[-1]])
+                    rec_ = dict(position=t, oracle_margin_selected_vs_rejected=round(sc[beam - 1] - sc[beam], 5),
+                                oracle_score_gap_to_engine_pick=round(gap, 5), engine_pick_oracle_rank=ranks)
+                    break
+                eng, ref = e_new, r_new
+            first_div.append(rec_)
+        return first_div
+
+    same_seq32, same_tok32 = metrics.token_agreement(hip_seq32.tolist(), ref_seq.tolist())
+    par = dict(first_divergent_decision=first_divergence(picks16), identical_sequences=same_seq,
+               rm_f32_mode=dict(first_divergent_decision=first_divergence(picks32), identical_sequences=same_seq32, token_agreement=same_tok32,
+                                note='same inputs with EVK_DECODE_RM_F32=1 (relational memory of the decode step in f32: no drift of the recurrence, '
+                                     '14 % fewer tokens/s; opt-in)'), token_agreement=same_tok, bleu4_vs_oracle=bl[3], studies=Bc, common_prefix_tokens=pref,
                oracle_logprob_of_engine_sequences=sc_h, oracle_logprob_of_oracle_sequences=sc_r,
                note='engine (16-bit) vs CPU oracle (fp32) on the same inputs and the procedural weights of the golden fixtures, beam %d, %d positions; '
                     'an untrained network never emits [EOS] and its logit gaps are tiny, so once one near-tie resolves differently the rest of the '
