@@ -442,6 +442,9 @@ struct DecAttP { const bf16_t* q; const bf16_t* k; const bf16_t* v; const unsign
                  const bf16_t* knew; const bf16_t* vnew; long ldq; };   // optional: this step's K / V rows [R][ldq] (fused qkv output); the kernel
                                                  // attends to them as position *last_pos and appends them to row r of the caches
 
+#ifndef EVK_DEC_ATTN_UNR
+#define EVK_DEC_ATTN_UNR 6
+#endif
 __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttP p) {
   // lane = (g, c): g = lane >> 3 picks one of 8 key rows per pass, c = lane & 7 one 16-byte chunk of the 128-byte head row, so
   // every load instruction of the wave reads 8 whole rows and all passes are independent (no load waits on a shuffle)
@@ -483,7 +486,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttP p) {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   // the key rows of UNR passes are requested before the first is used: one memory round trip per UNR x 8 keys, not per 8
   // (the step is latency bound: 18 dependent round trips for the 144 cross-attention keys were most of this kernel's 17-21 us)
-  constexpr int UNR = 6;
+  constexpr int UNR = EVK_DEC_ATTN_UNR;
   for (int it0 = 0; it0 < passes; it0 += UNR) {
     uint4 ku[UNR];
 #pragma unroll
