@@ -1,0 +1,431 @@
+// conv3x3.hip -- 3x3 stride-1 "same" convolution (torchvision Bottleneck.conv2 as driven by modules/visual_extractor.py:30-38)
+// with the INPUT HALO TILE resident in LDS: y[n][oy][ox][co] = sum_{kh,kw,ci} x[n][oy+kh-1][ox+kw-1][ci] * w[co][kh][kw][ci].
+//
+// Why a second kernel beside the implicit-GEMM path of gemm.hip (A_CONV loader): those tile kernels are bound by the bytes a CU can
+// FILL into LDS (~30 GB/s per CU whether the lines come from L2 or HBM), and the im2col gather fills every
+// input pixel nine times -- layer3 (64 x 24 x 24, 256 -> 256): 680 MB of fills for 38 MB of operands, 79-88 us.  Here a workgroup
+// owns R whole image rows (<= 320 output pixels) x 128 output channels and walks K as (64-channel chunk, tap): the (R+2) x (W+2)
+// halo of one chunk is filled ONCE and the nine taps read it at shifted rows, so per chunk the fills are one halo (<= 56 KB) plus nine
+// 16 KB weight tiles for 2 * 320 * 128 * 576 flop -- about twice the flop per filled byte of the 128 x 128 x 64 tile -- and
+// layer3 is exactly 256 workgroups of equal work, one per CU.
+//
+// Geometry: the N images are stacked into one "tall" image of N*H rows; a tile is R consecutive tall rows (it may cross image
+// boundaries).  In LDS the halo is addressed in PADDED coordinates -- one zero row above every image (padded row P = n*(H+1)+y+1,
+// rows with P % (H+1) == 0 are zero) and a zero column left and right -- so the three input rows of any output row are
+// consecutive halo rows whether or not the tile crosses an image boundary, and every tap is a constant row offset.
+// LDS rows are 128 B (64 channels), 16-byte chunk index XOR (row & 7) as in gemm.hip (conflict-free ds_read_b128).
+// Pipeline (register staged, cdna_hip_programming.md T14): at the top of K-step s the loads issued at the top of step s-1 (weight
+// tile s+2 into one of three stages, one 16-byte piece per thread of the next chunk's halo) are written to LDS and the loads of step
+// s+3 are issued; the MFMA fragments are read half a step ahead of their use (k-step 0 of step s+1 during k-step 1 of step s), so the
+// 40 MFMAs that follow the step's one barrier wait for nothing issued after it.  8 waves = 4 (pixels) x 2 (channels), each 80 px x 64 ch = 5 x 4 MFMA tiles.
+// Epilogues = those of the tile path: per-channel sum / sum of squares partials (forward: batch-norm statistics), or residual +
+// ReLU gate + gate statistics (the data gradient run as a forward convolution over flipped weights, conv.hip).
+#include <stdlib.h>
+#include <type_traits>
+#include "common.h"
+
+namespace {
+
+constexpr int NTH = 512;
+constexpr int WM = 4, WN = 2, MI = 5, NI = 4;
+constexpr int TP = 16 * MI * WM;             // 320 output pixels per workgroup
+constexpr int TN = 16 * NI * WN;             // 128 output channels per workgroup
+constexpr int HALO_MAX = 432;                // halo pixels per chunk buffer
+constexpr int NPIECE = (HALO_MAX * 8 + NTH - 1) / NTH;   // 16-byte pieces per thread and chunk (7; the last one partly beyond the buffer: masked)
+constexpr int A_BYTES = HALO_MAX * 128;
+constexpr int B_BYTES = TN * 128;
+constexpr int NBST = 3;                      // weight-tile stages
+constexpr int LDS_BYTES = 2 * A_BYTES + NBST * B_BYTES;   // 159744 of 163840
+static_assert(NPIECE <= 8, "the halo pieces of the next chunk are loaded one per K-step, before the chunk's last step");
+static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+
+struct C3P {
+  const bf16_t* x; const bf16_t* w; bf16_t* y;
+  int N, H, W, C, Co;
+  int R, tilesM, tilesN;
+  float* colstats;                 // [tilesM * WM][2][Co] or null
+  const bf16_t* resid; long ldr;   // optional, added before the gate
+  const bf16_t* gate; long ldg;    // optional ReLU gate (post-ReLU forward value of the tensor y belongs to)
+  float* gatestats;                // [tilesM * WM][2][Co] or null (needs gate)
+  unsigned long long* stamps;      // diagnostic (evk_conv3x3_halo_debug_stamps): per workgroup {memtime x 4, memrealtime x 2} or null
+  int kmul;                        // 1; 0 = timing probe (EVK_C3_PROBE=1): every in-loop load reads the step-0 addresses (cache hits, wrong results)
+};
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true);
+  return v + __builtin_bit_cast(float, t);
+}
+// sum over the 16 lanes of a DPP row (lanes sharing lane >> 4)
+__device__ __forceinline__ float row16_sum(float v) {
+  v = dpp_add<0xB1>(v);
+  v = dpp_add<0x4E>(v);
+  v = dpp_add<0x141>(v);
+  return dpp_add<0x140>(v);
+}
+
+__global__ __launch_bounds__(NTH, 2) void conv3x3_halo_kernel(const C3P p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Abuf = smem;
+  char* const Bst = smem + 2 * A_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int frow = lane & 15, fq = lane >> 4;
+  if (p.stamps && tid == 0) { p.stamps[blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memtime(); p.stamps[blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime(); }
+
+  // blocks b, b + 8, ... share an XCD: give each XCD a contiguous run of tiles, the channel tiles of one pixel tile adjacent
+  // (they read the same halo: the second one finds it in that L2)
+  const int bid = blockIdx.x, nwg = gridDim.x;
+  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+  const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int tm = wg / p.tilesN, tn = wg - tm * p.tilesN;
+
+  const int H = p.H, W = p.W, C = p.C;
+  const int W2 = W + 2, H1 = H + 1;
+  const int TR = p.N * H;
+  const int g0 = tm * p.R;
+  const int reff = min(p.R, TR - g0);
+  const int npx = reff * W;
+  const int P0 = (g0 / H) * H1 + (g0 % H);                    // padded row of tall row g0, minus one
+  const int glast = g0 + reff - 1;
+  const int hpx = ((glast / H) * H1 + (glast % H) + 3 - P0) * W2;   // halo pixels of this tile (<= HALO_MAX by the host's choice of R)
+
+  // halo pieces of this thread: piece i covers halo pixel (tid >> 3) + 64 i, 16-byte chunk tid & 7 of the 64-channel row
+  unsigned aoff[NPIECE];
+  unsigned amask = 0, inbuf = 0;                 // amask: the piece holds data (else zeros); inbuf: its halo pixel lies inside the buffer
+#pragma unroll
+  for (int i = 0; i < NPIECE; ++i) {
+    const int hp = (tid >> 3) + 64 * i;
+    const int hr = hp / W2, hx = hp - hr * W2;
+    const int P = P0 + hr;
+    const int n = P / H1, yy = P - n * H1;
+    const bool valid = hp < hpx && yy != 0 && hx >= 1 && hx <= W && n < p.N;
+    aoff[i] = valid ? (unsigned)(((((long)n * H + (yy - 1)) * W + (hx - 1)) * C + (tid & 7) * 8) * 2) : 0u;
+    amask |= (valid ? 1u : 0u) << i;
+    inbuf |= (hp < HALO_MAX ? 1u : 0u) << i;
+  }
+  const int adst = (tid >> 3) * 128 + (((tid & 7) ^ ((tid >> 3) & 7)) << 4);     // + i * 8192
+
+  // halo row of each of this lane's MFMA rows (centre tap); rows beyond the tile read pixel 0 and are masked in the epilogue
+  int hb[MI];
+#pragma unroll
+  for (int im = 0; im < MI; ++im) {
+    int pp = wm * (16 * MI) + im * 16 + frow;
+    if (pp >= npx) pp = 0;
+    const int j = pp / W, xx = pp - j * W;
+    const int g = g0 + j;
+    const int n = g / H, y = g - n * H;
+    hb[im] = (n * H1 + y + 1 - P0) * W2 + xx + 1;
+  }
+
+  const int co0 = tn * TN;
+  const char* const wsrc = reinterpret_cast<const char*>(p.w) + ((long)(co0 + (tid >> 3)) * 9 * C + (tid & 7) * 8) * 2;
+  const long wrow64 = (long)64 * 9 * C * 2;
+  const int bdst = adst;                                                         // same (row, chunk) -> byte mapping; + 8192 for rows 64..127
+  const char* const xsrc = reinterpret_cast<const char*>(p.x);
+
+  f32x4 acc[NI][MI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int baddr[NI];
+#pragma unroll
+  for (int in = 0; in < NI; ++in) {
+    const int row = wn * 64 + in * 16 + frow;
+    baddr[in] = row * 128 + ((fq ^ (row & 7)) << 4);
+  }
+  const int nchunk = C >> 6;
+  const int nsteps = nchunk * 9;
+  uint4 rb0, rb1, ra;
+
+  auto loadB = [&](int c, int t) {
+    const char* s = wsrc + (long)(t * C + c * 64) * 2 * p.kmul;
+    rb0 = *reinterpret_cast<const uint4*>(s);
+    rb1 = *reinterpret_cast<const uint4*>(s + wrow64);
+  };
+  auto storeB = [&](int stage) {
+    char* d = Bst + stage * B_BYTES + bdst;
+    *reinterpret_cast<uint4*>(d) = rb0;
+    *reinterpret_cast<uint4*>(d + 8192) = rb1;
+  };
+  auto storeA = [&](char* buf, int i, const uint4& v) {      // only the last piece can lie beyond the buffer
+    if ((i + 1) * 64 <= HALO_MAX || ((inbuf >> i) & 1u))
+      *reinterpret_cast<uint4*>(buf + adst + i * 8192) = ((amask >> i) & 1u) ? v : make_uint4(0, 0, 0, 0);
+  };
+  // fragment addresses of tap t inside a halo buffer (k-step 1 = the same address with byte bit 6 flipped: chunk index ^ 4).  The empty
+  // asm keeps the compiler from hoisting the 9 x MI addresses of all taps out of the chunk loop (loop-invariant: 45 registers, spills)
+  auto tap_addr = [&](int t, int (&a)[MI]) {
+    const int toff = (t / 3 - 1) * W2 + (t % 3 - 1);
+#pragma unroll
+    for (int im = 0; im < MI; ++im) {
+      int h = hb[im];
+      asm volatile("" : "+v"(h));
+      const int hr = h + toff;
+      a[im] = hr * 128 + ((fq ^ (hr & 7)) << 4);
+    }
+  };
+
+  // prologue: the whole halo of chunk 0 and the weight tiles of steps 0 and 1 into LDS, the weight tile of step 2 into registers --
+  // every load issued before the first wait (one memory round trip instead of three)
+  {
+    uint4 v[NPIECE], b0[2], b1[2];
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) v[i] = *reinterpret_cast<const uint4*>(xsrc + aoff[i]);
+    b0[0] = *reinterpret_cast<const uint4*>(wsrc);
+    b0[1] = *reinterpret_cast<const uint4*>(wsrc + wrow64);
+    b1[0] = *reinterpret_cast<const uint4*>(wsrc + (long)C * 2 * p.kmul);
+    b1[1] = *reinterpret_cast<const uint4*>(wsrc + (long)C * 2 * p.kmul + wrow64);
+    loadB(0, 2);            // nsteps >= 9
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) storeA(Abuf, i, v[i]);
+    *reinterpret_cast<uint4*>(Bst + bdst) = b0[0];
+    *reinterpret_cast<uint4*>(Bst + bdst + 8192) = b0[1];
+    *reinterpret_cast<uint4*>(Bst + B_BYTES + bdst) = b1[0];
+    *reinterpret_cast<uint4*>(Bst + B_BYTES + bdst + 8192) = b1[1];
+  }
+  __syncthreads();
+
+  // K-step s = 9 c + t multiplies tap t of chunk c: weight stage s % 3 = t % 3, halo buffer c & 1.  Per step, in program order:
+  //   registers -> LDS (weight tile s + 2, halo piece t - 1 of chunk c + 1: both loaded at the top of step s - 1), the loads of step
+  //   s + 3 / the next halo piece, the k-step-1 fragments of step s, MFMAs of k-step 0 (fragments read during step s - 1), the
+  //   k-step-0 fragments of step s + 1 (its weight tile was written at the top of step s - 1), MFMAs of k-step 1, barrier.
+  // So the MFMAs that follow a barrier never wait for an LDS write or read issued after it.
+  bf16x8 af0[MI], bf0[NI], af1[MI], bf1[NI];
+  int acur[MI];
+  tap_addr(0, acur);
+#pragma unroll
+  for (int im = 0; im < MI; ++im) af0[im] = *reinterpret_cast<const bf16x8*>(Abuf + acur[im]);
+#pragma unroll
+  for (int in = 0; in < NI; ++in) bf0[in] = *reinterpret_cast<const bf16x8*>(Bst + baddr[in]);
+
+  // one chunk = nine steps, fully unrolled and branch-free: MORE (another chunk follows) is a compile-time flag, so every
+  // "is there a step s + k" test folds (with MORE they all exist; in the last chunk they depend on t alone)
+  auto chunk = [&](auto more_tag, int c) {
+    constexpr bool MORE = decltype(more_tag)::value;
+    const char* const As = Abuf + (c & 1) * A_BYTES;
+    char* const Anext = Abuf + ((c + 1) & 1) * A_BYTES;
+    const char* const xnext = xsrc + (long)(c + 1) * 128 * p.kmul;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      if (MORE || t + 2 < 9) storeB((t + 2) % 3);
+      if (MORE && t >= 1 && t - 1 < NPIECE) storeA(Anext, t - 1, ra);
+      if (MORE || t + 3 < 9) {
+        if (t < 6) loadB(c, t + 3); else loadB(c + 1, t - 6);
+      }
+      if (MORE && t < NPIECE) ra = *reinterpret_cast<const uint4*>(xnext + aoff[t]);
+
+      const char* const Bs = Bst + (t % 3) * B_BYTES;
+#pragma unroll
+      for (int im = 0; im < MI; ++im) af1[im] = *reinterpret_cast<const bf16x8*>(As + (acur[im] ^ 64));
+#pragma unroll
+      for (int in = 0; in < NI; ++in) bf1[in] = *reinterpret_cast<const bf16x8*>(Bs + (baddr[in] ^ 64));
+#pragma unroll
+      for (int in = 0; in < NI; ++in)
+#pragma unroll
+        for (int im = 0; im < MI; ++im) acc[in][im] = EVK_MFMA_16x16x32(bf0[in], af0[im], acc[in][im], 0, 0, 0);
+      if (MORE || t + 1 < 9) {
+        const char* const An = t < 8 ? As : Anext;
+        const char* const Bn = Bst + ((t + 1) % 3) * B_BYTES;
+        tap_addr(t < 8 ? t + 1 : 0, acur);
+#pragma unroll
+        for (int im = 0; im < MI; ++im) af0[im] = *reinterpret_cast<const bf16x8*>(An + acur[im]);
+#pragma unroll
+        for (int in = 0; in < NI; ++in) bf0[in] = *reinterpret_cast<const bf16x8*>(Bn + baddr[in]);
+      }
+#pragma unroll
+      for (int in = 0; in < NI; ++in)
+#pragma unroll
+        for (int im = 0; im < MI; ++im) acc[in][im] = EVK_MFMA_16x16x32(bf1[in], af1[im], acc[in][im], 0, 0, 0);
+      __syncthreads();
+    }
+  };
+  if (p.stamps && tid == 0) p.stamps[blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memtime();
+  for (int c = 0; c + 1 < nchunk; ++c) chunk(std::true_type{}, c);
+  chunk(std::false_type{}, nchunk - 1);
+  if (p.stamps && tid == 0) p.stamps[blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memtime();
+
+  // ---- epilogue: lane holds y[m][n0 .. n0+3], m = tile pixel wm*80 + im*16 + frow, n0 = co0 + wn*64 + in*16 + fq*4 ----
+  const long m0 = (long)g0 * W;
+  const int Co = p.Co;
+  bool rowok[MI];
+#pragma unroll
+  for (int im = 0; im < MI; ++im) {
+    rowok[im] = wm * (16 * MI) + im * 16 + frow < npx;
+    if (!rowok[im]) {
+#pragma unroll
+      for (int in = 0; in < NI; ++in) acc[in][im] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  if (p.colstats) {
+    float* prow = p.colstats + ((long)(tm * WM + wm)) * 2 * Co;
+#pragma unroll
+    for (int in = 0; in < NI; ++in) {
+      float sm[4], sq[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int im = 0; im < MI; ++im) { const float v = acc[in][im][j]; a += v; b += v * v; }
+        sm[j] = row16_sum(a);
+        sq[j] = row16_sum(b);
+      }
+      const int n0 = co0 + wn * 64 + in * 16 + fq * 4;
+      if (frow == 0) {
+        *reinterpret_cast<float4*>(prow + n0) = make_float4(sm[0], sm[1], sm[2], sm[3]);
+        *reinterpret_cast<float4*>(prow + Co + n0) = make_float4(sq[0], sq[1], sq[2], sq[3]);
+      }
+    }
+  }
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 gs[NI][2], gz[NI][2];
+#pragma unroll
+  for (int in = 0; in < NI; ++in)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) { gs[in][h] = f32x2{0.f, 0.f}; gz[in][h] = f32x2{0.f, 0.f}; }
+#pragma unroll
+  for (int im = 0; im < MI; ++im) {
+    if (!rowok[im]) continue;
+    const long m = m0 + wm * (16 * MI) + im * 16 + frow;
+#pragma unroll
+    for (int in = 0; in < NI; ++in) {
+      const int n0 = co0 + wn * 64 + in * 16 + fq * 4;
+      float v[4] = {acc[in][im][0], acc[in][im][1], acc[in][im][2], acc[in][im][3]};
+      if (p.resid) {
+        const uint2 t = *reinterpret_cast<const uint2*>(p.resid + m * p.ldr + n0);
+        v[0] += lo_bf(t.x); v[1] += hi_bf(t.x); v[2] += lo_bf(t.y); v[3] += hi_bf(t.y);
+      }
+      if (p.gate) {
+        const uint2 t = *reinterpret_cast<const uint2*>(p.gate + m * p.ldg + n0);
+        const float gv[4] = {lo_bf(t.x), hi_bf(t.x), lo_bf(t.y), hi_bf(t.y)};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (!(gv[j] > 0.f)) v[j] = 0.f;
+        if (p.gatestats) {
+          // explicit two-wide vectors in natural order: see gemm.hip (the SLP-chosen cross-half v_pk_add_f32 form is unsafe on gfx950)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const f32x2 vv = {v[2 * h], v[2 * h + 1]}, gg = {gv[2 * h], gv[2 * h + 1]};
+            gs[in][h] += vv;
+            gz[in][h] += vv * gg;
+          }
+        }
+      }
+      *reinterpret_cast<uint2*>(p.y + m * Co + n0) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+    }
+  }
+  if (p.gatestats) {
+    float* prow = p.gatestats + ((long)(tm * WM + wm)) * 2 * Co;
+#pragma unroll
+    for (int in = 0; in < NI; ++in) {
+      float a[4], b[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { a[j] = row16_sum(gs[in][j >> 1][j & 1]); b[j] = row16_sum(gz[in][j >> 1][j & 1]); }
+      const int n0 = co0 + wn * 64 + in * 16 + fq * 4;
+      if (frow == 0) {
+        *reinterpret_cast<float4*>(prow + n0) = make_float4(a[0], a[1], a[2], a[3]);
+        *reinterpret_cast<float4*>(prow + Co + n0) = make_float4(b[0], b[1], b[2], b[3]);
+      }
+    }
+  }
+  if (p.stamps && tid == 0) { p.stamps[blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memtime(); p.stamps[blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime(); }
+}
+
+// most halo rows (padded coordinates) any tile of R tall rows needs: the phases g0 % H repeat after at most H tiles
+int halo_rows_max(int TR, int H, int R) {
+  const int H1 = H + 1;
+  const int tiles = (int)cdiv(TR, R), lim = tiles < H ? tiles : H;
+  int best = 0;
+  for (int k = 0; k < lim; ++k) {
+    const int g0 = k * R, gl = (g0 + R < TR ? g0 + R : TR) - 1;
+    const int rows = (gl / H) * H1 + gl % H + 3 - ((g0 / H) * H1 + g0 % H);
+    if (rows > best) best = rows;
+  }
+  return best;
+}
+
+// rows per tile: the most whole rows whose pixels fit the tile and whose halo fits the buffer; 0 = not tileable
+int choose_rows(int N, int H, int W) {
+  for (int R = TP / W; R >= 1; --R)
+    if (halo_rows_max(N * H, H, R) * (W + 2) <= HALO_MAX) return R;
+  return 0;
+}
+
+unsigned long long* g_stamps = nullptr;
+
+bool halo_enabled() {
+  static const int on = [] { const char* e = getenv("EVK_CONV3X3_HALO"); return e ? atoi(e) : 1; }();
+  return on != 0;
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int evk_conv3x3_halo_supported(int32_t N, int32_t H, int32_t W, int32_t C, int32_t Co) {
+  if (N <= 0 || H <= 0 || W <= 0 || C < 64 || (C % 64) || Co < TN || (Co % TN)) return 0;
+  if ((long)N * H * W * C * 2 >= (1L << 32)) return 0;          // 32-bit byte offsets into x
+  const int R = choose_rows(N, H, W);
+  if (R < 1 || R * W < TP / 2) return 0;                         // tiles under half full: the tile GEMM path is the better kernel
+  return 1;
+}
+
+int64_t evk_conv3x3_halo_part_bytes(int32_t N, int32_t H, int32_t W, int32_t Co) {
+  const int R = choose_rows(N, H, W);
+  if (R < 1) return 0;
+  return cdiv((int64_t)N * H, R) * WM * 2 * Co * (int64_t)sizeof(float);
+}
+
+int evk_conv3x3_halo(const void* x, const void* w, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t Co,
+                     const void* resid, int64_t ldr, const void* gate, int64_t ldg, float* colstats, float* gatestats,
+                     int64_t part_bytes, int32_t* nblk, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(x && w && y, "conv3x3_halo: null operand");
+  EVK_REQUIRE(evk_conv3x3_halo_supported(N, H, W, C, Co), "conv3x3_halo: unsupported shape N=%d H=%d W=%d C=%d Co=%d (C %% 64, Co %% 128, tileable rows)", N, H, W, C, Co);
+  EVK_REQUIRE(al16(x) && al16(w) && al16(y) && (!resid || (al16(resid) && ldr % 4 == 0 && ldr >= Co)) && (!gate || (al16(gate) && ldg % 4 == 0 && ldg >= Co)),
+              "conv3x3_halo: operands must be 16-byte aligned, leading dimensions multiples of 4 and >= Co");
+  EVK_REQUIRE(!(colstats && gatestats) && (!gatestats || gate), "conv3x3_halo: one statistics epilogue at a time; gate statistics need a gate");
+  C3P p{};
+  p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.y = (bf16_t*)y;
+  p.N = N; p.H = H; p.W = W; p.C = C; p.Co = Co;
+  p.R = choose_rows(N, H, W);
+  p.tilesM = (int)cdiv((int64_t)N * H, p.R);
+  p.tilesN = Co / TN;
+  p.resid = (const bf16_t*)resid; p.ldr = ldr; p.gate = (const bf16_t*)gate; p.ldg = ldg;
+  p.colstats = colstats; p.gatestats = gatestats;
+  static const int probe = [] { const char* e = getenv("EVK_C3_PROBE"); return e ? atoi(e) : 0; }();
+  p.kmul = probe ? 0 : 1;
+  p.stamps = g_stamps;
+  if (colstats || gatestats) {
+    EVK_REQUIRE(nblk && part_bytes >= evk_conv3x3_halo_part_bytes(N, H, W, Co), "conv3x3_halo: statistics buffer too small");
+    *nblk = p.tilesM * WM;
+  }
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    attr_done = true;
+  }
+  evk_prof_tag(N * H * W, Co, 9 * C, 1, EVK_A_CONV, EVK_B_PLAIN);
+  ProfScope ps(EVK_FAM_GEMM, s, 2.0 * N * H * W * (double)Co * 9 * C);
+  hipLaunchKernelGGL(conv3x3_halo_kernel, dim3(p.tilesM * p.tilesN), dim3(NTH), LDS_BYTES, s, p);
+  return evk_check_launch("conv3x3_halo_kernel");
+}
+
+// diagnostic: while buf is non-null every evk_conv3x3_halo launch writes, per workgroup, 8 x uint64 {s_memtime at entry, before the
+// K loop, after it, at exit; s_memrealtime (100 MHz) at entry and exit; 2 unused} into buf (tools/conv3x3_probe.py)
+int evk_conv3x3_halo_debug_stamps(void* buf) { g_stamps = reinterpret_cast<unsigned long long*>(buf); return EVK_OK; }
+
+// routing used by conv.hip: 1 when the halo kernel takes a 3x3 / stride 1 / pad 1 convolution of this geometry with a statistics
+// buffer of part_bytes (0 = no statistics requested)
+int evk_conv3x3_halo_routes(const evk_conv_geom* g, int32_t C, int32_t Co, int64_t part_bytes, int32_t want_stats) {
+  if (!halo_enabled() || !g) return 0;
+  if (g->KH != 3 || g->KW != 3 || g->stride_h != 1 || g->stride_w != 1 || g->pad_h != 1 || g->pad_w != 1) return 0;
+  if (g->Hi != g->Ho || g->Wi != g->Wo) return 0;
+  if (!evk_conv3x3_halo_supported(g->N, g->Hi, g->Wi, C, Co)) return 0;
+  if (want_stats && part_bytes < evk_conv3x3_halo_part_bytes(g->N, g->Hi, g->Wi, Co)) return 0;
+  return 1;
+}
+
+}  // extern "C"

@@ -150,6 +150,23 @@ int evk_conv_flip_weights(const void* const* w, void* const* wt, const int32_t* 
                           int32_t n_layers, evk_stream_t stream);
 int evk_conv2d_dgrad_flipped_gated_stats(const void* dy, const void* wt, const void* resid, const void* gate, void* dx, const evk_conv_geom* g,
                                          float* part, int64_t part_bytes, int32_t* nblk, evk_stream_t stream);
+/* 3x3 / stride 1 / pad 1 convolution with the input halo tile resident in LDS (conv3x3.hip): torchvision Bottleneck.conv2 of every
+ * non-strided block as driven by modules/visual_extractor.py:30-38 -- forward (x [N][H][W][C], w [Co][3][3][C], y [N][H][W][Co], 16-bit
+ * NHWC; colstats: *nblk rows of [2][Co] partial (sum, sum of squares) of the f32 result for the batch norm that follows) and, over
+ * the flipped / transposed weights of evk_conv_flip_weights, its data gradient (resid added, ReLU gate applied, gatestats: *nblk rows of
+ * [2][Co] partial (sum g, sum g * gate)).  A workgroup owns whole image rows (<= 320 pixels) x 128 output channels and fills the halo
+ * of a 64-channel chunk once for the nine taps: about half the LDS-fill bytes per flop of the implicit-GEMM tile path, which stays the
+ * route for every other geometry (evk_conv3x3_halo_supported: C % 64 == 0, Co % 128 == 0, rows that tile; evk_conv3x3_halo_routes: what
+ * evk_conv2d_fwd_stats / evk_conv2d_dgrad_flipped_gated_stats ask before taking it, EVK_CONV3X3_HALO=0 disables).  The statistics
+ * buffer holds evk_conv3x3_halo_part_bytes. */
+int evk_conv3x3_halo_supported(int32_t N, int32_t H, int32_t W, int32_t C, int32_t Co);
+int64_t evk_conv3x3_halo_part_bytes(int32_t N, int32_t H, int32_t W, int32_t Co);
+int evk_conv3x3_halo(const void* x, const void* w, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t Co,
+                     const void* resid, int64_t ldr, const void* gate, int64_t ldg, float* colstats, float* gatestats,
+                     int64_t part_bytes, int32_t* nblk, evk_stream_t stream);
+/* diagnostic: in-kernel cycle stamps of every later evk_conv3x3_halo launch into buf (8 x uint64 per workgroup), null = off */
+int evk_conv3x3_halo_debug_stamps(void* buf);
+int evk_conv3x3_halo_routes(const evk_conv_geom* g, int32_t C, int32_t Co, int64_t part_bytes, int32_t want_stats);
 /* Weight-stationary kernel for the short-K pointwise convolutions (conv1x1.hip): y[M][N] = x[M][K] . w[N][K]^T with the weights
  * held in registers for the whole launch and only the pixel tiles streaming (torchvision Bottleneck conv3 forward: planes -> 4 planes;
  * the data gradient of conv1 is the same shape with the transposed weights; conv1 forward / conv3 data gradient at K = 512, 1024).

@@ -284,6 +284,86 @@ def test_weight_stationary_pointwise_conv_forward_and_data_gradient(H, M, K, N):
     assert float((s3[2] - want).abs().max()) <= 1e-5 * scale + 1e-4
 
 
+HALO_SHAPES = [(2, 24, 24, 256, 256), (5, 7, 7, 64, 128), (3, 14, 14, 128, 256), (2, 48, 48, 128, 128), (3, 12, 12, 512, 512),
+               (3, 10, 23, 64, 128), (1, 16, 20, 64, 384), (7, 5, 40, 128, 128)]
+
+
+@pytest.mark.parametrize('N,Hh,W,Ci,Co', HALO_SHAPES)
+def test_halo_conv3x3_forward_and_flipped_data_gradient(H, N, Hh, W, Ci, Co):
+    """csrc/conv3x3.hip through its own entry point (evk_conv3x3_halo): tiles of whole rows that cross image boundaries (7 x 7 and
+    5-row images: several images per tile), ragged last tiles, one to eight 64-channel chunks.  Forward against the fp32 convolution
+    of the same rounded operands (one output rounding + the f32 summation order), the batch-norm partials against the sums of the
+    UNROUNDED result, the tile path as a second witness; then the data gradient as a forward convolution over the flipped weights with
+    the residual / ReLU gate / gate statistics epilogue."""
+    assert H.lib.evk_conv3x3_halo_supported(N, Hh, W, Ci, Co) == 1
+    x = rnd(N, Hh, W, Ci, seed=21, scale=0.7).cuda()
+    w = rnd(Co, 3, 3, Ci, seed=22, scale=(2.0 / (9 * Ci)) ** 0.5).cuda()
+    ref = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.float().cpu().permute(0, 3, 1, 2), None, 1, 1).permute(0, 2, 3, 1).contiguous()
+    y = torch.full((N, Hh, W, Co), 9.0, dtype=STORE_DTYPE, device='cuda')
+    nb = H.lib.evk_conv3x3_halo_part_bytes(N, Hh, W, Co)
+    part = torch.full((nb // 4,), 3.0, device='cuda')
+    nblk = C.c_int32(0)
+    H.check(H.lib.evk_conv3x3_halo(H.ptr(x), H.ptr(w), H.ptr(y), N, Hh, W, Ci, Co, None, 0, None, 0, H.ptr(part), None, nb, C.byref(nblk), H.stream()))
+    torch.cuda.synchronize()
+    rt = 2.0 ** -8 if STORE_DTYPE == torch.bfloat16 else 2.0 ** -10
+    close(y, ref, rt, 2e-3)
+    assert nblk.value * 2 * Co * 4 == nb
+    s = part.view(nblk.value, 2, Co).sum(0).cpu()
+    flat = ref.reshape(-1, Co)
+    assert float((s[0] - flat.sum(0)).abs().max()) <= 1e-5 * float(flat.abs().sum(0).max()) + 1e-4
+    assert float((s[1] - (flat ** 2).sum(0)).abs().max()) <= 1e-5 * float((flat ** 2).sum(0).max()) + 1e-4
+    # second witness: the implicit-GEMM tile path (EVK_A_CONV loader) on the same operands
+    g = H.conv_geom(N, Hh, W, Ci, Co, 3, 3, 1, 1)
+    d = H.Gemm()
+    y2 = torch.empty_like(y)
+    d.A, d.B, d.C = x.data_ptr(), w.data_ptr(), y2.data_ptr()
+    d.M, d.N, d.K, d.a_mode, d.b_mode = N * Hh * W, Co, 9 * Ci, H.A_CONV, H.B_PLAIN
+    d.lda, d.ldb, d.ldc = Ci, 9 * Ci, Co
+    d.batch_outer = d.batch_inner = 1
+    d.alpha, d.c_dtype = 1.0, H.dt(y2)
+    d.g = g
+    d.g.sN, d.g.sH, d.g.sW = Hh * W * Ci, W * Ci, Ci
+    H.gemm_launch(d)
+    torch.cuda.synchronize()
+    close(y, y2.float().cpu(), 2 * rt, 2e-3)
+    # data gradient of a Co -> Ci ... here: the same kernel as "dy [.., Ci] -> dx [.., Co]" over weights flipped by evk_conv_flip_weights
+    wf = torch.empty(Ci, 3, 3, Co, dtype=STORE_DTYPE, device='cuda')          # wt[ci][2-kh][2-kw][co] = w[co][kh][kw][ci]
+    ptrs_w, ptrs_wt = (C.c_void_p * 1)(w.data_ptr()), (C.c_void_p * 1)(wf.data_ptr())
+    one = lambda v: (C.c_int32 * 1)(v)
+    H.check(H.lib.evk_conv_flip_weights(ptrs_w, ptrs_wt, one(Co), one(Ci), one(3), one(3), 1, H.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(wf.cpu(), w.cpu().flip(1, 2).permute(3, 1, 2, 0).contiguous())
+    if Ci % 128 == 0:
+        # dgrad of the forward conv (Ci -> Co): input dy has Co channels, output dx has Ci channels, weights wf [Ci][3][3][Co]
+        dy = rnd(N, Hh, W, Co, seed=23).cuda()
+        skip = rnd(N, Hh, W, Ci, seed=24, scale=0.3).cuda()
+        gate = torch.relu(rnd(N, Hh, W, Ci, seed=25).float()).to(STORE_DTYPE).cuda()
+        dx = torch.full((N, Hh, W, Ci), 5.0, dtype=STORE_DTYPE, device='cuda')
+        nb2 = H.lib.evk_conv3x3_halo_part_bytes(N, Hh, W, Ci)
+        part2 = torch.full((nb2 // 4,), 3.0, device='cuda')
+        H.check(H.lib.evk_conv3x3_halo(H.ptr(dy), H.ptr(wf), H.ptr(dx), N, Hh, W, Co, Ci, H.ptr(skip), Ci, H.ptr(gate), Ci, None, H.ptr(part2),
+                                       nb2, C.byref(nblk), H.stream()))
+        torch.cuda.synchronize()
+        dref = F.conv_transpose2d(dy.float().cpu().permute(0, 3, 1, 2), w.float().cpu().permute(0, 3, 1, 2), None, 1, 1).permute(0, 2, 3, 1)
+        gref = (dref + skip.float().cpu()) * (gate.float().cpu() > 0)
+        close(dx, gref, rt, 2e-2 * (9 * Co / 64) ** 0.5 * float(w.float().std()))
+        s = part2.view(nblk.value, 2, Ci).sum(0).cpu()
+        gf, zf = gref.reshape(-1, Ci), gate.float().cpu().reshape(-1, Ci)
+        assert float((s[0] - gf.sum(0)).abs().max()) <= 2e-5 * float(gf.abs().sum(0).max()) + 1e-3
+        assert float((s[1] - (gf * zf).sum(0)).abs().max()) <= 2e-5 * float((gf * zf).abs().sum(0).max()) + 1e-3
+
+
+def test_halo_conv3x3_refuses_what_it_cannot_tile(H):
+    assert H.lib.evk_conv3x3_halo_supported(1, 8, 200, 64, 128) == 0       # the halo of even one 200-pixel row exceeds the LDS buffer
+    assert H.lib.evk_conv3x3_halo_supported(4, 4, 5, 64, 128) == 1         # tiny images: many per tile
+    assert H.lib.evk_conv3x3_halo_supported(2, 24, 24, 96, 128) == 0       # C % 64
+    assert H.lib.evk_conv3x3_halo_supported(2, 24, 24, 64, 64) == 0        # Co % 128
+    x = torch.zeros(2, 24, 24, 96, dtype=STORE_DTYPE, device='cuda')
+    w = torch.zeros(128, 3, 3, 96, dtype=STORE_DTYPE, device='cuda')
+    y = torch.zeros(2, 24, 24, 128, dtype=STORE_DTYPE, device='cuda')
+    assert H.lib.evk_conv3x3_halo(H.ptr(x), H.ptr(w), H.ptr(y), 2, 24, 24, 96, 128, None, 0, None, 0, None, None, 0, None, H.stream()) != 0
+
+
 def test_weight_stationary_kernel_refuses_what_it_cannot_tile(H):
     """Shapes outside the instantiated set are reported as unsupported and the entry point returns an error (no fallback inside it)."""
     assert H.lib.evk_conv1x1_ws_supported(100, 96, 256) == 0

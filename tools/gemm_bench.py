@@ -43,6 +43,19 @@ def conv_case(N, Hh, Ci, Co, k, stride, kind):
     st = H.stream
     if kind == 'fwd':
         return lambda: H.check(H.lib.evk_conv2d_fwd(H.ptr(x), H.ptr(w), H.ptr(y), C.byref(g), st()))
+    if kind == 'dgrad_flip':          # the data gradient as the trunk runs it: forward convolution over flipped weights + gate + gate statistics
+        wt = torch.randn(Ci, k, k, Co, device='cuda').to(BF)
+        gate = torch.relu(torch.randn_like(x)).to(BF)
+        pb = max(H.lib.evk_conv_stats_bytes(N * Hh * Hh, Ci), H.lib.evk_conv3x3_halo_part_bytes(N, Hh, Hh, Ci))
+        part = torch.empty(pb // 4, device='cuda')
+        nblk = C.c_int32(0)
+        return lambda: H.check(H.lib.evk_conv2d_dgrad_flipped_gated_stats(H.ptr(y), H.ptr(wt), None, H.ptr(gate), H.ptr(dx), C.byref(g),
+                                                                          H.ptr(part), pb, C.byref(nblk), st()))
+    if kind == 'fwd_stats':
+        pb = max(H.lib.evk_conv_stats_bytes(N * g.Ho * g.Wo, Co), H.lib.evk_conv3x3_halo_part_bytes(N, Hh, Hh, Co))
+        part = torch.empty(pb // 4, device='cuda')
+        nblk = C.c_int32(0)
+        return lambda: H.check(H.lib.evk_conv2d_fwd_stats(H.ptr(x), H.ptr(w), H.ptr(y), C.byref(g), H.ptr(part), pb, C.byref(nblk), st()))
     if kind == 'dgrad':
         return lambda: H.check(H.lib.evk_conv2d_dgrad(H.ptr(y), H.ptr(w), H.ptr(dx), C.byref(g), st()))
     return lambda: H.check(H.lib.evk_conv2d_wgrad(H.ptr(y), H.ptr(x), H.ptr(dw), C.byref(g), H.ptr(ws), nb, st()))
@@ -55,6 +68,11 @@ CASES = [
     ('gemm 4640x16384x2048 NN(dX)', lambda: gemm_case(4640, 16384, 2048, 0, 1), 2 * 4640 * 16384 * 2048),
     ('gemm 16384x2048x4640 TN(dW)', lambda: gemm_case(16384, 2048, 4640, 3, 1), 2 * 4640 * 16384 * 2048),
     ('conv3x3 l3 fwd 64x24x24 256->256', lambda: conv_case(64, 24, 256, 256, 3, 1, 'fwd'), 2 * 36864 * 256 * 2304),
+    ('conv3x3 l3 fwd+stats', lambda: conv_case(64, 24, 256, 256, 3, 1, 'fwd_stats'), 2 * 36864 * 256 * 2304),
+    ('conv3x3 l3 dgrad flipped+gate+stats', lambda: conv_case(64, 24, 256, 256, 3, 1, 'dgrad_flip'), 2 * 36864 * 256 * 2304),
+    ('conv3x3 l2 fwd+stats 64x48x48 128->128', lambda: conv_case(64, 48, 128, 128, 3, 1, 'fwd_stats'), 2 * 147456 * 128 * 1152),
+    ('conv3x3 l4 fwd+stats 64x12x12 512->512', lambda: conv_case(64, 12, 512, 512, 3, 1, 'fwd_stats'), 2 * 9216 * 512 * 4608),
+    ('conv3x3 l3 fwd+stats 128 images (decode encoder)', lambda: conv_case(128, 24, 256, 256, 3, 1, 'fwd_stats'), 2 * 73728 * 256 * 2304),
     ('conv3x3 l3 dgrad', lambda: conv_case(64, 24, 256, 256, 3, 1, 'dgrad'), 2 * 36864 * 256 * 2304),
     ('conv3x3 l3 wgrad', lambda: conv_case(64, 24, 256, 256, 3, 1, 'wgrad'), 2 * 36864 * 256 * 2304),
     ('conv3x3 l1 wgrad 64->64', lambda: conv_case(64, 96, 64, 64, 3, 1, 'wgrad'), 2 * 589824 * 64 * 576),
