@@ -88,6 +88,9 @@ struct ProfScope {
   ~ProfScope() { evk_prof_end(fam, s, flops); }
 };
 
+// gemm.hip: C[z][m][n] += sum over `splitk` f32 slabs [z][split][M][N] (z = zo * bi + zi -> C + zo * sCo + zi * sCi + m * ldc + n), N % 4 == 0
+int evk_splitk_reduce_launch(const float* slab, float* C, long mn, int M, int N, int splitk, int bi, long ldc, long sCo, long sCi, int batch, hipStream_t s);
+
 static inline int ilog2_exact(int64_t v) {
   int l = 0;
   while ((int64_t(1) << l) < v) ++l;

@@ -278,11 +278,18 @@ int64_t evk_conv2d_wgrad_ws_bytes(const evk_conv_geom* g) {
   if (!g) return 0;
   evk_gemm d{};
   wgrad_desc(d, nullptr, nullptr, nullptr, g);
-  return evk_gemm_workspace_bytes(&d);
+  int64_t nb = evk_gemm_workspace_bytes(&d);
+  if (evk_conv3x3_wgrad_halo_routes(g)) {           // conv3x3.hip: enough for either route
+    const int64_t nh = evk_conv3x3_wgrad_halo_ws_bytes(g->N, g->Hi, g->Wi, g->Ci, g->Co);
+    if (nh > nb) nb = nh;
+  }
+  return nb;
 }
 
 int evk_conv2d_wgrad(const void* dy, const void* x, float* dw, const evk_conv_geom* g, void* ws, int64_t ws_bytes, evk_stream_t stream) {
   if (int e = check_geom(g)) return e;
+  if (ws && evk_conv3x3_wgrad_halo_routes(g) && ws_bytes >= evk_conv3x3_wgrad_halo_ws_bytes(g->N, g->Hi, g->Wi, g->Ci, g->Co))
+    return evk_conv3x3_wgrad_halo(dy, x, dw, g->N, g->Hi, g->Wi, g->Ci, g->Co, ws, ws_bytes, stream);
   evk_gemm d{};
   wgrad_desc(d, dy, x, dw, g);
   d.workspace = ws; d.workspace_bytes = ws_bytes;

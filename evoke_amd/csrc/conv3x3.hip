@@ -26,6 +26,8 @@
 
 namespace {
 
+unsigned long long* g_stamps = nullptr;      // evk_conv3x3_halo_debug_stamps
+
 constexpr int NTH = 512;
 constexpr int WM = 4, WN = 2, MI = 5, NI = 4;
 constexpr int TP = 16 * MI * WM;             // 320 output pixels per workgroup
@@ -48,8 +50,17 @@ struct C3P {
   const bf16_t* gate; long ldg;    // optional ReLU gate (post-ReLU forward value of the tensor y belongs to)
   float* gatestats;                // [tilesM * WM][2][Co] or null (needs gate)
   unsigned long long* stamps;      // diagnostic (evk_conv3x3_halo_debug_stamps): per workgroup {memtime x 4, memrealtime x 2} or null
+  float inv_w, inv_w2, inv_h, inv_h1;
   int kmul;                        // 1; 0 = timing probe (EVK_C3_PROBE=1): every in-loop load reads the step-0 addresses (cache hits, wrong results)
 };
+
+// a / b for 0 <= a < 2^22, b > 0, inv = 1 / b (integer division proper costs ~40 instructions per use on this ISA)
+__device__ __forceinline__ int fdiv(int a, int b, float inv) {
+  int q = (int)((float)a * inv);
+  const int r = a - q * b;
+  if (r < 0) --q; else if (r >= b) ++q;
+  return q;
+}
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
@@ -96,9 +107,9 @@ __global__ __launch_bounds__(NTH, 2) void conv3x3_halo_kernel(const C3P p) {
 #pragma unroll
   for (int i = 0; i < NPIECE; ++i) {
     const int hp = (tid >> 3) + 64 * i;
-    const int hr = hp / W2, hx = hp - hr * W2;
+    const int hr = fdiv(hp, W2, p.inv_w2), hx = hp - hr * W2;
     const int P = P0 + hr;
-    const int n = P / H1, yy = P - n * H1;
+    const int n = fdiv(P, H1, p.inv_h1), yy = P - n * H1;
     const bool valid = hp < hpx && yy != 0 && hx >= 1 && hx <= W && n < p.N;
     aoff[i] = valid ? (unsigned)(((((long)n * H + (yy - 1)) * W + (hx - 1)) * C + (tid & 7) * 8) * 2) : 0u;
     amask |= (valid ? 1u : 0u) << i;
@@ -112,9 +123,9 @@ __global__ __launch_bounds__(NTH, 2) void conv3x3_halo_kernel(const C3P p) {
   for (int im = 0; im < MI; ++im) {
     int pp = wm * (16 * MI) + im * 16 + frow;
     if (pp >= npx) pp = 0;
-    const int j = pp / W, xx = pp - j * W;
+    const int j = fdiv(pp, W, p.inv_w), xx = pp - j * W;
     const int g = g0 + j;
-    const int n = g / H, y = g - n * H;
+    const int n = fdiv(g, H, p.inv_h), y = g - n * H;
     hb[im] = (n * H1 + y + 1 - P0) * W2 + xx + 1;
   }
 
@@ -351,7 +362,257 @@ int choose_rows(int N, int H, int W) {
   return 0;
 }
 
-unsigned long long* g_stamps = nullptr;
+
+
+// ================================================================================================================================
+// Weight gradient of the same convolution: dw[co][kh][kw][ci] += sum_px dy[px][co] * x[px + (kh-1, kw-1)][ci].
+// The tile path (gemm.hip: A_KSTR x B_WGATHER, the tap as batch index) fills both operands once per tap and per 128 x 128 tile: 680 MB
+// of LDS fills on layer3, 140-157 us.  Here a workgroup owns a slice of the pixels and one 64 (co) x 64 (ci) block of the filter and
+// accumulates ALL NINE taps in registers (9 x 16 MFMA tiles over 8 waves = 72 accumulator registers): per pixel it fills 128 B of dy and
+// ~1.35 x 128 B of the x halo for 2 * 9 * 64 * 64 flop -- four times the flop per filled byte -- and the taps read the halo at
+// shifted rows.  Pixels are the contraction index, so both operands are staged as they lie in memory ([pixel][64 channels]) and the MFMA
+// fragments come from the transposing LDS read (ds_read_b64_tr_b16, cdna_hip_programming.md T10).  LDS rows have a pitch of 160 B
+// (5 x 32 B): the eight consecutive pixel rows one 32-lane half of such a read touches fall into eight different 32-byte bank groups
+// WITHOUT an XOR swizzle, so the address of a shifted tap is the centre address plus a constant -- the kw shifts are immediate offsets
+// of the read, the kh shifts one add each.  (Within a 32-pixel MFMA step logical k = 8 fq + q + 4 hi is pixel 16 hi + 4 fq + q for
+// both operands, which makes the eight rows of a half consecutive; any pixel permutation common to both operands is a valid contraction
+// order.)  The K-slices leave as f32 slabs [tap][split][co][ci] and gemm.hip's split-K reduction adds them into dw.
+// ================================================================================================================================
+namespace wgk {
+
+__device__ uint4 g_zero16;        // zero-initialised
+
+constexpr int PITCH = 160;
+constexpr int STAGE_ROWS = 464;                       // dy rows (tile pixels padded to 32) + halo rows of one tile
+constexpr int STAGE_BYTES = STAGE_ROWS * PITCH;       // 74240
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;            // 148480
+constexpr int NPC = (STAGE_ROWS * 8 + NTH - 1) / NTH; // 16-byte pieces per thread and tile (8)
+
+struct W3P {
+  const bf16_t* dy; const bf16_t* x; float* slab;
+  int N, H, W, Co, Ci;
+  int R, tpxp;                // tall rows per tile; tile pixels rounded up to 32
+  int rps, nsplit;            // tall rows per K-slice (a multiple of R), slices
+  int pairs_ci, npairs;       // 64-channel blocks of ci, of (co, ci)
+  float inv_w, inv_w2, inv_h, inv_h1;
+  const void* zeros;           // 16 bytes of zeros in device memory: what a piece without data is loaded from
+  unsigned long long* stamps;  // diagnostic, as in the forward kernel
+};
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((address_space(3))) char lds_char;       // 32-bit LDS pointers: constant offsets fold into the read's offset field
+__device__ __forceinline__ bf16x8 frag2(const lds_char* lo_addr, const lds_char* hi_addr) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)lo_addr);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)hi_addr);
+  const s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+__global__ __launch_bounds__(NTH, 2) void conv3x3_wgrad_halo_kernel(const W3P p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fq = lane >> 4, q4 = (lane & 15) >> 2, pp = lane & 3;
+  const int wci = wave & 3, wco = (wave >> 2) * 2;        // this wave's 16-channel ci tile and the first of its two co tiles
+  if (p.stamps && tid == 0) { p.stamps[blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memtime(); p.stamps[blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime(); }
+
+  // the blocks of one K-slice (they read the same pixels) are consecutive on one XCD
+  const int bid = blockIdx.x, nwg = gridDim.x;
+  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+  const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int split = wg / p.npairs, pair = wg - split * p.npairs;
+  const int cot = pair / p.pairs_ci, cit = pair - cot * p.pairs_ci;
+
+  // R divides H (the host's choice): every tile is R whole rows of ONE image, tiles_per_image = H / R of them per image
+  const int H = p.H, W = p.W, W2 = W + 2, TR = p.N * H, R = p.R, TPXP = p.tpxp;
+  const int row_begin = split * p.rps;
+  const int row_end = min(TR, row_begin + p.rps);
+  const int ntiles = row_end > row_begin ? (row_end - row_begin) / R : 0;
+  const int full_px = R * W;
+
+  // This thread's pieces of a tile: stage row (tid >> 3) + 64 i, 16-byte chunk tid & 7.  Everything about a piece is known up front:
+  // its byte offset from the tile's first pixel, whether it is a dy row or a halo row, whether it can ever hold data; per tile only the
+  // top / bottom halo rows switch off when the tile touches the image's edge.  Pieces without data are loaded from a 16-byte block of
+  // zeros, so nothing is masked on the way into LDS.
+  const int pc = tid & 7;
+  int offs[NPC];                     // signed byte offset from the tile origin (dy: row ri; halo: pixel (hr - 1, hx - 1))
+  unsigned isdy = 0, smask = 0, topmask = 0, botmask = 0;
+#pragma unroll
+  for (int i = 0; i < NPC; ++i) {
+    const int ri = (tid >> 3) + 64 * i;
+    if (ri < TPXP) {
+      offs[i] = ri * p.Co * 2;
+      isdy |= 1u << i;
+      smask |= (ri < full_px ? 1u : 0u) << i;
+    } else {
+      const int hp = ri - TPXP;
+      const int hr = fdiv(hp, W2, p.inv_w2), hx = hp - hr * W2;
+      offs[i] = ((hr - 1) * W + (hx - 1)) * p.Ci * 2;
+      smask |= ((hr <= R + 1 && hx >= 1 && hx <= W) ? 1u : 0u) << i;
+      topmask |= (hr == 0 ? 1u : 0u) << i;
+      botmask |= (hr == R + 1 ? 1u : 0u) << i;
+    }
+  }
+  const int ldst = (tid >> 3) * PITCH + pc * 16;       // + i * 64 * PITCH
+  const char* const dyb = reinterpret_cast<const char*>(p.dy) + ((long)cot * 64 + pc * 8) * 2;
+  const char* const xb = reinterpret_cast<const char*>(p.x) + ((long)cit * 64 + pc * 8) * 2;
+  const char* const zsrc = reinterpret_cast<const char*>(p.zeros);
+
+  // the eight staged pieces are eight named register sets (an array captured by the lambdas below ends up in scratch memory, and the
+  // store to scratch waits for every load at once)
+  static_assert(NPC == 8, "the staging registers are spelled out for eight pieces");
+  uint4 st0, st1, st2, st3, st4, st5, st6, st7;
+#define EVK_C3_PIECES(M) M(0, st0) M(1, st1) M(2, st2) M(3, st3) M(4, st4) M(5, st5) M(6, st6) M(7, st7)
+  int yi = row_begin % H;            // row (inside its image) of the tile whose loads are issued next: advanced by R per tile
+  auto issue = [&](int tile) {
+    const long m0 = (long)(row_begin + tile * R) * W;
+    const unsigned vm = smask & ~(yi == 0 ? topmask : 0u) & ~(yi + R == H ? botmask : 0u);
+    const char* const tdy = dyb + m0 * p.Co * 2;
+    const char* const tx = xb + m0 * p.Ci * 2;
+    auto ld = [&](int i) {
+      const char* src = (((isdy >> i) & 1u) ? tdy : tx) + offs[i];
+      return *reinterpret_cast<const uint4*>(((vm >> i) & 1u) ? src : zsrc);
+    };
+#define EVK_C3_LD(i, r) r = ld(i);
+    EVK_C3_PIECES(EVK_C3_LD)
+#undef EVK_C3_LD
+    yi += R;
+    if (yi >= H) yi = 0;
+  };
+  auto commit = [&](int stage) {
+    char* d = smem + stage * STAGE_BYTES + ldst;
+#define EVK_C3_ST(i, r) \
+    if ((i + 1) * 64 <= STAGE_ROWS || (tid >> 3) + 64 * i < STAGE_ROWS) *reinterpret_cast<uint4*>(d + i * 64 * PITCH) = r;
+    EVK_C3_PIECES(EVK_C3_ST)
+#undef EVK_C3_ST
+  };
+
+  f32x4 acc[9][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  const lds_char* const L = (const lds_char*)(uintptr_t)(uint32_t)(uintptr_t)smem;
+  const int doff = (4 * fq + q4) * PITCH + wco * 32 + pp * 8;                  // dy fragment, MFMA step 0, first co tile
+  const int hoff = TPXP * PITCH + wci * 32 + pp * 8;                           // halo row 0, this wave's ci tile
+  const int rowb = W2 * PITCH;
+  // One 32-pixel MFMA step = 2 dy fragments (the wave's two co tiles) + 9 x fragments (its ci tile at the nine taps) -> 18 MFMAs.
+  // The fragments of step k + 1 are read while the MFMAs of step k run (two register sets, the loop unrolled by two).
+  struct Frags { bf16x8 dy[2]; bf16x8 x[9]; };
+  auto load = [&](Frags& f, const lds_char* da, const lds_char* xl, const lds_char* xh) {
+    f.dy[0] = frag2(da, da + 16 * PITCH);
+    f.dy[1] = frag2(da + 32, da + 16 * PITCH + 32);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const lds_char* const bl = xl + (kh - 1) * rowb;
+      const lds_char* const bh = xh + (kh - 1) * rowb;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) f.x[kh * 3 + kw] = frag2(bl + (kw - 1) * PITCH, bh + (kw - 1) * PITCH);
+    }
+  };
+  auto mac = [&](const Frags& f) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      acc[t][0] = EVK_MFMA_16x16x32(f.x[t], f.dy[0], acc[t][0], 0, 0, 0);
+      acc[t][1] = EVK_MFMA_16x16x32(f.x[t], f.dy[1], acc[t][1], 0, 0, 0);
+    }
+  };
+  // (pixel row j, column x) of the lane's two pixel groups at MFMA step 0, and the advance per step (32 pixels)
+  int j0[2], x0[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int px = 4 * fq + q4 + 16 * h;
+    j0[h] = fdiv(px, W, p.inv_w);
+    x0[h] = px - j0[h] * W;
+  }
+  const int dj = 32 / W, dx = 32 - dj * W;
+  const int full_kgs = (full_px + 31) >> 5;
+  auto compute = [&](int stage) {
+    const lds_char* const S = L + stage * STAGE_BYTES;
+    int j[2] = {j0[0], j0[1]}, x[2] = {x0[0], x0[1]};
+    const lds_char* da = S + doff;
+    auto fetch = [&](Frags& f) {                           // fragments of the next step; advances (j, x) and the dy address
+      int row[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        row[h] = (min(j[h], R - 1) + 1) * W2 + x[h] + 1;     // pixels beyond the tile multiply zero dy rows: any staged row will do
+        x[h] += dx; j[h] += dj;
+        if (x[h] >= W) { x[h] -= W; ++j[h]; }
+      }
+      load(f, da, S + hoff + row[0] * PITCH, S + hoff + row[1] * PITCH);
+      da += 32 * PITCH;
+    };
+    Frags fa, fb;
+    fetch(fa);
+    int kg = 0;
+    while (true) {
+      if (kg + 1 < full_kgs) fetch(fb);
+      mac(fa);
+      if (++kg >= full_kgs) break;
+      if (kg + 1 < full_kgs) fetch(fa);
+      mac(fb);
+      if (++kg >= full_kgs) break;
+    }
+  };
+
+  if (ntiles > 0) {
+    issue(0);
+    commit(0);
+    __syncthreads();
+    if (p.stamps && tid == 0) p.stamps[blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memtime();
+    for (int tile = 0; tile < ntiles; ++tile) {
+      const bool more = tile + 1 < ntiles;
+      if (more) issue(tile + 1);
+      compute(tile & 1);
+      if (more) commit((tile + 1) & 1);
+      __syncthreads();
+    }
+    if (p.stamps && tid == 0) p.stamps[blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memtime();
+  }
+#undef EVK_C3_PIECES
+
+  // slab [tap][split][co][ci]: lane holds co = .. + (lane & 15), ci = .. + 4 (lane >> 4) + 0..3
+  const long mn = (long)p.Co * p.Ci;
+  const int co = cot * 64 + wco * 16 + (lane & 15);
+  const int ci = cit * 64 + wci * 16 + fq * 4;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    float* s0 = p.slab + ((long)t * p.nsplit + split) * mn + (long)co * p.Ci + ci;
+    *reinterpret_cast<float4*>(s0) = make_float4(acc[t][0][0], acc[t][0][1], acc[t][0][2], acc[t][0][3]);
+    *reinterpret_cast<float4*>(s0 + 16L * p.Ci) = make_float4(acc[t][1][0], acc[t][1][1], acc[t][1][2], acc[t][1][3]);
+  }
+  if (p.stamps && tid == 0) { p.stamps[blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memtime(); p.stamps[blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime(); }
+}
+
+struct Plan { int R, tpxp, rps, nsplit, pairs_ci, npairs; };
+
+bool make_plan(int N, int H, int W, int Ci, int Co, Plan& pl) {
+  if (N <= 0 || H <= 0 || W <= 0 || Ci < 64 || (Ci % 64) || Co < 64 || (Co % 64) || W + 2 > 0xffff) return false;
+  const int TR = N * H;
+  if ((long)TR * (H + 1) >= (1L << 22) || (long)TR * W >= (1L << 31)) return false;
+  // rows per tile: the largest divisor of H whose pixels (rounded up to 32) and halo fit one stage; tiles never cross an image
+  int R = 0;
+  for (int r = H; r >= 1; --r) {
+    if (H % r) continue;
+    const int tp = (r * W + 31) / 32 * 32;
+    if (tp + (r + 2) * (W + 2) <= STAGE_ROWS) { R = r; break; }
+  }
+  if (R < 1 || R * W < 48) return false;                  // tiles of under 48 pixels: the tile path is the better kernel
+  pl.R = R;
+  pl.tpxp = (R * W + 31) / 32 * 32;
+  pl.pairs_ci = Ci / 64;
+  pl.npairs = (Ci / 64) * (Co / 64);
+  static const int target = [] { const char* e = getenv("EVK_C3W_BLOCKS"); return e ? atoi(e) : 256; }();
+  int ns = (target + pl.npairs / 2) / pl.npairs;
+  const int tiles = (int)cdiv(TR, R);
+  if (ns > tiles) ns = tiles;
+  if (ns < 1) ns = 1;
+  pl.rps = (int)cdiv(cdiv(TR, ns), R) * R;
+  pl.nsplit = (int)cdiv(TR, pl.rps);
+  return true;
+}
+
+}  // namespace wgk
 
 bool halo_enabled() {
   static const int on = [] { const char* e = getenv("EVK_CONV3X3_HALO"); return e ? atoi(e) : 1; }();
@@ -397,6 +658,7 @@ int evk_conv3x3_halo(const void* x, const void* w, void* y, int32_t N, int32_t H
   p.colstats = colstats; p.gatestats = gatestats;
   static const int probe = [] { const char* e = getenv("EVK_C3_PROBE"); return e ? atoi(e) : 0; }();
   p.kmul = probe ? 0 : 1;
+  p.inv_w = 1.f / W; p.inv_w2 = 1.f / (W + 2); p.inv_h = 1.f / H; p.inv_h1 = 1.f / (H + 1);
   p.stamps = g_stamps;
   if (colstats || gatestats) {
     EVK_REQUIRE(nblk && part_bytes >= evk_conv3x3_halo_part_bytes(N, H, W, Co), "conv3x3_halo: statistics buffer too small");
@@ -411,6 +673,57 @@ int evk_conv3x3_halo(const void* x, const void* w, void* y, int32_t N, int32_t H
   ProfScope ps(EVK_FAM_GEMM, s, 2.0 * N * H * W * (double)Co * 9 * C);
   hipLaunchKernelGGL(conv3x3_halo_kernel, dim3(p.tilesM * p.tilesN), dim3(NTH), LDS_BYTES, s, p);
   return evk_check_launch("conv3x3_halo_kernel");
+}
+
+int evk_conv3x3_wgrad_halo_supported(int32_t N, int32_t H, int32_t W, int32_t Ci, int32_t Co) {
+  wgk::Plan pl;
+  return wgk::make_plan(N, H, W, Ci, Co, pl) ? 1 : 0;
+}
+
+int64_t evk_conv3x3_wgrad_halo_ws_bytes(int32_t N, int32_t H, int32_t W, int32_t Ci, int32_t Co) {
+  wgk::Plan pl;
+  if (!wgk::make_plan(N, H, W, Ci, Co, pl)) return 0;
+  return 9LL * pl.nsplit * Co * Ci * (int64_t)sizeof(float);
+}
+
+int evk_conv3x3_wgrad_halo(const void* dy, const void* x, float* dw, int32_t N, int32_t H, int32_t W, int32_t Ci, int32_t Co,
+                           void* ws, int64_t ws_bytes, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(dy && x && dw && ws, "conv3x3_wgrad_halo: null operand / workspace");
+  wgk::Plan pl;
+  EVK_REQUIRE(wgk::make_plan(N, H, W, Ci, Co, pl), "conv3x3_wgrad_halo: unsupported shape N=%d H=%d W=%d Ci=%d Co=%d (channels %% 64, rows that tile)", N, H, W, Ci, Co);
+  EVK_REQUIRE(ws_bytes >= evk_conv3x3_wgrad_halo_ws_bytes(N, H, W, Ci, Co), "conv3x3_wgrad_halo: workspace too small");
+  EVK_REQUIRE(al16(dy) && al16(x) && al16(dw) && al16(ws), "conv3x3_wgrad_halo: operands must be 16-byte aligned");
+  wgk::W3P p{};
+  p.dy = (const bf16_t*)dy; p.x = (const bf16_t*)x; p.slab = (float*)ws;
+  p.N = N; p.H = H; p.W = W; p.Co = Co; p.Ci = Ci;
+  p.R = pl.R; p.tpxp = pl.tpxp; p.rps = pl.rps; p.nsplit = pl.nsplit; p.pairs_ci = pl.pairs_ci; p.npairs = pl.npairs;
+  p.inv_w = 1.f / W; p.inv_w2 = 1.f / (W + 2); p.inv_h = 1.f / H; p.inv_h1 = 1.f / (H + 1);
+  static void* zeros = nullptr;
+  if (!zeros) {
+    EVK_REQUIRE(hipGetSymbolAddress(&zeros, HIP_SYMBOL(wgk::g_zero16)) == hipSuccess && zeros, "conv3x3_wgrad_halo: no address for the zero block");
+  }
+  p.zeros = zeros;
+  p.stamps = g_stamps;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgk::conv3x3_wgrad_halo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, wgk::LDS_BYTES);
+    attr_done = true;
+  }
+  evk_prof_tag(Co, Ci, N * H * W, 9, EVK_A_KSTR, EVK_B_WGATHER);
+  ProfScope ps(EVK_FAM_GEMM, s, 2.0 * N * H * W * (double)Co * 9 * Ci);
+  hipLaunchKernelGGL(wgk::conv3x3_wgrad_halo_kernel, dim3(pl.npairs * pl.nsplit), dim3(NTH), wgk::LDS_BYTES, s, p);
+  if (int e = evk_check_launch("conv3x3_wgrad_halo_kernel")) return e;
+  // dw[co][tap][ci] += sum over the K-slices: gemm.hip's split-K reduction with the tap as batch index
+  return evk_splitk_reduce_launch(p.slab, dw, (long)Co * Ci, Co, Ci, pl.nsplit, 9, 9L * Ci, 0, Ci, 9, s);
+}
+
+int evk_conv3x3_wgrad_halo_routes(const evk_conv_geom* g) {
+  static const int on = [] { const char* e = getenv("EVK_CONV3X3_WGRAD_HALO"); return e ? atoi(e) : 1; }();
+  if (!on || !g) return 0;
+  if (g->KH != 3 || g->KW != 3 || g->stride_h != 1 || g->stride_w != 1 || g->pad_h != 1 || g->pad_w != 1) return 0;
+  if (g->Hi != g->Ho || g->Wi != g->Wo) return 0;
+  return evk_conv3x3_wgrad_halo_supported(g->N, g->Hi, g->Wi, g->Ci, g->Co);
 }
 
 // diagnostic: while buf is non-null every evk_conv3x3_halo launch writes, per workgroup, 8 x uint64 {s_memtime at entry, before the

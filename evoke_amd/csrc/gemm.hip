@@ -1114,6 +1114,12 @@ inline bool al(const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) % 
 
 }  // namespace
 
+int evk_splitk_reduce_launch(const float* slab, float* C, long mn, int M, int N, int splitk, int bi, long ldc, long sCo, long sCi, int batch, hipStream_t s) {
+  SkrP r{slab, C, mn, M, N, splitk, bi, ldc, sCo, sCi};
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)cdiv(mn / 4, 16), batch), dim3(256), 0, s, r);
+  return evk_check_launch("splitk_reduce");
+}
+
 // y[M][N] = act(LayerNorm(x)[M][512] . W[N][512]^T + bias) (+ resid): the norm happens in the GEMM's operand load (decode step)
 extern "C" int evk_linear_ln(const void* x, const float* gamma, const float* beta, const void* dgam, const void* dbet, int64_t ld_delta,
                              float eps, int32_t mode, const void* w, const float* bias, const void* resid, int64_t ldr, void* y, int32_t y_dtype,

@@ -164,6 +164,16 @@ int64_t evk_conv3x3_halo_part_bytes(int32_t N, int32_t H, int32_t W, int32_t Co)
 int evk_conv3x3_halo(const void* x, const void* w, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t Co,
                      const void* resid, int64_t ldr, const void* gate, int64_t ldg, float* colstats, float* gatestats,
                      int64_t part_bytes, int32_t* nblk, evk_stream_t stream);
+/* Weight gradient of the same convolution (torchvision Bottleneck.conv2; the reference gets it from autograd over
+ * modules/visual_extractor.py:30-38): dw[Co][3][3][Ci] (f32) += sum over pixels of dy[px][co] * x[px + tap][ci].  A workgroup owns a pixel
+ * slice and a 64 x 64 (co, ci) block of the filter and accumulates all nine taps in registers from one dy tile and one x halo tile in LDS
+ * (a quarter of the LDS-fill bytes per flop of the per-tap tile path); K-slices leave as f32 slabs in ws (evk_conv3x3_wgrad_halo_ws_bytes)
+ * and are added into dw by the split-K reduction.  Ci, Co multiples of 64; evk_conv2d_wgrad routes here (EVK_CONV3X3_WGRAD_HALO=0 disables). */
+int evk_conv3x3_wgrad_halo_supported(int32_t N, int32_t H, int32_t W, int32_t Ci, int32_t Co);
+int64_t evk_conv3x3_wgrad_halo_ws_bytes(int32_t N, int32_t H, int32_t W, int32_t Ci, int32_t Co);
+int evk_conv3x3_wgrad_halo(const void* dy, const void* x, float* dw, int32_t N, int32_t H, int32_t W, int32_t Ci, int32_t Co,
+                           void* ws, int64_t ws_bytes, evk_stream_t stream);
+int evk_conv3x3_wgrad_halo_routes(const evk_conv_geom* g);
 /* diagnostic: in-kernel cycle stamps of every later evk_conv3x3_halo launch into buf (8 x uint64 per workgroup), null = off */
 int evk_conv3x3_halo_debug_stamps(void* buf);
 int evk_conv3x3_halo_routes(const evk_conv_geom* g, int32_t C, int32_t Co, int64_t part_bytes, int32_t want_stats);

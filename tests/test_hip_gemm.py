@@ -353,11 +353,48 @@ def test_halo_conv3x3_forward_and_flipped_data_gradient(H, N, Hh, W, Ci, Co):
         assert float((s[1] - (gf * zf).sum(0)).abs().max()) <= 2e-5 * float((gf * zf).abs().sum(0).max()) + 1e-3
 
 
+WG_HALO_SHAPES = [(2, 24, 24, 256, 256), (5, 7, 7, 64, 128), (3, 14, 14, 128, 64), (2, 48, 48, 128, 128), (3, 12, 12, 192, 320),
+                  (3, 10, 23, 64, 64), (2, 96, 96, 64, 64), (7, 6, 40, 128, 64), (64, 8, 8, 64, 64)]
+
+
+@pytest.mark.parametrize('N,Hh,W,Ci,Co', WG_HALO_SHAPES)
+def test_halo_conv3x3_weight_gradient(H, N, Hh, W, Ci, Co):
+    """csrc/conv3x3.hip, evk_conv3x3_wgrad_halo: dw += dy^T x over all nine taps from one dy tile + one x halo tile in LDS, K-slices through
+    f32 slabs.  Against the fp32 weight gradient of the same rounded operands (f32 accumulation order only: tolerance ~ sqrt(pixels)
+    ulps of f32 on sums of 16-bit products), accumulation into a non-zero dw, tiles at the top / bottom edge of an image, tiles whose
+    pixel count is not a multiple of the 32-pixel MFMA step, uneven K-slices."""
+    assert H.lib.evk_conv3x3_wgrad_halo_supported(N, Hh, W, Ci, Co) == 1
+    x = rnd(N, Hh, W, Ci, seed=31, scale=0.7)
+    dy = rnd(N, Hh, W, Co, seed=32, scale=0.5)
+    xr = x.float().permute(0, 3, 1, 2)
+    wr = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+    F.conv2d(xr, wr, None, 1, 1).backward(dy.float().permute(0, 3, 1, 2))
+    want = wr.grad.permute(0, 2, 3, 1).contiguous()                   # [Co][3][3][Ci]
+    nb = H.lib.evk_conv3x3_wgrad_halo_ws_bytes(N, Hh, W, Ci, Co)
+    ws = torch.full((nb // 4,), float('nan'), device='cuda')
+    dw = torch.full((Co, 3, 3, Ci), 0.5, dtype=torch.float32, device='cuda')
+    xd, dyd = x.cuda(), dy.cuda()
+    H.check(H.lib.evk_conv3x3_wgrad_halo(H.ptr(dyd), H.ptr(xd), H.ptr(dw), N, Hh, W, Ci, Co, H.ptr(ws), nb, H.stream()))
+    torch.cuda.synchronize()
+    close(dw - 0.5, want, 2e-4, 3e-3 * (N * Hh * W) ** 0.5)
+    # the routed entry point takes the same kernel: identical result
+    g = H.conv_geom(N, Hh, W, Ci, Co, 3, 3, 1, 1)
+    nb2 = H.lib.evk_conv2d_wgrad_ws_bytes(C.byref(g))
+    assert nb2 >= nb
+    ws2 = torch.empty(nb2 // 4, device='cuda')
+    dw2 = torch.full((Co, 3, 3, Ci), 0.5, dtype=torch.float32, device='cuda')
+    H.check(H.lib.evk_conv2d_wgrad(H.ptr(dyd), H.ptr(xd), H.ptr(dw2), C.byref(g), H.ptr(ws2), nb2, H.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(dw, dw2)
+
+
 def test_halo_conv3x3_refuses_what_it_cannot_tile(H):
     assert H.lib.evk_conv3x3_halo_supported(1, 8, 200, 64, 128) == 0       # the halo of even one 200-pixel row exceeds the LDS buffer
     assert H.lib.evk_conv3x3_halo_supported(4, 4, 5, 64, 128) == 1         # tiny images: many per tile
     assert H.lib.evk_conv3x3_halo_supported(2, 24, 24, 96, 128) == 0       # C % 64
     assert H.lib.evk_conv3x3_halo_supported(2, 24, 24, 64, 64) == 0        # Co % 128
+    assert H.lib.evk_conv3x3_wgrad_halo_supported(7, 5, 40, 128, 64) == 0  # no divisor of H = 5 gives a tile of >= 48 pixels that fits
+    assert H.lib.evk_conv3x3_wgrad_halo_supported(2, 24, 24, 96, 64) == 0  # Ci % 64
     x = torch.zeros(2, 24, 24, 96, dtype=STORE_DTYPE, device='cuda')
     w = torch.zeros(128, 3, 3, 96, dtype=STORE_DTYPE, device='cuda')
     y = torch.zeros(2, 24, 24, 128, dtype=STORE_DTYPE, device='cuda')
