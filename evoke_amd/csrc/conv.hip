@@ -126,6 +126,9 @@ int evk_conv2d_fwd_stats(const void* x, const void* w, void* y, const evk_conv_g
 int evk_conv2d_fwd_stats_tile(const void* x, const void* w, void* y, const evk_conv_geom* g, float* part, int64_t part_bytes,
                               int32_t* nblk, evk_stream_t stream) {
   if (int e = check_geom(g)) return e;
+  if (is_pointwise(g) && evk_gemm_strip_routes((int64_t)g->N * g->Ho * g->Wo, g->Co, g->Ci, part ? part_bytes : 0, part != nullptr))   // gemm_strip.hip
+    return evk_gemm_strip(x, g->Ci, w, g->Ci, y, g->Co, (int64_t)g->N * g->Ho * g->Wo, g->Co, g->Ci, nullptr, 0, nullptr, 0, part, nullptr,
+                          part_bytes, nblk, stream);
   if (evk_conv3x3_halo_routes(g, g->Ci, g->Co, part ? part_bytes : 0, part != nullptr))      // conv3x3.hip: halo tile in LDS
     return evk_conv3x3_halo(x, w, y, g->N, g->Hi, g->Wi, g->Ci, g->Co, nullptr, 0, nullptr, 0, part, nullptr, part_bytes, nblk, stream);
   evk_gemm d{};
@@ -232,6 +235,12 @@ int evk_conv2d_dgrad_flipped_gated_stats(const void* dy, const void* wt, const v
   EVK_REQUIRE(g->stride_h == 1 && g->stride_w == 1 && g->KH == 2 * g->pad_h + 1 && g->KW == 2 * g->pad_w + 1 && g->Co % 8 == 0 && g->Ci % 8 == 0,
               "conv dgrad (flipped weights): stride 1, pad = (K - 1) / 2, channels %% 8");
   const int T = g->KH * g->KW;
+  // pointwise: dx[M][Ci] = dy[M][Co] . wt[Ci][Co]^T -- the strip GEMM when it pays
+  if (is_pointwise(g) && evk_gemm_strip_routes((int64_t)g->N * g->Hi * g->Wi, g->Ci, g->Co, part ? part_bytes : 0, part != nullptr)) {
+    EVK_REQUIRE(!part || gate, "conv dgrad: gate statistics need a gate");
+    return evk_gemm_strip(dy, g->Co, wt, g->Co, dx, g->Ci, (int64_t)g->N * g->Hi * g->Wi, g->Ci, g->Co, resid, g->Ci, gate, g->Ci, nullptr, part,
+                          part_bytes, nblk, stream);
+  }
   // the data gradient is a forward convolution of dy (Co channels) into dx (Ci channels) over wt: same halo kernel
   if (evk_conv3x3_halo_routes(g, g->Co, g->Ci, part ? part_bytes : 0, part != nullptr)) {
     EVK_REQUIRE(!part || gate, "conv dgrad: gate statistics need a gate");

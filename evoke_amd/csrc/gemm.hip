@@ -972,6 +972,45 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const SkrP p) {
   }
 }
 
+// The same sum for large outputs: one float4 column per thread, 256 consecutive columns per block (whole 4 KB runs of every slab),
+// four slabs in flight per thread.  Order of the additions: ((s0 + s1) + (s2 + s3)) per group of four slabs, groups in order.
+__global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(const SkrP p) {
+  const long nq = p.mn >> 2;
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= nq) return;
+  const int z = blockIdx.y;
+  const float4* base = reinterpret_cast<const float4*>(p.slab + (long)z * p.splitk * p.mn) + q;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  int sp = 0;
+  for (; sp + 3 < p.splitk; sp += 4) {
+    const float4 t0 = base[(long)sp * nq], t1 = base[(long)(sp + 1) * nq], t2 = base[(long)(sp + 2) * nq], t3 = base[(long)(sp + 3) * nq];
+    a.x += (t0.x + t1.x) + (t2.x + t3.x); a.y += (t0.y + t1.y) + (t2.y + t3.y);
+    a.z += (t0.z + t1.z) + (t2.z + t3.z); a.w += (t0.w + t1.w) + (t2.w + t3.w);
+  }
+  for (; sp < p.splitk; ++sp) { const float4 t = base[(long)sp * nq]; a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; }
+  const long idx = q << 2;
+  const int m = (int)(idx / p.N), n = (int)(idx - (long)m * p.N);
+  const int zo = z / p.bi, zi = z - zo * p.bi;
+  float* c = p.C + zo * p.sCo + zi * p.sCi + (long)m * p.ldc + n;
+  if ((reinterpret_cast<uintptr_t>(c) & 15) == 0) {
+    float4 t = *reinterpret_cast<float4*>(c);
+    t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
+    *reinterpret_cast<float4*>(c) = t;
+  } else {
+    c[0] += a.x; c[1] += a.y; c[2] += a.z; c[3] += a.w;
+  }
+}
+
+// one launch of the reduction: the wide kernel once the output gives every CU a few blocks of whole 4 KB runs (EVK_REDUCE_WIDE=0/1 forces)
+inline int launch_splitk_reduce(const SkrP& r, int batch, hipStream_t s) {
+  static const int mode = [] { const char* e = getenv("EVK_REDUCE_WIDE"); return e ? atoi(e) : -1; }();
+  const long nq = r.mn >> 2;
+  const bool wide = mode >= 0 ? mode == 1 : cdiv(nq, 256) * batch >= 192;
+  if (wide) hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3((int)cdiv(nq, 256), batch), dim3(256), 0, s, r);
+  else hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)cdiv(nq, 16), batch), dim3(256), 0, s, r);
+  return evk_check_launch("splitk_reduce");
+}
+
 constexpr long SLAB_MAX_BYTES = 192L << 20;
 
 // LDS staging per operand mode (measured on MI355X, FineTune 384^2 bs 32, profiles/r01_*): a single 32-40 KB buffer
@@ -1066,8 +1105,7 @@ int launch_modes(GemmP& p, int batch, int splitk_req, void* ws, long ws_bytes, c
         int rc = evk_check_launch("gemm_small_kernel");
         if (rc == EVK_OK) {
           SkrP r{p.slab, reinterpret_cast<float*>(p.C), p.slab_mn, p.M, p.N, 2 * sk, p.bi, p.ldc, p.sCo, p.sCi};
-          hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)cdiv(p.slab_mn / 4, 16), batch), dim3(256), 0, s, r);
-          rc = evk_check_launch("splitk_reduce");
+          rc = launch_splitk_reduce(r, batch, s);
         }
         return rc;
       }
@@ -1104,8 +1142,7 @@ int launch_modes(GemmP& p, int batch, int splitk_req, void* ws, long ws_bytes, c
   }
   if (rc == EVK_OK && p.slab) {
     SkrP r{p.slab, reinterpret_cast<float*>(p.C), p.slab_mn, p.M, p.N, splitk, p.bi, p.ldc, p.sCo, p.sCi};
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)cdiv(p.slab_mn / 4, 16), batch), dim3(256), 0, s, r);
-    rc = evk_check_launch("splitk_reduce");
+    rc = launch_splitk_reduce(r, batch, s);
   }
   return rc;
 }
@@ -1116,8 +1153,7 @@ inline bool al(const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) % 
 
 int evk_splitk_reduce_launch(const float* slab, float* C, long mn, int M, int N, int splitk, int bi, long ldc, long sCo, long sCi, int batch, hipStream_t s) {
   SkrP r{slab, C, mn, M, N, splitk, bi, ldc, sCo, sCi};
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)cdiv(mn / 4, 16), batch), dim3(256), 0, s, r);
-  return evk_check_launch("splitk_reduce");
+  return launch_splitk_reduce(r, batch, s);
 }
 
 // y[M][N] = act(LayerNorm(x)[M][512] . W[N][512]^T + bias) (+ resid): the norm happens in the GEMM's operand load (decode step)

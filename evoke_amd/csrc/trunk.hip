@@ -104,6 +104,10 @@ int make_plan(const evk_trunk_cfg* cfg, int N, int H, int W, Plan& P) {
     const evk_conv_geom& g = P.pairs[i].g;
     if (g.KH == 3 && g.KW == 3 && g.stride_h == 1 && g.stride_w == 1 && g.pad_h == 1 && g.pad_w == 1)
       P.wflip[i] = take((long)g.Co * 9 * g.Ci * 2);
+    // contracting pointwise data gradients (Bottleneck.conv3) the strip GEMM takes: their weights transposed to [Ci][Co]
+    else if (g.KH == 1 && g.KW == 1 && g.stride_h == 1 && g.stride_w == 1 && g.pad_h == 0 && g.pad_w == 0 && g.Co > g.Ci &&
+             evk_gemm_strip_routes((int64_t)g.N * g.Hi * g.Wi, g.Ci, g.Co, 0, 0))
+      P.wflip[i] = take((long)g.Co * g.Ci * 2);
   }
   P.total = off;
   return EVK_OK;
@@ -280,11 +284,11 @@ int evk_trunk_backward(const evk_trunk_cfg* cfg, const evk_trunk_layer* layers, 
   static const bool x_stats = [] { const char* e = getenv("EVK_BN_XSTATS"); return !e || atoi(e) != 0; }();
   int nbz = 0;                           // > 0: the kernel that produced gZ left bn3's backward sums of the current block in P.part
   static const bool flip_on = [] { const char* e = getenv("EVK_DGRAD_FLIP"); return !e || atoi(e) != 0; }();
-  if (flip_on) {        // flipped / transposed weights of every stride-1 3x3 convolution, one launch (evk_conv_flip_weights)
+  if (flip_on) {        // flipped / transposed weights of every stride-1 3x3 convolution and every conv3 the strip GEMM takes, one launch (evk_conv_flip_weights)
     std::vector<const void*> ws_; std::vector<void*> wt_; std::vector<int32_t> co_, ci_, k_;
     for (size_t i = 1; i < P.pairs.size(); ++i)
       if (P.wflip[i] >= 0) {
-        ws_.push_back(layers[i].w); wt_.push_back(c.at(P.wflip[i])); co_.push_back(P.pairs[i].g.Co); ci_.push_back(P.pairs[i].g.Ci); k_.push_back(3);
+        ws_.push_back(layers[i].w); wt_.push_back(c.at(P.wflip[i])); co_.push_back(P.pairs[i].g.Co); ci_.push_back(P.pairs[i].g.Ci); k_.push_back(P.pairs[i].g.KH);
       }
     if (!ws_.empty()) TRY(evk_conv_flip_weights(ws_.data(), wt_.data(), co_.data(), ci_.data(), k_.data(), k_.data(), (int32_t)ws_.size(), stream));
   }
@@ -326,8 +330,12 @@ int evk_trunk_backward(const evk_trunk_cfg* cfg, const evk_trunk_layer* layers, 
     int nb1 = 0, nb0 = 0;
     if (nbz > 0) TRY(bn_backward_from_xstat(c, i + 2, gZ, nbz));
     else TRY(bn_backward(c, i + 2, gZ, nullptr, 0));
-    TRY(evk_conv2d_dgrad_gated_stats(c.at(P.pairs[i + 2].dy), layers[i + 2].w, nullptr, c.at(P.pairs[i + 1].z), S1, &P.pairs[i + 2].g,
-                                     gs1 ? part : nullptr, P.part_bytes, &nb1, stream));
+    if (flip_on && P.wflip[i + 2] >= 0)
+      TRY(evk_conv2d_dgrad_flipped_gated_stats(c.at(P.pairs[i + 2].dy), c.at(P.wflip[i + 2]), nullptr, c.at(P.pairs[i + 1].z), S1, &P.pairs[i + 2].g,
+                                               gs1 ? part : nullptr, P.part_bytes, &nb1, stream));
+    else
+      TRY(evk_conv2d_dgrad_gated_stats(c.at(P.pairs[i + 2].dy), layers[i + 2].w, nullptr, c.at(P.pairs[i + 1].z), S1, &P.pairs[i + 2].g,
+                                       gs1 ? part : nullptr, P.part_bytes, &nb1, stream));
     TRY(wgrad(i + 2, c.at(P.pairs[i + 1].z)));
     if (gs1) TRY(bn_backward_from_gate(c, i + 1, S1, nb1));
     else TRY(bn_backward(c, i + 1, S1, nullptr, 0));

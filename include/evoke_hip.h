@@ -150,6 +150,19 @@ int evk_conv_flip_weights(const void* const* w, void* const* wt, const int32_t* 
                           int32_t n_layers, evk_stream_t stream);
 int evk_conv2d_dgrad_flipped_gated_stats(const void* dy, const void* wt, const void* resid, const void* gate, void* dx, const evk_conv_geom* g,
                                          float* part, int64_t part_bytes, int32_t* nblk, evk_stream_t stream);
+/* Strip GEMM for the tall products of the contracting pointwise convolutions (gemm_strip.hip): C[M][N] = A[M][K] . B[N][K]^T, 16-bit
+ * row-major operands, f32 accumulation -- torchvision Bottleneck.conv1 forward (4 planes -> planes; colstats = batch-norm partials as
+ * evk_conv2d_fwd_stats) and the data gradient of Bottleneck.conv3 over the transposed weights of evk_conv_flip_weights (resid, ReLU
+ * gate, gatestats as evk_conv2d_dgrad_gated_stats), both driven by modules/visual_extractor.py:30-38.  A workgroup owns 288 rows x
+ * 128 columns (layer3: exactly one workgroup per CU), three LDS stages per operand, one barrier per 64-deep K step.  N % 128 == 0,
+ * K % 64 == 0; evk_gemm_strip_routes is what evk_conv2d_fwd_stats / evk_conv2d_dgrad_flipped_gated_stats ask before taking it
+ * (>= 200 workgroups, K >= 256; EVK_GEMM_STRIP=0 disables).  The statistics buffer holds evk_gemm_strip_part_bytes. */
+int evk_gemm_strip_supported(int64_t M, int32_t N, int32_t K);
+int64_t evk_gemm_strip_part_bytes(int64_t M, int32_t N);
+int evk_gemm_strip(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int32_t N, int32_t K,
+                   const void* resid, int64_t ldr, const void* gate, int64_t ldg, float* colstats, float* gatestats, int64_t part_bytes,
+                   int32_t* nblk, evk_stream_t stream);
+int evk_gemm_strip_routes(int64_t M, int32_t N, int32_t K, int64_t part_bytes, int32_t want_stats);
 /* 3x3 / stride 1 / pad 1 convolution with the input halo tile resident in LDS (conv3x3.hip): torchvision Bottleneck.conv2 of every
  * non-strided block as driven by modules/visual_extractor.py:30-38 -- forward (x [N][H][W][C], w [Co][3][3][C], y [N][H][W][Co], 16-bit
  * NHWC; colstats: *nblk rows of [2][Co] partial (sum, sum of squares) of the f32 result for the batch norm that follows) and, over

@@ -284,6 +284,82 @@ def test_weight_stationary_pointwise_conv_forward_and_data_gradient(H, M, K, N):
     assert float((s3[2] - want).abs().max()) <= 1e-5 * scale + 1e-4
 
 
+STRIP_SHAPES = [(2304, 128, 256), (1000, 256, 64), (289, 128, 128), (5000, 384, 192), (36864, 256, 1024), (1, 128, 64), (577, 128, 640)]
+
+
+@pytest.mark.parametrize('M,N,K', STRIP_SHAPES)
+def test_strip_gemm_forward_statistics_and_gated_data_gradient(H, M, N, K):
+    """csrc/gemm_strip.hip through its own entry point: one to sixteen K steps (the pipeline's prologue / clamped tail loads), ragged
+    last strip, both epilogues.  Against the fp32 product of the same rounded operands (one output rounding + the f32 summation order);
+    statistics partials against the sums of the UNROUNDED / gated result."""
+    assert H.lib.evk_gemm_strip_supported(M, N, K) == 1
+    a, b = rnd(M, K, seed=41, scale=0.7).cuda(), rnd(N, K, seed=42, scale=(1.0 / K) ** 0.5).cuda()
+    ref = (a.float() @ b.float().t()).cpu()
+    c = torch.full((M, N), 9.0, dtype=STORE_DTYPE, device='cuda')
+    nb = H.lib.evk_gemm_strip_part_bytes(M, N)
+    part = torch.full((nb // 4,), 3.0, device='cuda')
+    nblk = C.c_int32(0)
+    H.check(H.lib.evk_gemm_strip(H.ptr(a), K, H.ptr(b), K, H.ptr(c), N, M, N, K, None, 0, None, 0, H.ptr(part), None, nb, C.byref(nblk), H.stream()))
+    torch.cuda.synchronize()
+    rt = 2.0 ** -8 if STORE_DTYPE == torch.bfloat16 else 2.0 ** -10
+    close(c, ref, rt, 2e-3)
+    assert nblk.value * 2 * N * 4 == nb
+    s = part.view(nblk.value, 2, N).sum(0).cpu()
+    assert float((s[0] - ref.sum(0)).abs().max()) <= 1e-5 * float(ref.abs().sum(0).max()) + 1e-4
+    assert float((s[1] - (ref ** 2).sum(0)).abs().max()) <= 1e-5 * float((ref ** 2).sum(0).max()) + 1e-4
+    skip = rnd(M, N, seed=43, scale=0.3).cuda()
+    gate = torch.relu(rnd(M, N, seed=44).float()).to(STORE_DTYPE).cuda()
+    c2 = torch.full((M, N), 5.0, dtype=STORE_DTYPE, device='cuda')
+    part.fill_(3.0)
+    H.check(H.lib.evk_gemm_strip(H.ptr(a), K, H.ptr(b), K, H.ptr(c2), N, M, N, K, H.ptr(skip), N, H.ptr(gate), N, None, H.ptr(part), nb, C.byref(nblk),
+                                 H.stream()))
+    torch.cuda.synchronize()
+    gref = (ref + skip.float().cpu()) * (gate.float().cpu() > 0)
+    close(c2, gref, rt, 2e-3)
+    s = part.view(nblk.value, 2, N).sum(0).cpu()
+    gz = gref * gate.float().cpu()
+    assert float((s[0] - gref.sum(0)).abs().max()) <= 2e-5 * float(gref.abs().sum(0).max()) + 1e-3
+    assert float((s[1] - gz.sum(0)).abs().max()) <= 2e-5 * float(gz.abs().sum(0).max()) + 1e-3
+
+
+def test_strip_gemm_is_what_the_contracting_pointwise_convolutions_take(H):
+    """Routing: Bottleneck.conv1 forward and conv3's data gradient over transposed weights at layer3's size go to the strip kernel and
+    agree with the tile path (EVK_A_PLAIN / EVK_B_KSTR loaders) to one output ulp."""
+    N, Hh, Ci, Co = 64, 24, 1024, 256
+    g = H.conv_geom(N, Hh, Hh, Ci, Co, 1, 1, 1, 0)
+    M = N * Hh * Hh
+    assert H.lib.evk_gemm_strip_routes(M, Co, Ci, 0, 0) == 1
+    x, w = rnd(M, Ci, seed=45, scale=0.7).cuda(), rnd(Co, Ci, seed=46, scale=Ci ** -0.5).cuda()
+    y = torch.empty(M, Co, dtype=STORE_DTYPE, device='cuda')
+    H.check(H.lib.evk_conv2d_fwd(H.ptr(x), H.ptr(w), H.ptr(y), C.byref(g), H.stream()))
+    d = base_desc(H, x, w, torch.empty_like(y), M, Co, Ci, lda=Ci, ldb=Ci, ldc=Co)
+    y2 = torch.empty_like(y)
+    d.C = y2.data_ptr()
+    H.gemm_launch(d)
+    torch.cuda.synchronize()
+    rt = 2.0 ** -8 if STORE_DTYPE == torch.bfloat16 else 2.0 ** -10
+    close(y, y2.float().cpu(), 2 * rt, 2e-3)
+    # data gradient of a Co = 4 Ci pointwise convolution over weights transposed by evk_conv_flip_weights
+    g3 = H.conv_geom(N, Hh, Hh, Co, Ci, 1, 1, 1, 0)          # conv3: 256 -> 1024
+    w3 = rnd(Ci, 1, 1, Co, seed=47, scale=Co ** -0.5).cuda()
+    wt = torch.empty(Co, 1, 1, Ci, dtype=STORE_DTYPE, device='cuda')
+    one = lambda v: (C.c_int32 * 1)(v)
+    H.check(H.lib.evk_conv_flip_weights((C.c_void_p * 1)(w3.data_ptr()), (C.c_void_p * 1)(wt.data_ptr()), one(Ci), one(Co), one(1), one(1), 1, H.stream()))
+    dy = rnd(M, Ci, seed=48).cuda()
+    gate = torch.relu(rnd(M, Co, seed=49).float()).to(STORE_DTYPE).cuda()
+    dx, dx2 = torch.empty(M, Co, dtype=STORE_DTYPE, device='cuda'), torch.empty(M, Co, dtype=STORE_DTYPE, device='cuda')
+    nb = max(H.lib.evk_conv_stats_bytes(M, Co), H.lib.evk_gemm_strip_part_bytes(M, Co))
+    p1, p2 = torch.zeros(nb // 4, device='cuda'), torch.zeros(nb // 4, device='cuda')
+    n1, n2 = C.c_int32(0), C.c_int32(0)
+    H.check(H.lib.evk_conv2d_dgrad_flipped_gated_stats(H.ptr(dy), H.ptr(wt), None, H.ptr(gate), H.ptr(dx), C.byref(g3), H.ptr(p1), nb, C.byref(n1), H.stream()))
+    H.check(H.lib.evk_conv2d_dgrad_gated_stats(H.ptr(dy), H.ptr(w3), None, H.ptr(gate), H.ptr(dx2), C.byref(g3), H.ptr(p2), nb, C.byref(n2), H.stream()))
+    torch.cuda.synchronize()
+    close(dx, dx2.float().cpu(), 2 * rt, 2e-3)
+    s1 = p1[:n1.value * 2 * Co].view(n1.value, 2, Co).sum(0)
+    s2 = p2[:n2.value * 2 * Co].view(n2.value, 2, Co).sum(0)
+    assert float((s1 - s2).abs().max()) <= 2e-5 * float(s2.abs().max()) + 1e-3
+
+
 HALO_SHAPES = [(2, 24, 24, 256, 256), (5, 7, 7, 64, 128), (3, 14, 14, 128, 256), (2, 48, 48, 128, 128), (3, 12, 12, 512, 512),
                (3, 10, 23, 64, 128), (1, 16, 20, 64, 384), (7, 5, 40, 128, 128)]
 

@@ -80,6 +80,9 @@ CASES = [
     ('conv1x1 l3 fwd 256->1024', lambda: conv_case(64, 24, 256, 1024, 1, 1, 'fwd'), 2 * 36864 * 256 * 1024),
     ('conv1x1 l3 fwd 1024->256', lambda: conv_case(64, 24, 1024, 256, 1, 1, 'fwd'), 2 * 36864 * 256 * 1024),
     ('conv1x1 l3 dgrad 1024->256', lambda: conv_case(64, 24, 1024, 256, 1, 1, 'dgrad'), 2 * 36864 * 256 * 1024),
+    ('conv1x1 l3 fwd+stats 1024->256', lambda: conv_case(64, 24, 1024, 256, 1, 1, 'fwd_stats'), 2 * 36864 * 256 * 1024),
+    ('conv1x1 l3 dgrad flipped+gate+stats 256->1024', lambda: conv_case(64, 24, 256, 1024, 1, 1, 'dgrad_flip'), 2 * 36864 * 256 * 1024),
+    ('conv1x1 l2 fwd+stats 512->128', lambda: conv_case(64, 48, 512, 128, 1, 1, 'fwd_stats'), 2 * 147456 * 128 * 512),
     ('conv1x1 l3 wgrad 1024->256', lambda: conv_case(64, 24, 1024, 256, 1, 1, 'wgrad'), 2 * 36864 * 256 * 1024),
     ('conv3x3 l2 fwd 64x48x48 128->128', lambda: conv_case(64, 48, 128, 128, 3, 1, 'fwd'), 2 * 147456 * 128 * 1152),
     ('conv1x1 l1 fwd 64x96x96 64->256', lambda: conv_case(64, 96, 64, 256, 1, 1, 'fwd'), 2 * 589824 * 64 * 256),
