@@ -496,7 +496,7 @@ def main():
                     and tj.get('store') == H.STORE):
                 traffic, tsrc = tj.get('gemm_family_hbm_bytes_per_step'), 'profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per step)' % tname
                 break
-        out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_kernel (MFMA GEMM / implicit-GEMM conv family)', 'achieved': ach,
+        out['roofline'] = {'bound': 'mfma', 'kernel': 'MFMA GEMM / convolution family (gemm_kernel tiles, halo-tile 3x3 kernels, strip GEMM, weight-stationary 1x1, attention, relational memory)', 'achieved': ach,
                            'peak': MFMA_BF16_DENSE_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / MFMA_BF16_DENSE_PEAK_TFLOPS,
                            'traffic': traffic, 'traffic_source': tsrc,
                            'launches_per_step': n / psteps, 'event_timed': '1 extra step after the timed region, single stream', 'avg_launch_us': 1e3 * ms / max(n, 1),

@@ -1,6 +1,6 @@
 set -x
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r3e
+O=$R/gpurun_out/${1:-r3e}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o st -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-decode > $O/stats.log 2>&1
