@@ -87,6 +87,21 @@ __global__ __launch_bounds__(256) void conv_flip_weights_kernel(const FlipTab t)
   }
 }
 
+// dst[n][2 y][2 x][:] = src[n][y][x][:], every other pixel of dst zero: the data gradient of a pointwise stride-2 convolution from
+// the compact product (one 16-byte piece per thread; C % 8 == 0)
+__global__ __launch_bounds__(256) void upsample2_zero_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int Ho, int Wo, int C8, long total) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C8);
+    long t = i / C8;
+    const int x = (int)(t % (2 * Wo)); t /= 2 * Wo;
+    const int y = (int)(t % (2 * Ho));
+    const long n = t / (2 * Ho);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (!((x | y) & 1)) v = src[((n * Ho + (y >> 1)) * Wo + (x >> 1)) * C8 + c];
+    dst[i] = v;
+  }
+}
+
 void stem_geom(evk_conv_geom* g, int N, int H, int W) {
   const int Hp = H + 6, Wp = W + 8;
   g->N = N; g->Hi = Hp; g->Wi = W / 2; g->Ci = 32;
@@ -204,6 +219,18 @@ int evk_conv2d_dgrad_gated_stats(const void* dy, const void* w, const void* resi
   }
   d.g = *g;
   return evk_gemm_launch(&d, stream);
+}
+
+int evk_upsample2_zero(const void* src, void* dst, int32_t N, int32_t Ho, int32_t Wo, int32_t C, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(src && dst && N > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 8 == 0, "upsample2_zero: bad args (C %% 8)");
+  EVK_REQUIRE((reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0, "upsample2_zero: 16-byte alignment");
+  const long total = (long)N * 2 * Ho * 2 * Wo * (C / 8);
+  const long blocks = cdiv(total, 256 * 4);
+  ProfScope ps(EVK_FAM_ELTWISE, s);
+  hipLaunchKernelGGL(upsample2_zero_kernel, dim3((unsigned)(blocks < 1 ? 1 : (blocks > 65535 * 4 ? 65535 * 4 : blocks))), dim3(256), 0, s,
+                     reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst), Ho, Wo, C / 8, total);
+  return evk_check_launch("upsample2_zero");
 }
 
 int evk_conv_flip_weights(const void* const* w, void* const* wt, const int32_t* Co, const int32_t* Ci, const int32_t* KH, const int32_t* KW,

@@ -29,17 +29,24 @@ namespace {
 unsigned long long* g_stamps = nullptr;      // evk_conv3x3_halo_debug_stamps
 
 constexpr int NTH = 512;
-constexpr int WM = 4, WN = 2, MI = 5, NI = 4;
+constexpr int WM = 4, WN = 2, MI = 5;
 constexpr int TP = 16 * MI * WM;             // 320 output pixels per workgroup
-constexpr int TN = 16 * NI * WN;             // 128 output channels per workgroup
-constexpr int HALO_MAX = 432;                // halo pixels per chunk buffer
-constexpr int NPIECE = (HALO_MAX * 8 + NTH - 1) / NTH;   // 16-byte pieces per thread and chunk (7; the last one partly beyond the buffer: masked)
-constexpr int A_BYTES = HALO_MAX * 128;
-constexpr int B_BYTES = TN * 128;
 constexpr int NBST = 3;                      // weight-tile stages
-constexpr int LDS_BYTES = 2 * A_BYTES + NBST * B_BYTES;   // 159744 of 163840
-static_assert(NPIECE <= 8, "the halo pieces of the next chunk are loaded one per K-step, before the chunk's last step");
-static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+// Two configurations: 128 output channels per workgroup (4 MFMA tiles per wave, halo buffers of 432 pixels) and 64 (2 tiles per wave:
+// the 64-channel convolutions of layer1, whose 96-pixel rows need the 512-pixel halo the smaller weight stages leave room for).
+template <int NI_, int HALO_> struct Cfg {
+  static constexpr int NI = NI_, HALO_MAX = HALO_;
+  static constexpr int TN = 16 * NI * WN;                       // output channels per workgroup
+  static constexpr int NPIECE = (HALO_MAX * 8 + NTH - 1) / NTH; // 16-byte halo pieces per thread and chunk (the last one partly beyond the buffer: masked)
+  static constexpr int A_BYTES = HALO_MAX * 128;
+  static constexpr int B_BYTES = TN * 128;
+  static constexpr int LDS_BYTES = 2 * A_BYTES + NBST * B_BYTES;
+  static_assert(NPIECE <= 8, "the halo pieces of the next chunk are loaded one per K-step, before the chunk's last step");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+  static_assert(NI == 4 || NI == 2, "one or two 64-row weight pieces per thread");
+};
+using Cfg128 = Cfg<4, 432>;                  // 159744 B of LDS
+using Cfg64 = Cfg<2, 512>;                   // 155648 B
 
 struct C3P {
   const bf16_t* x; const bf16_t* w; bf16_t* y;
@@ -75,7 +82,9 @@ __device__ __forceinline__ float row16_sum(float v) {
   return dpp_add<0x140>(v);
 }
 
+template <class CF>
 __global__ __launch_bounds__(NTH, 2) void conv3x3_halo_kernel(const C3P p) {
+  constexpr int NI = CF::NI, TN = CF::TN, HALO_MAX = CF::HALO_MAX, NPIECE = CF::NPIECE, A_BYTES = CF::A_BYTES, B_BYTES = CF::B_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const Abuf = smem;
   char* const Bst = smem + 2 * A_BYTES;
@@ -97,9 +106,24 @@ __global__ __launch_bounds__(NTH, 2) void conv3x3_halo_kernel(const C3P p) {
   const int g0 = tm * p.R;
   const int reff = min(p.R, TR - g0);
   const int npx = reff * W;
-  const int P0 = (g0 / H) * H1 + (g0 % H);                    // padded row of tall row g0, minus one
+  const int n_first = fdiv(g0, H, p.inv_h);
+  const int P0 = n_first * H1 + (g0 - n_first * H);           // padded row of tall row g0, minus one
   const int glast = g0 + reff - 1;
-  const int hpx = ((glast / H) * H1 + (glast % H) + 3 - P0) * W2;   // halo pixels of this tile (<= HALO_MAX by the host's choice of R)
+  const int n_last = fdiv(glast, H, p.inv_h);
+  const int hpx = (n_last * H1 + (glast - n_last * H) + 3 - P0) * W2;   // halo pixels of this tile (<= HALO_MAX by the host's choice of R)
+
+  // the weight tiles of steps 0, 1 and 2 are requested before the index arithmetic below (their addresses need none of it)
+  const int co0 = tn * TN;
+  const char* const wsrc = reinterpret_cast<const char*>(p.w) + ((long)(co0 + (tid >> 3)) * 9 * C + (tid & 7) * 8) * 2;
+  const long wrow64 = (long)64 * 9 * C * 2;
+  uint4 rb0, rb1, ra;
+  uint4 pb0[2], pb1[2];
+  pb0[0] = *reinterpret_cast<const uint4*>(wsrc);
+  if constexpr (NI == 4) pb0[1] = *reinterpret_cast<const uint4*>(wsrc + wrow64);
+  pb1[0] = *reinterpret_cast<const uint4*>(wsrc + (long)C * 2 * p.kmul);
+  if constexpr (NI == 4) pb1[1] = *reinterpret_cast<const uint4*>(wsrc + (long)C * 2 * p.kmul + wrow64);
+  rb0 = *reinterpret_cast<const uint4*>(wsrc + (long)C * 4 * p.kmul);
+  if constexpr (NI == 4) rb1 = *reinterpret_cast<const uint4*>(wsrc + (long)C * 4 * p.kmul + wrow64);
 
   // halo pieces of this thread: piece i covers halo pixel (tid >> 3) + 64 i, 16-byte chunk tid & 7 of the 64-channel row
   unsigned aoff[NPIECE];
@@ -129,9 +153,6 @@ __global__ __launch_bounds__(NTH, 2) void conv3x3_halo_kernel(const C3P p) {
     hb[im] = (n * H1 + y + 1 - P0) * W2 + xx + 1;
   }
 
-  const int co0 = tn * TN;
-  const char* const wsrc = reinterpret_cast<const char*>(p.w) + ((long)(co0 + (tid >> 3)) * 9 * C + (tid & 7) * 8) * 2;
-  const long wrow64 = (long)64 * 9 * C * 2;
   const int bdst = adst;                                                         // same (row, chunk) -> byte mapping; + 8192 for rows 64..127
   const char* const xsrc = reinterpret_cast<const char*>(p.x);
 
@@ -144,22 +165,21 @@ __global__ __launch_bounds__(NTH, 2) void conv3x3_halo_kernel(const C3P p) {
   int baddr[NI];
 #pragma unroll
   for (int in = 0; in < NI; ++in) {
-    const int row = wn * 64 + in * 16 + frow;
+    const int row = wn * (16 * NI) + in * 16 + frow;
     baddr[in] = row * 128 + ((fq ^ (row & 7)) << 4);
   }
   const int nchunk = C >> 6;
   const int nsteps = nchunk * 9;
-  uint4 rb0, rb1, ra;
 
   auto loadB = [&](int c, int t) {
     const char* s = wsrc + (long)(t * C + c * 64) * 2 * p.kmul;
     rb0 = *reinterpret_cast<const uint4*>(s);
-    rb1 = *reinterpret_cast<const uint4*>(s + wrow64);
+    if constexpr (NI == 4) rb1 = *reinterpret_cast<const uint4*>(s + wrow64);
   };
   auto storeB = [&](int stage) {
     char* d = Bst + stage * B_BYTES + bdst;
     *reinterpret_cast<uint4*>(d) = rb0;
-    *reinterpret_cast<uint4*>(d + 8192) = rb1;
+    if constexpr (NI == 4) *reinterpret_cast<uint4*>(d + 8192) = rb1;
   };
   auto storeA = [&](char* buf, int i, const uint4& v) {      // only the last piece can lie beyond the buffer
     if ((i + 1) * 64 <= HALO_MAX || ((inbuf >> i) & 1u))
@@ -178,23 +198,18 @@ __global__ __launch_bounds__(NTH, 2) void conv3x3_halo_kernel(const C3P p) {
     }
   };
 
-  // prologue: the whole halo of chunk 0 and the weight tiles of steps 0 and 1 into LDS, the weight tile of step 2 into registers --
-  // every load issued before the first wait (one memory round trip instead of three)
+  // prologue: the whole halo of chunk 0 and the weight tiles of steps 0 and 1 into LDS (the weight tile of step 2 stays in registers);
+  // every load was issued before the first wait
   {
-    uint4 v[NPIECE], b0[2], b1[2];
+    uint4 v[NPIECE];
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i) v[i] = *reinterpret_cast<const uint4*>(xsrc + aoff[i]);
-    b0[0] = *reinterpret_cast<const uint4*>(wsrc);
-    b0[1] = *reinterpret_cast<const uint4*>(wsrc + wrow64);
-    b1[0] = *reinterpret_cast<const uint4*>(wsrc + (long)C * 2 * p.kmul);
-    b1[1] = *reinterpret_cast<const uint4*>(wsrc + (long)C * 2 * p.kmul + wrow64);
-    loadB(0, 2);            // nsteps >= 9
+    *reinterpret_cast<uint4*>(Bst + bdst) = pb0[0];
+    if constexpr (NI == 4) *reinterpret_cast<uint4*>(Bst + bdst + 8192) = pb0[1];
+    *reinterpret_cast<uint4*>(Bst + B_BYTES + bdst) = pb1[0];
+    if constexpr (NI == 4) *reinterpret_cast<uint4*>(Bst + B_BYTES + bdst + 8192) = pb1[1];
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i) storeA(Abuf, i, v[i]);
-    *reinterpret_cast<uint4*>(Bst + bdst) = b0[0];
-    *reinterpret_cast<uint4*>(Bst + bdst + 8192) = b0[1];
-    *reinterpret_cast<uint4*>(Bst + B_BYTES + bdst) = b1[0];
-    *reinterpret_cast<uint4*>(Bst + B_BYTES + bdst + 8192) = b1[1];
   }
   __syncthreads();
 
@@ -282,12 +297,27 @@ __global__ __launch_bounds__(NTH, 2) void conv3x3_halo_kernel(const C3P p) {
         sm[j] = row16_sum(a);
         sq[j] = row16_sum(b);
       }
-      const int n0 = co0 + wn * 64 + in * 16 + fq * 4;
+      const int n0 = co0 + wn * (16 * NI) + in * 16 + fq * 4;
       if (frow == 0) {
         *reinterpret_cast<float4*>(prow + n0) = make_float4(sm[0], sm[1], sm[2], sm[3]);
         *reinterpret_cast<float4*>(prow + Co + n0) = make_float4(sq[0], sq[1], sq[2], sq[3]);
       }
     }
+  }
+  if (!p.gate && !p.resid) {
+    // forward convolution: nothing but the rounded result leaves -- one row pointer per MFMA tile row, no per-tile branches
+    char* const cb = reinterpret_cast<char*>(p.y) + ((m0 + wm * (16 * MI) + frow) * Co + co0 + wn * (16 * NI) + fq * 4) * 2;
+    const long rstep = 16L * Co * 2;
+#pragma unroll
+    for (int im = 0; im < MI; ++im) {
+      if (!rowok[im]) continue;
+#pragma unroll
+      for (int in = 0; in < NI; ++in)
+        *reinterpret_cast<uint2*>(cb + im * rstep + in * 32) =
+            make_uint2(pack2bf(acc[in][im][0], acc[in][im][1]), pack2bf(acc[in][im][2], acc[in][im][3]));
+    }
+    if (p.stamps && tid == 0) { p.stamps[blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memtime(); p.stamps[blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime(); }
+    return;
   }
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   f32x2 gs[NI][2], gz[NI][2];
@@ -301,7 +331,7 @@ __global__ __launch_bounds__(NTH, 2) void conv3x3_halo_kernel(const C3P p) {
     const long m = m0 + wm * (16 * MI) + im * 16 + frow;
 #pragma unroll
     for (int in = 0; in < NI; ++in) {
-      const int n0 = co0 + wn * 64 + in * 16 + fq * 4;
+      const int n0 = co0 + wn * (16 * NI) + in * 16 + fq * 4;
       float v[4] = {acc[in][im][0], acc[in][im][1], acc[in][im][2], acc[in][im][3]};
       if (p.resid) {
         const uint2 t = *reinterpret_cast<const uint2*>(p.resid + m * p.ldr + n0);
@@ -332,7 +362,7 @@ __global__ __launch_bounds__(NTH, 2) void conv3x3_halo_kernel(const C3P p) {
       float a[4], b[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) { a[j] = row16_sum(gs[in][j >> 1][j & 1]); b[j] = row16_sum(gz[in][j >> 1][j & 1]); }
-      const int n0 = co0 + wn * 64 + in * 16 + fq * 4;
+      const int n0 = co0 + wn * (16 * NI) + in * 16 + fq * 4;
       if (frow == 0) {
         *reinterpret_cast<float4*>(prow + n0) = make_float4(a[0], a[1], a[2], a[3]);
         *reinterpret_cast<float4*>(prow + Co + n0) = make_float4(b[0], b[1], b[2], b[3]);
@@ -356,11 +386,14 @@ int halo_rows_max(int TR, int H, int R) {
 }
 
 // rows per tile: the most whole rows whose pixels fit the tile and whose halo fits the buffer; 0 = not tileable
-int choose_rows(int N, int H, int W) {
+int choose_rows(int N, int H, int W, int halo_max) {
   for (int R = TP / W; R >= 1; --R)
-    if (halo_rows_max(N * H, H, R) * (W + 2) <= HALO_MAX) return R;
+    if (halo_rows_max(N * H, H, R) * (W + 2) <= halo_max) return R;
   return 0;
 }
+// 128-channel tiles wherever the output has them; the 64-channel configuration for Co % 128 == 64
+inline bool wide_tiles(int Co) { return Co % Cfg128::TN == 0; }
+inline int halo_max_for(int Co) { return wide_tiles(Co) ? Cfg128::HALO_MAX : Cfg64::HALO_MAX; }
 
 
 
@@ -385,7 +418,7 @@ __device__ uint4 g_zero16;        // zero-initialised
 constexpr int PITCH = 160;
 constexpr int STAGE_ROWS = 464;                       // dy rows (tile pixels padded to 32) + halo rows of one tile
 constexpr int STAGE_BYTES = STAGE_ROWS * PITCH;       // 74240
-constexpr int LDS_BYTES = 2 * STAGE_BYTES;            // 148480
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;            // 148480 (wgk::)
 constexpr int NPC = (STAGE_ROWS * 8 + NTH - 1) / NTH; // 16-byte pieces per thread and tile (8)
 
 struct W3P {
@@ -619,6 +652,17 @@ bool halo_enabled() {
   return on != 0;
 }
 
+template <class CF>
+int launch_halo(const C3P& p, hipStream_t s) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<CF>), hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS_BYTES);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(conv3x3_halo_kernel<CF>, dim3(p.tilesM * p.tilesN), dim3(NTH), CF::LDS_BYTES, s, p);
+  return evk_check_launch("conv3x3_halo_kernel");
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -626,15 +670,18 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 extern "C" {
 
 int evk_conv3x3_halo_supported(int32_t N, int32_t H, int32_t W, int32_t C, int32_t Co) {
-  if (N <= 0 || H <= 0 || W <= 0 || C < 64 || (C % 64) || Co < TN || (Co % TN)) return 0;
+  if (N <= 0 || H <= 0 || W <= 0 || C < 64 || (C % 64) || Co < Cfg64::TN || (Co % Cfg64::TN)) return 0;
+  // the 64-channel configuration stores its eighth halo piece in a chunk's last step, the step that already reads the next chunk's
+  // fragments: it is built for single-chunk inputs (C == 64, layer1), where no piece is ever loaded inside the loop
+  if (!wide_tiles(Co) && C != 64) return 0;
   if ((long)N * H * W * C * 2 >= (1L << 32)) return 0;          // 32-bit byte offsets into x
-  const int R = choose_rows(N, H, W);
+  const int R = choose_rows(N, H, W, halo_max_for(Co));
   if (R < 1 || R * W < TP / 2) return 0;                         // tiles under half full: the tile GEMM path is the better kernel
   return 1;
 }
 
 int64_t evk_conv3x3_halo_part_bytes(int32_t N, int32_t H, int32_t W, int32_t Co) {
-  const int R = choose_rows(N, H, W);
+  const int R = choose_rows(N, H, W, halo_max_for(Co));
   if (R < 1) return 0;
   return cdiv((int64_t)N * H, R) * WM * 2 * Co * (int64_t)sizeof(float);
 }
@@ -644,16 +691,17 @@ int evk_conv3x3_halo(const void* x, const void* w, void* y, int32_t N, int32_t H
                      int64_t part_bytes, int32_t* nblk, evk_stream_t stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   EVK_REQUIRE(x && w && y, "conv3x3_halo: null operand");
-  EVK_REQUIRE(evk_conv3x3_halo_supported(N, H, W, C, Co), "conv3x3_halo: unsupported shape N=%d H=%d W=%d C=%d Co=%d (C %% 64, Co %% 128, tileable rows)", N, H, W, C, Co);
+  EVK_REQUIRE(evk_conv3x3_halo_supported(N, H, W, C, Co), "conv3x3_halo: unsupported shape N=%d H=%d W=%d C=%d Co=%d (C %% 64, Co %% 64, tileable rows)", N, H, W, C, Co);
   EVK_REQUIRE(al16(x) && al16(w) && al16(y) && (!resid || (al16(resid) && ldr % 4 == 0 && ldr >= Co)) && (!gate || (al16(gate) && ldg % 4 == 0 && ldg >= Co)),
               "conv3x3_halo: operands must be 16-byte aligned, leading dimensions multiples of 4 and >= Co");
   EVK_REQUIRE(!(colstats && gatestats) && (!gatestats || gate), "conv3x3_halo: one statistics epilogue at a time; gate statistics need a gate");
+  const bool wide = wide_tiles(Co);
   C3P p{};
   p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.y = (bf16_t*)y;
   p.N = N; p.H = H; p.W = W; p.C = C; p.Co = Co;
-  p.R = choose_rows(N, H, W);
+  p.R = choose_rows(N, H, W, halo_max_for(Co));
   p.tilesM = (int)cdiv((int64_t)N * H, p.R);
-  p.tilesN = Co / TN;
+  p.tilesN = Co / (wide ? Cfg128::TN : Cfg64::TN);
   p.resid = (const bf16_t*)resid; p.ldr = ldr; p.gate = (const bf16_t*)gate; p.ldg = ldg;
   p.colstats = colstats; p.gatestats = gatestats;
   static const int probe = [] { const char* e = getenv("EVK_C3_PROBE"); return e ? atoi(e) : 0; }();
@@ -664,15 +712,9 @@ int evk_conv3x3_halo(const void* x, const void* w, void* y, int32_t N, int32_t H
     EVK_REQUIRE(nblk && part_bytes >= evk_conv3x3_halo_part_bytes(N, H, W, Co), "conv3x3_halo: statistics buffer too small");
     *nblk = p.tilesM * WM;
   }
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    attr_done = true;
-  }
   evk_prof_tag(N * H * W, Co, 9 * C, 1, EVK_A_CONV, EVK_B_PLAIN);
   ProfScope ps(EVK_FAM_GEMM, s, 2.0 * N * H * W * (double)Co * 9 * C);
-  hipLaunchKernelGGL(conv3x3_halo_kernel, dim3(p.tilesM * p.tilesN), dim3(NTH), LDS_BYTES, s, p);
-  return evk_check_launch("conv3x3_halo_kernel");
+  return wide ? launch_halo<Cfg128>(p, s) : launch_halo<Cfg64>(p, s);
 }
 
 int evk_conv3x3_wgrad_halo_supported(int32_t N, int32_t H, int32_t W, int32_t Ci, int32_t Co) {

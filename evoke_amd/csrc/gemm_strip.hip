@@ -202,6 +202,20 @@ __global__ __launch_bounds__(NTH, 2) void gemm_strip_kernel(const StP p) {
       }
     }
   }
+  if (!p.gate && !p.resid) {
+    // forward convolution: nothing but the rounded product leaves -- one row pointer per MFMA tile row, no per-tile branches
+    char* const cb = reinterpret_cast<char*>(p.C) + (((long)row0 + wm * (16 * MI) + frow) * p.ldc + col0 + wn * (16 * NI) + fq * 4) * 2;
+    const long rstep = 16L * p.ldc * 2;
+#pragma unroll
+    for (int im = 0; im < MI; ++im) {
+      if (!rowok[im]) continue;
+#pragma unroll
+      for (int in = 0; in < NI; ++in)
+        *reinterpret_cast<uint2*>(cb + im * rstep + in * 32) =
+            make_uint2(pack2bf(acc[in][im][0], acc[in][im][1]), pack2bf(acc[in][im][2], acc[in][im][3]));
+    }
+    return;
+  }
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   f32x2 gs[NI][2], gz[NI][2];
 #pragma unroll

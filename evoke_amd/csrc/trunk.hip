@@ -351,7 +351,22 @@ int evk_trunk_backward(const evk_trunk_cfg* cfg, const evk_trunk_layer* layers, 
     const void* skip = gZ;
     if (down) {
       TRY(bn_backward(c, i + 3, gZ, nullptr, 0));
-      TRY(evk_conv2d_dgrad(c.at(P.pairs[i + 3].dy), layers[i + 3].w, T, &P.pairs[i + 3].g, stream));
+      {
+        // down-sampling shortcut: a pointwise stride-2 convolution gives gradient to the even pixels only -- the product on the compact
+        // rows (a quarter of them), then one pass that spreads them and writes the zeros (EVK_DOWN_COMPACT=0: the gathering GEMM)
+        static const bool compact = [] { const char* e = getenv("EVK_DOWN_COMPACT"); return !e || atoi(e) != 0; }();
+        const evk_conv_geom& gd = P.pairs[i + 3].g;
+        if (compact && gd.KH == 1 && gd.KW == 1 && gd.stride_h == 2 && gd.stride_w == 2 && gd.pad_h == 0 && gd.pad_w == 0 &&
+            gd.Hi == 2 * gd.Ho && gd.Wi == 2 * gd.Wo && gd.Ci % 8 == 0) {
+          evk_conv_geom gc = gd;
+          gc.Hi = gd.Ho; gc.Wi = gd.Wo; gc.stride_h = gc.stride_w = 1;
+          void* Tc = c.at(P.gbuf[2]);                 // free until the max-pool backward at the very end
+          TRY(evk_conv2d_dgrad(c.at(P.pairs[i + 3].dy), layers[i + 3].w, Tc, &gc, stream));
+          TRY(evk_upsample2_zero(Tc, T, gd.N, gd.Ho, gd.Wo, gd.Ci, stream));
+        } else {
+          TRY(evk_conv2d_dgrad(c.at(P.pairs[i + 3].dy), layers[i + 3].w, T, &P.pairs[i + 3].g, stream));
+        }
+      }
       TRY(wgrad(i + 3, X));
       skip = T;
     }

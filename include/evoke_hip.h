@@ -146,6 +146,10 @@ int evk_conv2d_dgrad_add(const void* dy, const void* w, const void* resid, void*
  * instead of the gather + K-strided one (layer3: 87 instead of 123 us alone, 167 with the gate epilogue).  evk_conv_flip_weights
  * produces wt for a whole table of layers in one launch (w / wt: arrays of n_layers device pointers in HOST memory);
  * evk_conv2d_dgrad_flipped_gated_stats = evk_conv2d_dgrad_gated_stats with wt in place of w (g = the geometry of the forward conv). */
+/* dst[N][2 Ho][2 Wo][C] = src[N][Ho][Wo][C] at the even pixels, zero elsewhere (16-bit, C % 8 == 0): the data gradient of a pointwise
+ * stride-2 convolution (torchvision Bottleneck.downsample[0] of layers 2-4) from the COMPACT product dy . w -- three quarters of the
+ * input pixels receive no gradient, so the product runs on a quarter of the rows and this pass writes the zeros */
+int evk_upsample2_zero(const void* src, void* dst, int32_t N, int32_t Ho, int32_t Wo, int32_t C, evk_stream_t stream);
 int evk_conv_flip_weights(const void* const* w, void* const* wt, const int32_t* Co, const int32_t* Ci, const int32_t* KH, const int32_t* KW,
                           int32_t n_layers, evk_stream_t stream);
 int evk_conv2d_dgrad_flipped_gated_stats(const void* dy, const void* wt, const void* resid, const void* gate, void* dx, const evk_conv_geom* g,

@@ -361,7 +361,7 @@ def test_strip_gemm_is_what_the_contracting_pointwise_convolutions_take(H):
 
 
 HALO_SHAPES = [(2, 24, 24, 256, 256), (5, 7, 7, 64, 128), (3, 14, 14, 128, 256), (2, 48, 48, 128, 128), (3, 12, 12, 512, 512),
-               (3, 10, 23, 64, 128), (1, 16, 20, 64, 384), (7, 5, 40, 128, 128)]
+               (3, 10, 23, 64, 128), (1, 16, 20, 64, 384), (7, 5, 40, 128, 128), (2, 96, 96, 64, 64), (3, 20, 20, 64, 192), (5, 9, 31, 64, 64)]
 
 
 @pytest.mark.parametrize('N,Hh,W,Ci,Co', HALO_SHAPES)
@@ -409,7 +409,7 @@ def test_halo_conv3x3_forward_and_flipped_data_gradient(H, N, Hh, W, Ci, Co):
     H.check(H.lib.evk_conv_flip_weights(ptrs_w, ptrs_wt, one(Co), one(Ci), one(3), one(3), 1, H.stream()))
     torch.cuda.synchronize()
     assert torch.equal(wf.cpu(), w.cpu().flip(1, 2).permute(3, 1, 2, 0).contiguous())
-    if Ci % 128 == 0:
+    if H.lib.evk_conv3x3_halo_supported(N, Hh, W, Co, Ci) == 1:
         # dgrad of the forward conv (Ci -> Co): input dy has Co channels, output dx has Ci channels, weights wf [Ci][3][3][Co]
         dy = rnd(N, Hh, W, Co, seed=23).cuda()
         skip = rnd(N, Hh, W, Ci, seed=24, scale=0.3).cuda()
@@ -468,7 +468,8 @@ def test_halo_conv3x3_refuses_what_it_cannot_tile(H):
     assert H.lib.evk_conv3x3_halo_supported(1, 8, 200, 64, 128) == 0       # the halo of even one 200-pixel row exceeds the LDS buffer
     assert H.lib.evk_conv3x3_halo_supported(4, 4, 5, 64, 128) == 1         # tiny images: many per tile
     assert H.lib.evk_conv3x3_halo_supported(2, 24, 24, 96, 128) == 0       # C % 64
-    assert H.lib.evk_conv3x3_halo_supported(2, 24, 24, 64, 64) == 0        # Co % 128
+    assert H.lib.evk_conv3x3_halo_supported(2, 24, 24, 64, 32) == 0        # Co % 64
+    assert H.lib.evk_conv3x3_halo_supported(2, 24, 24, 128, 64) == 0       # 64-channel tiles: single-chunk inputs only
     assert H.lib.evk_conv3x3_wgrad_halo_supported(7, 5, 40, 128, 64) == 0  # no divisor of H = 5 gives a tile of >= 48 pixels that fits
     assert H.lib.evk_conv3x3_wgrad_halo_supported(2, 24, 24, 96, 64) == 0  # Ci % 64
     x = torch.zeros(2, 24, 24, 96, dtype=STORE_DTYPE, device='cuda')

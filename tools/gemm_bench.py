@@ -73,6 +73,8 @@ CASES = [
     ('conv3x3 l2 fwd+stats 64x48x48 128->128', lambda: conv_case(64, 48, 128, 128, 3, 1, 'fwd_stats'), 2 * 147456 * 128 * 1152),
     ('conv3x3 l4 fwd+stats 64x12x12 512->512', lambda: conv_case(64, 12, 512, 512, 3, 1, 'fwd_stats'), 2 * 9216 * 512 * 4608),
     ('conv3x3 l3 fwd+stats 128 images (decode encoder)', lambda: conv_case(128, 24, 256, 256, 3, 1, 'fwd_stats'), 2 * 73728 * 256 * 2304),
+    ('conv3x3 l1 fwd+stats 64x96x96 64->64', lambda: conv_case(64, 96, 64, 64, 3, 1, 'fwd_stats'), 2 * 589824 * 64 * 576),
+    ('conv3x3 l1 dgrad flipped+gate+stats 64->64', lambda: conv_case(64, 96, 64, 64, 3, 1, 'dgrad_flip'), 2 * 589824 * 64 * 576),
     ('conv3x3 l3 dgrad', lambda: conv_case(64, 24, 256, 256, 3, 1, 'dgrad'), 2 * 36864 * 256 * 2304),
     ('conv3x3 l3 wgrad', lambda: conv_case(64, 24, 256, 256, 3, 1, 'wgrad'), 2 * 36864 * 256 * 2304),
     ('conv3x3 l1 wgrad 64->64', lambda: conv_case(64, 96, 64, 64, 3, 1, 'wgrad'), 2 * 589824 * 64 * 576),
