@@ -363,6 +363,8 @@ int evk_stem_fwd(const void* xpad, const void* wp, void* y, int32_t N, int32_t H
 int evk_stem_fwd_stats(const void* xpad, const void* wp, void* y, int32_t N, int32_t H, int32_t W, float* part, int64_t part_bytes,
                        int32_t* nblk, evk_stream_t stream) {
   EVK_REQUIRE(H % 2 == 0 && W % 2 == 0, "stem: H and W must be even");
+  if (evk_stem_halo_supported(N, H, W) && (!part || part_bytes >= evk_stem_halo_part_bytes(N, H, W)))      // stem.hip: halo tile in LDS
+    return evk_stem_halo_fwd(xpad, wp, y, N, H, W, part, part_bytes, nblk, stream);
   evk_gemm d{};
   if (part) {
     const int64_t M = (int64_t)N * (H / 2) * (W / 2);
@@ -390,11 +392,15 @@ static void stem_wgrad_desc(evk_gemm& d, const void* dy, const void* xpad, float
 int64_t evk_stem_wgrad_ws_bytes(int32_t N, int32_t H, int32_t W) {
   evk_gemm d{};
   stem_wgrad_desc(d, nullptr, nullptr, nullptr, N, H, W);
-  return evk_gemm_workspace_bytes(&d);
+  int64_t nb = evk_gemm_workspace_bytes(&d);
+  const int64_t nh = evk_stem_halo_wgrad_ws_bytes(N, H, W);          // stem.hip: enough for either route
+  return nh > nb ? nh : nb;
 }
 
 int evk_stem_wgrad(const void* dy, const void* xpad, float* dwp, int32_t N, int32_t H, int32_t W, void* ws, int64_t ws_bytes, evk_stream_t stream) {
   EVK_REQUIRE(H % 2 == 0 && W % 2 == 0, "stem: H and W must be even");
+  if (ws && evk_stem_halo_supported(N, H, W) && ws_bytes >= evk_stem_halo_wgrad_ws_bytes(N, H, W))
+    return evk_stem_halo_wgrad(dy, xpad, dwp, N, H, W, ws, ws_bytes, stream);
   evk_gemm d{};
   stem_wgrad_desc(d, dy, xpad, dwp, N, H, W);
   d.workspace = ws; d.workspace_bytes = ws_bytes;

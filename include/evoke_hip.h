@@ -236,6 +236,16 @@ int evk_stem_unpack_wgrad(const float* dw_packed, float* dw_oihw, evk_stream_t s
 int evk_stem_fwd(const void* xpad, const void* w_packed, void* y, int32_t N, int32_t H, int32_t W, evk_stream_t stream);
 int evk_stem_fwd_stats(const void* xpad, const void* w_packed, void* y, int32_t N, int32_t H, int32_t W, float* part, int64_t part_bytes,
                        int32_t* nblk, evk_stream_t stream);
+/* The stem with the input halo of a 4 x 64 output tile resident in LDS and all weight fragments in registers (stem.hip): same operands
+ * and results as evk_stem_fwd_stats, which routes here when H / 2 is a multiple of 4 and W / 2 of 64 (EVK_STEM_HALO=0 disables); the
+ * statistics buffer holds evk_stem_halo_part_bytes (one partial row per wave of the persistent grid) */
+int evk_stem_halo_supported(int32_t N, int32_t H, int32_t W);
+int64_t evk_stem_halo_part_bytes(int32_t N, int32_t H, int32_t W);
+int evk_stem_halo_fwd(const void* xpad, const void* w_packed, void* y, int32_t N, int32_t H, int32_t W, float* part, int64_t part_bytes,
+                      int32_t* nblk, evk_stream_t stream);
+int64_t evk_stem_halo_wgrad_ws_bytes(int32_t N, int32_t H, int32_t W);
+int evk_stem_halo_wgrad(const void* dy, const void* xpad, float* dw_packed, int32_t N, int32_t H, int32_t W, void* ws, int64_t ws_bytes,
+                        evk_stream_t stream);
 int evk_stem_wgrad(const void* dy, const void* xpad, float* dw_packed, int32_t N, int32_t H, int32_t W, void* ws, int64_t ws_bytes, evk_stream_t stream);
 int64_t evk_stem_wgrad_ws_bytes(int32_t N, int32_t H, int32_t W);
 

@@ -171,7 +171,7 @@ def test_conv_fwd_dgrad_wgrad(H, cfg):
     close(dw, wr.grad.permute(0, 2, 3, 1), 2e-4, 3e-3 * (N * g.Ho * g.Wo) ** 0.5)
 
 
-@pytest.mark.parametrize('N,Hh,W', [(2, 32, 32), (1, 64, 48)])
+@pytest.mark.parametrize('N,Hh,W', [(2, 32, 32), (1, 64, 48), (2, 64, 128), (3, 40, 256)])       # the last two: the halo kernel of stem.hip
 def test_stem(H, N, Hh, W):
     g = torch.Generator().manual_seed(11)
     img = torch.randn(N, 3, Hh, W, generator=g)
@@ -183,6 +183,19 @@ def test_stem(H, N, Hh, W):
     H.check(H.lib.evk_stem_pack_weight(H.ptr(wdev), H.ptr(wp), H.stream()))
     y = torch.zeros(N, Hh // 2, W // 2, 64, dtype=STORE_DTYPE, device='cuda')
     H.check(H.lib.evk_stem_fwd(H.ptr(xpad), H.ptr(wp), H.ptr(y), N, Hh, W, H.stream()))
+    if H.lib.evk_stem_halo_supported(N, Hh, W) == 1:
+        # the same call with the batch-norm partials: sums of the unrounded result
+        nb = max(H.lib.evk_conv_stats_bytes(N * (Hh // 2) * (W // 2), 64), H.lib.evk_stem_halo_part_bytes(N, Hh, W))
+        part = torch.full((nb // 4,), 3.0, device='cuda')
+        nblk = C.c_int32(0)
+        y2 = torch.zeros_like(y)
+        H.check(H.lib.evk_stem_fwd_stats(H.ptr(xpad), H.ptr(wp), H.ptr(y2), N, Hh, W, H.ptr(part), nb, C.byref(nblk), H.stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(y, y2)
+        yf = F.conv2d(img.to(STORE_DTYPE).float(), w.to(STORE_DTYPE).float(), None, 2, 3).permute(0, 2, 3, 1).reshape(-1, 64)
+        sums = part[:nblk.value * 128].view(nblk.value, 2, 64).sum(0).cpu()
+        assert float((sums[0] - yf.sum(0)).abs().max()) <= 1e-5 * float(yf.abs().sum(0).max()) + 1e-3
+        assert float((sums[1] - (yf ** 2).sum(0)).abs().max()) <= 1e-5 * float((yf ** 2).sum(0).max()) + 1e-3
     ir = img.to(STORE_DTYPE).float().requires_grad_(False)
     wr = w.to(STORE_DTYPE).float().requires_grad_(True)
     yr = F.conv2d(ir, wr, None, 2, 3)
