@@ -238,6 +238,13 @@ class GradReducer:
         self.counts[id(p)] = self.counts.get(id(p), 0) + 1
         if self.flat[self.buckets[b][0]].is_cuda:
             self.streams[b].add(torch.cuda.current_stream())
+            # Weight gradients are launched on the 'wgrad' side stream (ops.wgrad_stream, the trunk runner's second stream) while the
+            # callback runs on the stream that issued the backward op: the collective of this bucket must wait for that stream too.
+            # (Without it the all-reduce could start before the last weight-gradient kernel had added its part, which then landed on
+            # top of the reduced values of THIS rank only: parameters drifting apart across ranks, seen once in the two-rank test.)
+            wg = ops.existing_side_stream('wgrad')
+            if wg is not None:
+                self.streams[b].add(wg)
         if not self.learning:
             self.pending[b] -= 1
             if self.overlap and self.pending[b] == 0 and b == self.next:

@@ -292,6 +292,12 @@ def side_stream(name, device=None):
 _main_stream = {}
 
 
+def existing_side_stream(name, device=None):
+    """the named side stream of `device` if it has been created, else None (never creates one)"""
+    dev = torch.cuda.current_device() if device is None else device
+    return _side_streams.get((name, dev))
+
+
 def _capturing(st):
     with torch.cuda.stream(st):
         return torch.cuda.is_current_stream_capturing()
@@ -911,6 +917,9 @@ class _Attention(torch.autograd.Function):
         return dQ, dK, dV, None, None, None, None, None, None
 
 
+FUSED_MAX_DH = [int(os.environ.get('EVK_ATTN_FUSED_MAX_DH', '1000000'))]
+
+
 def attention(q, k, v, heads, mask=None, causal=False, p_drop=0.0, training=False, scale=None):
     """softmax(q k^T * scale [masked]) v per head.  mask: uint8 [B,S] (keys) or [B,T,S], 1 = attend."""
     assert q.dtype == BF16 and q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
@@ -918,7 +927,9 @@ def attention(q, k, v, heads, mask=None, causal=False, p_drop=0.0, training=Fals
     if scale is None:
         scale = 1.0 / math.sqrt(dh)
     p = float(p_drop) if (training and DROPOUT_ENABLED[0]) else 0.0
-    if FUSED_ATTENTION[0] and H.lib.evk_attention_supported(k.shape[1], dh):
+    # heads wider than FUSED_MAX_DH (EVK_ATTN_FUSED_MAX_DH) take the batched-GEMM path: the fused kernel re-streams K and V for every
+    # 32-row query tile, which costs more than the f32 score round trip once a head is thousands of dims wide
+    if FUSED_ATTENTION[0] and dh <= FUSED_MAX_DH[0] and H.lib.evk_attention_supported(k.shape[1], dh):
         return _FusedAttention.apply(q, k, v, mask, heads, float(scale), causal, p, next_seed() if p > 0 else 0)
     return _Attention.apply(q, k, v, mask, heads, float(scale), causal, p, next_seed() if p > 0 else 0)
 

@@ -210,3 +210,29 @@ def test_two_rank_pretrain_matches_the_oracle_on_the_concatenated_batch():
     assert (e_all <= 0.10 and c_all >= 0.98) if F16_BUILD else (e_all <= 0.4 and c_all >= 0.8), (e_all, c_all)
     ops.clear_grad_callbacks()
     ops.set_dropout_enabled(True)
+
+
+def test_reducer_collectives_wait_for_the_weight_gradient_stream():
+    """Weight gradients are launched on the 'wgrad' side stream while their gradient-ready callback runs on the stream that issued
+    the backward op.  The reducer must list that side stream among the producers of the bucket, or a collective launched from the
+    backward starts before the last weight-gradient kernel has added its part (which then lands on top of this rank's reduced
+    values only: parameters drifting apart across ranks by a few ulps, seen once in the two-rank test above)."""
+    from evoke_amd import distributed as D, ops
+    ops.clear_grad_callbacks()
+    W = torch.nn.Parameter(torch.randn(64, 32, device='cuda') * 0.1)
+    flat = torch.zeros(W.numel(), device='cuda')
+    W.grad = flat.view_as(W)
+    red = D.GradReducer([flat], [[(W, 0, W.numel())]])
+    try:
+        x = torch.randn(16, 32, device='cuda').to(ops.BF16).requires_grad_(True)
+        red.begin('one-linear')
+        ops.linear(x, W).float().sum().backward()
+        wg = ops.existing_side_stream('wgrad')
+        assert wg is not None, 'the linear backward did not use the weight-gradient stream'
+        assert wg in red.streams[red.bucket_of[id(W)]]
+        red.finish()
+        torch.cuda.synchronize()
+        want = torch.ones(16, 64) .t() @ x.float().cpu()
+        assert torch.allclose(flat.view_as(W).cpu(), want, rtol=1e-3, atol=1e-3)
+    finally:
+        ops.clear_grad_callbacks()
