@@ -102,6 +102,81 @@ __global__ __launch_bounds__(256) void upsample2_zero_kernel(const uint4* __rest
   }
 }
 
+// ---- data gradient of a 3x3 / stride 2 / pad 1 convolution by OUTPUT PARITY ----------------------------------------------------------
+// dx[2i + a][2j + b] only receives the taps kh = a + 1 (mod 2), kw = b + 1 (mod 2): one tap for (even, even), two for the mixed classes,
+// four for (odd, odd) -- 2.25 per input pixel instead of the 9 the gathering GEMM multiplies (three quarters of them by zero).  Each class
+// is a small stride-1 convolution over dy (rows i, i + 1 / columns j, j + 1) with its own slice of the weights:
+//   a = 0: tap t = 0 <-> kh = 1 (dy row i);   a = 1: t = 0 <-> kh = 2 (dy row i), t = 1 <-> kh = 0 (dy row i + 1);  likewise for columns.
+// class weights wc[class][ci][t][u][co] = w[co][kh(a, t)][kw(b, u)][ci], classes in the order (0,0) (0,1) (1,0) (1,1) at element offsets
+// 0, 1, 3, 5 x Ci*Co.
+__device__ __forceinline__ int s2_tap(int par, int t) { return par == 0 ? 1 : (t == 0 ? 2 : 0); }
+__global__ __launch_bounds__(256) void conv_s2_class_weights_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ wc, int Co, int Ci) {
+  const long per = (long)Ci * Co, total = 9 * per;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long q = i / per;                       // 0 | 1,2 | 3,4 | 5..8
+    const int cls = q < 1 ? 0 : (q < 3 ? 1 : (q < 5 ? 2 : 3));
+    const int a = cls >> 1, b = cls & 1, TA = a + 1, TB = b + 1;
+    const long base = (cls == 0 ? 0 : cls == 1 ? 1 : cls == 2 ? 3 : 5) * per;
+    long r = i - base;                            // [ci][t][u][co]
+    const int co = (int)(r % Co); r /= Co;
+    const int u = (int)(r % TB); r /= TB;
+    const int t = (int)(r % TA);
+    const int ci = (int)(r / TA);
+    wc[i] = w[(((long)co * 3 + s2_tap(a, t)) * 3 + s2_tap(b, u)) * Ci + ci];
+  }
+}
+
+// dx[n][2i + a][2j + b][:] = gate > 0 ? cls[a][b][n][i][j][:] : 0, plus per-block partial sums (sum g, sum g * gate) per channel.
+// A thread owns 8 channels (blockDim.x % (C / 8) == 0: the grid stride keeps them), a block a contiguous range of output pixels;
+// its pixel lanes are summed through LDS and leave as one partial row [2][C].
+struct S2IP { const bf16_t* cls; const bf16_t* gate; bf16_t* dx; float* part; int N, Ho, Wo, C; long px_per_block; };
+__global__ __launch_bounds__(256) void conv_s2_interleave_kernel(const S2IP p) {
+  __shared__ float red[2][256][8];
+  const int G = p.C >> 3, cg = threadIdx.x % G, pl = threadIdx.x / G, PL = 256 / G;
+  const long M = (long)p.N * 4 * p.Ho * p.Wo, Mc = (long)p.N * p.Ho * p.Wo;
+  const long m0 = blockIdx.x * p.px_per_block, m1 = min(M, m0 + p.px_per_block);
+  float sg[8], sz[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sg[j] = 0.f; sz[j] = 0.f; }
+  const int W2 = 2 * p.Wo, H2 = 2 * p.Ho;
+  for (long m = m0 + pl; m < m1; m += PL) {
+    const int x = (int)(m % W2);
+    const long t = m / W2;
+    const int y = (int)(t % H2);
+    const long n = t / H2;
+    const int c = ((y & 1) << 1) | (x & 1);
+    const uint4 v = *reinterpret_cast<const uint4*>(p.cls + (((long)c * Mc + (n * p.Ho + (y >> 1)) * p.Wo + (x >> 1)) * p.C + cg * 8));
+    const uint4 z = *reinterpret_cast<const uint4*>(p.gate + m * p.C + cg * 8);
+    const uint32_t vw[4] = {v.x, v.y, v.z, v.w}, zw[4] = {z.x, z.y, z.z, z.w};
+    uint32_t ow[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float z0 = lo_bf(zw[k]), z1 = hi_bf(zw[k]);
+      // the gated value as it is stored (16-bit), so that the statistics describe the tensor the next pass reads
+      const uint32_t kept = (z0 > 0.f ? (vw[k] & 0xffffu) : 0u) | (z1 > 0.f ? (vw[k] & 0xffff0000u) : 0u);
+      ow[k] = kept;
+      const float g0 = lo_bf(kept), g1 = hi_bf(kept);
+      sg[2 * k] += g0; sg[2 * k + 1] += g1;
+      sz[2 * k] += g0 * z0; sz[2 * k + 1] += g1 * z1;
+    }
+    *reinterpret_cast<uint4*>(p.dx + m * p.C + cg * 8) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+  }
+  if (p.part) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[0][threadIdx.x][j] = sg[j]; red[1][threadIdx.x][j] = sz[j]; }
+    __syncthreads();
+    if (pl == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float a = 0.f, b = 0.f;
+        for (int q = 0; q < PL; ++q) { a += red[0][q * G + cg][j]; b += red[1][q * G + cg][j]; }
+        p.part[(long)blockIdx.x * 2 * p.C + cg * 8 + j] = a;
+        p.part[(long)blockIdx.x * 2 * p.C + p.C + cg * 8 + j] = b;
+      }
+    }
+  }
+}
+
 void stem_geom(evk_conv_geom* g, int N, int H, int W) {
   const int Hp = H + 6, Wp = W + 8;
   g->N = N; g->Hi = Hp; g->Wi = W / 2; g->Ci = 32;
@@ -219,6 +294,69 @@ int evk_conv2d_dgrad_gated_stats(const void* dy, const void* w, const void* resi
   }
   d.g = *g;
   return evk_gemm_launch(&d, stream);
+}
+
+static bool s2_parity_geom(const evk_conv_geom* g) {
+  return g && g->KH == 3 && g->KW == 3 && g->stride_h == 2 && g->stride_w == 2 && g->pad_h == 1 && g->pad_w == 1 && g->Hi == 2 * g->Ho &&
+         g->Wi == 2 * g->Wo && g->Ci % 8 == 0 && g->Ci <= 2048 && 256 % (g->Ci / 8) == 0 && ilog2_exact(g->Co) >= 3;
+}
+
+int evk_conv3x3s2_dgrad_parity_supported(const evk_conv_geom* g) {
+  static const int on = [] { const char* e = getenv("EVK_S2_PARITY"); return e ? atoi(e) : 1; }();
+  return on && s2_parity_geom(g) ? 1 : 0;
+}
+
+int64_t evk_conv3x3s2_dgrad_parity_ws_bytes(const evk_conv_geom* g) {
+  return s2_parity_geom(g) ? (int64_t)g->N * g->Hi * g->Wi * g->Ci * 2 : 0;          // the four compact class outputs
+}
+
+int evk_conv3x3s2_class_weights(const void* w, void* wc, int32_t Co, int32_t Ci, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(w && wc && Co > 0 && Ci > 0, "conv3x3s2_class_weights: bad args");
+  const long total = 9L * Co * Ci;
+  ProfScope ps(EVK_FAM_ELTWISE, s);
+  hipLaunchKernelGGL(conv_s2_class_weights_kernel, dim3((unsigned)(cdiv(total, 256) > 4096 ? 4096 : cdiv(total, 256))), dim3(256), 0, s,
+                     (const bf16_t*)w, (bf16_t*)wc, Co, Ci);
+  return evk_check_launch("conv_s2_class_weights");
+}
+
+int evk_conv3x3s2_dgrad_parity(const void* dy, const void* wc, const void* gate, void* dx, const evk_conv_geom* g, void* ws, int64_t ws_bytes,
+                               float* part, int64_t part_bytes, int32_t* nblk, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (int e = check_geom(g)) return e;
+  EVK_REQUIRE(dy && wc && gate && dx && ws, "conv3x3s2_dgrad_parity: null operand (the ReLU gate is required)");
+  EVK_REQUIRE(s2_parity_geom(g), "conv3x3s2_dgrad_parity: 3x3 / stride 2 / pad 1 with even input size, Ci %% 8 == 0 dividing 2048");
+  EVK_REQUIRE(ws_bytes >= evk_conv3x3s2_dgrad_parity_ws_bytes(g), "conv3x3s2_dgrad_parity: workspace too small");
+  const long Mc = (long)g->N * g->Ho * g->Wo, per = (long)g->Ci * g->Co;
+  const long woff[4] = {0, 1, 3, 5};
+  for (int cls = 0; cls < 4; ++cls) {
+    const int a = cls >> 1, b = cls & 1;
+    evk_gemm d{};
+    d.A = dy; d.B = (const bf16_t*)wc + woff[cls] * per; d.C = (bf16_t*)ws + (long)cls * Mc * g->Ci;
+    d.M = (int)Mc; d.N = g->Ci; d.K = (a + 1) * (b + 1) * g->Co;
+    d.a_mode = (a | b) ? EVK_A_CONV : EVK_A_PLAIN; d.b_mode = EVK_B_PLAIN;
+    d.lda = g->Co; d.ldb = d.K; d.ldc = g->Ci;
+    d.batch_outer = d.batch_inner = 1; d.alpha = 1.f; d.c_dtype = EVK_BF16;
+    d.g.N = g->N; d.g.Hi = g->Ho; d.g.Wi = g->Wo; d.g.Ci = g->Co; d.g.Ho = g->Ho; d.g.Wo = g->Wo; d.g.Co = g->Ci;
+    d.g.KH = a + 1; d.g.KW = b + 1; d.g.stride_h = d.g.stride_w = 1; d.g.pad_h = d.g.pad_w = 0;
+    d.g.sN = (int64_t)g->Ho * g->Wo * g->Co; d.g.sH = (int64_t)g->Wo * g->Co; d.g.sW = g->Co;
+    if (int e = evk_gemm_launch(&d, stream)) return e;
+  }
+  const long M = 4 * Mc;
+  long blocks = cdiv(M, 256 / (g->Ci / 8) * 4);          // at least four pixels per thread row, at most 2048 blocks
+  if (blocks > 2048) blocks = 2048;
+  if (part) {
+    EVK_REQUIRE(nblk, "conv3x3s2_dgrad_parity: nblk is required with part");
+    const long cap = part_bytes / (2L * g->Ci * (long)sizeof(float));
+    EVK_REQUIRE(cap >= 1, "conv3x3s2_dgrad_parity: statistics buffer too small");
+    if (blocks > cap) blocks = cap;
+    *nblk = (int)blocks;
+  }
+  S2IP p{(const bf16_t*)ws, (const bf16_t*)gate, (bf16_t*)dx, part, g->N, g->Ho, g->Wo, g->Ci, cdiv(M, blocks)};
+  ProfScope ps(EVK_FAM_ELTWISE, s);
+  hipLaunchKernelGGL(conv_s2_interleave_kernel, dim3((unsigned)cdiv(M, p.px_per_block)), dim3(256), 0, s, p);
+  if (part) *nblk = (int)cdiv(M, p.px_per_block);
+  return evk_check_launch("conv_s2_interleave");
 }
 
 int evk_upsample2_zero(const void* src, void* dst, int32_t N, int32_t Ho, int32_t Wo, int32_t C, evk_stream_t stream) {

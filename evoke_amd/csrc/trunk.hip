@@ -25,6 +25,7 @@ struct Plan {
   int N, H, W;
   long xpad, wp, dwp, pooled, pool_idx, red, slab, zeros, part, gbuf[6];
   std::vector<long> wflip;   // per pair: offset of the flipped / transposed 16-bit weights (stride-1 3x3 convolutions), or -1
+  std::vector<long> wcls;    // per pair: offset of the parity-class weights of a stride-2 3x3 convolution (evk_conv3x3s2_class_weights), or -1
   long gcap, slab_bytes, red_bytes, part_bytes;
   long total;
 };
@@ -100,8 +101,10 @@ int make_plan(const evk_trunk_cfg* cfg, int N, int H, int W, Plan& P) {
   P.part_bytes = part;
   P.part = take(part);
   P.wflip.assign(P.pairs.size(), -1);
+  P.wcls.assign(P.pairs.size(), -1);
   for (size_t i = 1; i < P.pairs.size(); ++i) {
     const evk_conv_geom& g = P.pairs[i].g;
+    if (evk_conv3x3s2_dgrad_parity_supported(&g) && evk_conv3x3s2_dgrad_parity_ws_bytes(&g) <= gcap) P.wcls[i] = take((long)g.Co * 9 * g.Ci * 2);
     if (g.KH == 3 && g.KW == 3 && g.stride_h == 1 && g.stride_w == 1 && g.pad_h == 1 && g.pad_w == 1)
       P.wflip[i] = take((long)g.Co * 9 * g.Ci * 2);
     // contracting pointwise data gradients (Bottleneck.conv3) the strip GEMM takes: their weights transposed to [Ci][Co]
@@ -293,6 +296,9 @@ int evk_trunk_backward(const evk_trunk_cfg* cfg, const evk_trunk_layer* layers, 
     if (!ws_.empty()) TRY(evk_conv_flip_weights(ws_.data(), wt_.data(), co_.data(), ci_.data(), k_.data(), k_.data(), (int32_t)ws_.size(), stream));
   }
 
+  for (size_t i = 1; i < P.pairs.size(); ++i)         // parity-class weights of the stride-2 3x3 convolutions (three small launches)
+    if (P.wcls[i] >= 0) TRY(evk_conv3x3s2_class_weights(layers[i].w, c.at(P.wcls[i]), P.pairs[i].g.Co, P.pairs[i].g.Ci, stream));
+
   auto wgrad = [&](int i, const void* xin) -> int {
     if (!layers[i].dw) return EVK_OK;
     evk_stream_t s2 = q.fork();
@@ -339,7 +345,10 @@ int evk_trunk_backward(const evk_trunk_cfg* cfg, const evk_trunk_layer* layers, 
     TRY(wgrad(i + 2, c.at(P.pairs[i + 1].z)));
     if (gs1) TRY(bn_backward_from_gate(c, i + 1, S1, nb1));
     else TRY(bn_backward(c, i + 1, S1, nullptr, 0));
-    if (flip_on && P.wflip[i + 1] >= 0)
+    if (P.wcls[i + 1] >= 0)        // stride 2: by output parity (2.25 taps per pixel instead of 9); gbuf[2] is free until the max-pool backward
+      TRY(evk_conv3x3s2_dgrad_parity(c.at(P.pairs[i + 1].dy), c.at(P.wcls[i + 1]), c.at(P.pairs[i].z), S2, &P.pairs[i + 1].g, c.at(P.gbuf[2]),
+                                     P.gcap, gs0 ? part : nullptr, P.part_bytes, &nb0, stream));
+    else if (flip_on && P.wflip[i + 1] >= 0)
       TRY(evk_conv2d_dgrad_flipped_gated_stats(c.at(P.pairs[i + 1].dy), c.at(P.wflip[i + 1]), nullptr, c.at(P.pairs[i].z), S2, &P.pairs[i + 1].g,
                                                gs0 ? part : nullptr, P.part_bytes, &nb0, stream));
     else

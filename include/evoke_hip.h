@@ -146,6 +146,17 @@ int evk_conv2d_dgrad_add(const void* dy, const void* w, const void* resid, void*
  * instead of the gather + K-strided one (layer3: 87 instead of 123 us alone, 167 with the gate epilogue).  evk_conv_flip_weights
  * produces wt for a whole table of layers in one launch (w / wt: arrays of n_layers device pointers in HOST memory);
  * evk_conv2d_dgrad_flipped_gated_stats = evk_conv2d_dgrad_gated_stats with wt in place of w (g = the geometry of the forward conv). */
+/* Data gradient of a 3x3 / stride 2 / pad 1 convolution (torchvision Bottleneck.conv2 of the first block of layers 2-4) by OUTPUT PARITY:
+ * input pixel (2i + a, 2j + b) only receives the taps kh = a + 1, kw = b + 1 (mod 2) -- 2.25 taps per pixel instead of the 9 the
+ * gathering GEMM multiplies.  evk_conv3x3s2_class_weights re-packs w [Co][3][3][Ci] into the four class slices (9 Ci Co elements, once per
+ * step); evk_conv3x3s2_dgrad_parity runs the four small stride-1 convolutions over dy into ws (evk_conv3x3s2_dgrad_parity_ws_bytes) and
+ * one pass that interleaves them into dx, applies the ReLU gate (required) and leaves *nblk partial rows [2][Ci] of (sum g, sum g * gate)
+ * as evk_conv2d_dgrad_gated_stats does.  EVK_S2_PARITY=0 disables the route in evk_trunk_backward. */
+int evk_conv3x3s2_dgrad_parity_supported(const evk_conv_geom* g);
+int64_t evk_conv3x3s2_dgrad_parity_ws_bytes(const evk_conv_geom* g);
+int evk_conv3x3s2_class_weights(const void* w, void* wc, int32_t Co, int32_t Ci, evk_stream_t stream);
+int evk_conv3x3s2_dgrad_parity(const void* dy, const void* wc, const void* gate, void* dx, const evk_conv_geom* g, void* ws, int64_t ws_bytes,
+                               float* part, int64_t part_bytes, int32_t* nblk, evk_stream_t stream);
 /* dst[N][2 Ho][2 Wo][C] = src[N][Ho][Wo][C] at the even pixels, zero elsewhere (16-bit, C % 8 == 0): the data gradient of a pointwise
  * stride-2 convolution (torchvision Bottleneck.downsample[0] of layers 2-4) from the COMPACT product dy . w -- three quarters of the
  * input pixels receive no gradient, so the product runs on a quarter of the rows and this pass writes the zeros */

@@ -477,6 +477,42 @@ def test_halo_conv3x3_weight_gradient(H, N, Hh, W, Ci, Co):
     assert torch.equal(dw, dw2)
 
 
+@pytest.mark.parametrize('N,Ho,Ci,Co', [(2, 8, 128, 128), (1, 12, 256, 64), (3, 5, 64, 256), (2, 6, 512, 512)])
+def test_stride2_conv3x3_data_gradient_by_output_parity(H, N, Ho, Ci, Co):
+    """conv.hip, evk_conv3x3s2_dgrad_parity: the data gradient of a 3x3 / stride 2 / pad 1 convolution as four small stride-1 convolutions
+    over dy (one per parity class of the input pixel) + the interleaving pass with the ReLU gate and the gate statistics, against the fp32
+    transposed convolution of the same rounded operands and against the gathering GEMM (evk_conv2d_dgrad_gated_stats)."""
+    Hi = 2 * Ho
+    g = H.conv_geom(N, Hi, Hi, Ci, Co, 3, 3, 2, 1)
+    assert g.Ho == Ho and H.lib.evk_conv3x3s2_dgrad_parity_supported(C.byref(g)) == 1
+    w = rnd(Co, 3, 3, Ci, seed=51, scale=(2.0 / (9 * Co)) ** 0.5).cuda()
+    dy = rnd(N, Ho, Ho, Co, seed=52).cuda()
+    gate = torch.relu(rnd(N, Hi, Hi, Ci, seed=53).float()).to(STORE_DTYPE).cuda()
+    wc = torch.empty(9 * Ci * Co, dtype=STORE_DTYPE, device='cuda')
+    H.check(H.lib.evk_conv3x3s2_class_weights(H.ptr(w), H.ptr(wc), Co, Ci, H.stream()))
+    wsb = H.lib.evk_conv3x3s2_dgrad_parity_ws_bytes(C.byref(g))
+    ws = torch.empty(wsb // 2, dtype=STORE_DTYPE, device='cuda')
+    nb = H.lib.evk_conv_stats_bytes(N * Hi * Hi, Ci)
+    part, part2 = torch.full((nb // 4,), 3.0, device='cuda'), torch.zeros(nb // 4, device='cuda')
+    n1, n2 = C.c_int32(0), C.c_int32(0)
+    dx = torch.full((N, Hi, Hi, Ci), 5.0, dtype=STORE_DTYPE, device='cuda')
+    H.check(H.lib.evk_conv3x3s2_dgrad_parity(H.ptr(dy), H.ptr(wc), H.ptr(gate), H.ptr(dx), C.byref(g), H.ptr(ws), wsb, H.ptr(part), nb, C.byref(n1), H.stream()))
+    dx2 = torch.empty_like(dx)
+    H.check(H.lib.evk_conv2d_dgrad_gated_stats(H.ptr(dy), H.ptr(w), None, H.ptr(gate), H.ptr(dx2), C.byref(g), H.ptr(part2), nb, C.byref(n2), H.stream()))
+    torch.cuda.synchronize()
+    ref = F.conv_transpose2d(dy.float().cpu().permute(0, 3, 1, 2), w.float().cpu().permute(0, 3, 1, 2), None, 2, 1, output_padding=1).permute(0, 2, 3, 1)
+    gref = ref * (gate.float().cpu() > 0)
+    rt = 2.0 ** -8 if STORE_DTYPE == torch.bfloat16 else 2.0 ** -10
+    close(dx, gref, rt, 2e-3)
+    close(dx, dx2.float().cpu(), 2 * rt, 2e-3)
+    s1 = part[:n1.value * 2 * Ci].view(n1.value, 2, Ci).sum(0).cpu()
+    gf, zf = dx.float().cpu().reshape(-1, Ci), gate.float().cpu().reshape(-1, Ci)           # statistics of the stored (rounded) gradient
+    assert float((s1[0] - gf.sum(0)).abs().max()) <= 2e-5 * float(gf.abs().sum(0).max()) + 1e-3
+    assert float((s1[1] - (gf * zf).sum(0)).abs().max()) <= 2e-5 * float((gf * zf).abs().sum(0).max()) + 1e-3
+    s2 = part2[:n2.value * 2 * Ci].view(n2.value, 2, Ci).sum(0).cpu()
+    assert float((s1 - s2).abs().max()) <= 4 * rt * float(gf.abs().sum(0).max()) + 1e-2
+
+
 def test_halo_conv3x3_refuses_what_it_cannot_tile(H):
     assert H.lib.evk_conv3x3_halo_supported(1, 8, 200, 64, 128) == 0       # the halo of even one 200-pixel row exceeds the LDS buffer
     assert H.lib.evk_conv3x3_halo_supported(4, 4, 5, 64, 128) == 1         # tiny images: many per tile

@@ -51,6 +51,21 @@ def conv_case(N, Hh, Ci, Co, k, stride, kind):
         nblk = C.c_int32(0)
         return lambda: H.check(H.lib.evk_conv2d_dgrad_flipped_gated_stats(H.ptr(y), H.ptr(wt), None, H.ptr(gate), H.ptr(dx), C.byref(g),
                                                                           H.ptr(part), pb, C.byref(nblk), st()))
+    if kind == 'dgrad_s2':            # 3x3 / stride 2 data gradient + gate + gate statistics: by output parity (default) or the gathering GEMM
+        import os
+        gate = torch.relu(torch.randn_like(x)).to(BF)
+        pb = H.lib.evk_conv_stats_bytes(N * Hh * Hh, Ci)
+        part = torch.empty(pb // 4, device='cuda')
+        nblk = C.c_int32(0)
+        if os.environ.get('EVK_S2_PARITY', '1') != '0':
+            wc = torch.empty(9 * Ci * Co, device='cuda', dtype=BF)
+            wsb = H.lib.evk_conv3x3s2_dgrad_parity_ws_bytes(C.byref(g))
+            ws2 = torch.empty(wsb // 2, device='cuda', dtype=BF)
+            H.check(H.lib.evk_conv3x3s2_class_weights(H.ptr(w), H.ptr(wc), Co, Ci, st()))
+            return lambda: H.check(H.lib.evk_conv3x3s2_dgrad_parity(H.ptr(y), H.ptr(wc), H.ptr(gate), H.ptr(dx), C.byref(g), H.ptr(ws2), wsb, H.ptr(part),
+                                                                    pb, C.byref(nblk), st()))
+        return lambda: H.check(H.lib.evk_conv2d_dgrad_gated_stats(H.ptr(y), H.ptr(w), None, H.ptr(gate), H.ptr(dx), C.byref(g), H.ptr(part), pb,
+                                                                  C.byref(nblk), st()))
     if kind == 'fwd_stats':
         pb = max(H.lib.evk_conv_stats_bytes(N * g.Ho * g.Wo, Co), H.lib.evk_conv3x3_halo_part_bytes(N, Hh, Hh, Co))
         part = torch.empty(pb // 4, device='cuda')
@@ -75,6 +90,9 @@ CASES = [
     ('conv3x3 l3 fwd+stats 128 images (decode encoder)', lambda: conv_case(128, 24, 256, 256, 3, 1, 'fwd_stats'), 2 * 73728 * 256 * 2304),
     ('conv3x3 l1 fwd+stats 64x96x96 64->64', lambda: conv_case(64, 96, 64, 64, 3, 1, 'fwd_stats'), 2 * 589824 * 64 * 576),
     ('conv3x3 l1 dgrad flipped+gate+stats 64->64', lambda: conv_case(64, 96, 64, 64, 3, 1, 'dgrad_flip'), 2 * 589824 * 64 * 576),
+    ('conv3x3 s2 dgrad+gate+stats l2 64x96x96 128->128', lambda: conv_case(64, 96, 128, 128, 3, 2, 'dgrad_s2'), 2 * 147456 * 128 * 1152),
+    ('conv3x3 s2 dgrad+gate+stats l3 64x48x48 256->256', lambda: conv_case(64, 48, 256, 256, 3, 2, 'dgrad_s2'), 2 * 36864 * 256 * 2304),
+    ('conv3x3 s2 dgrad+gate+stats l4 64x24x24 512->512', lambda: conv_case(64, 24, 512, 512, 3, 2, 'dgrad_s2'), 2 * 9216 * 512 * 4608),
     ('conv3x3 l3 dgrad', lambda: conv_case(64, 24, 256, 256, 3, 1, 'dgrad'), 2 * 36864 * 256 * 2304),
     ('conv3x3 l3 wgrad', lambda: conv_case(64, 24, 256, 256, 3, 1, 'wgrad'), 2 * 36864 * 256 * 2304),
     ('conv3x3 l1 wgrad 64->64', lambda: conv_case(64, 96, 64, 64, 3, 1, 'wgrad'), 2 * 589824 * 64 * 576),
