@@ -176,22 +176,33 @@ def decode_record(model, a, rank, world, dev, with_cpu):
     t_mean = (L - 1) / 2.0
     state_bytes = (t_mean * 3 * 2 * 512 + 144 * 3 * 2 * 512 + 1536) * 2.0
     alg_bytes = 2.0 * w_params + R * state_bytes
-    ach = depth * alg_bytes / (per_step_ms * 1e-3) / 1e9          # `depth` searches in flight: each of their steps moves alg_bytes
+    # achieved = the algorithmic bytes of EVERY token step issued in the timed region / the region's wall time (encoders of the batches
+    # included: they share the GPU with the searches in flight) -- reproducible from ms_per_batch alone: L * alg_bytes / ms_per_batch.
+    # per_search_step_ms (HIP events around one search's replays) is reported beside it; with `depth` searches in flight it is LONGER than
+    # ms_per_batch / L, which is the effective time per token step of the pipeline.
+    ms_per_batch = 1e3 * dt / n
+    eff_step_ms = ms_per_batch / L
+    ach = L * alg_bytes / (ms_per_batch * 1e-3) / 1e9
+    n_launch = DEC.stats.get('step_launches')
     rec = {
         'metric': 'decode tokens/sec (beam search, %d^2)' % a.res, 'value': B * L * n * world / dt, 'unit': 'tokens/s', 'steps': n,
-        'ms_per_batch': 1e3 * dt / n, 'higher_is_better': True, 'dtype': H.STORE,
+        'ms_per_batch': ms_per_batch, 'higher_is_better': True, 'dtype': H.STORE,
         'config': {'workload': 'EVOKE-%d inference: beam=%d, batch %d studies x %d views, max_seq_len %d (all steps run, as the reference), '
                                'incremental decoder state, visual extractor + fusion included, V=%d, random-init weights'
                                % (a.res, beam, B, a.views, L, V), 'parallelism': 'replicas x%d' % world,
                    'mean_generated_len': float((seq != 0).sum(1).float().mean().item()), 'hip_graph_step': DEC.stats.get('graph'),
                    'pipelined_encoders': pipelined, 'searches_in_flight': depth,
-                   'fused_beam_bookkeeping': DEC.stats.get('fused_bookkeeping')},
-        'roofline': {'bound': 'hbm', 'kernel': 'per-token decode step (captured once, re-issued by csrc/replay.hip: RM step, 3 decoder layers, logits, log-softmax, beam step = 52 launches)',
+                   'relational_memory': 'f32 (default)' if DEC._RM_F32[0] else '16-bit (EVK_DECODE_RM_F32=0)',
+                   'fused_beam_bookkeeping': DEC.stats.get('fused_bookkeeping'), 'launches_per_token_step': n_launch},
+        'roofline': {'bound': 'hbm', 'kernel': 'per-token decode step (captured once, re-issued by csrc/replay.hip: relational-memory step, 3 decoder layers, '
+                                               'logits, log-softmax, beam step = %s launches)' % (n_launch if n_launch else '~50'),
                      'achieved': ach, 'peak': 8000.0, 'unit': 'GB/s', 'frac': ach / 8000.0, 'traffic': None,
-                     'algorithmic_bytes_per_step': alg_bytes, 'step_ms': per_step_ms, 'hypotheses': R, 'searches_in_flight': depth,
-                     'note': 'the step is a chain of 52 small dependent kernels; the device retires about one such kernel per 5 us however many streams feed it, so '
-                             '`searches_in_flight` independent searches are decoded at the same time (FineTune.generate_pipelined) and achieved = their '
-                             'algorithmic bytes per measured per-search step time; step_ms is that per-search step time under the overlap'},
+                     'algorithmic_bytes_per_step': alg_bytes, 'step_ms': eff_step_ms, 'steps_per_batch': L, 'hypotheses': R,
+                     'per_search_step_ms': per_step_ms, 'searches_in_flight': depth,
+                     'overlap_factor': (per_step_ms / eff_step_ms) if eff_step_ms > 0 else None,
+                     'note': 'achieved = steps_per_batch x algorithmic_bytes_per_step / ms_per_batch (whole pipeline: encoders of the next batch and `searches_in_flight` '
+                             'independent searches share the GPU); step_ms = ms_per_batch / steps_per_batch, so step_ms x steps_per_batch = ms_per_batch by construction; '
+                             'per_search_step_ms = HIP events around ONE search\'s replays under that overlap (a chain of small dependent kernels)'},
     }
     if with_cpu:
         try:
@@ -232,18 +243,20 @@ def decode_cpu_baseline(model, a, dev, beam, L):
 
     with torch.no_grad():
         xs, ms = pm.encoder_states(b['images'].to(dev), b['pids'], Bc, b['inc'], b['inc_masks'])
+        # the shipped decode mode (relational memory in f32 unless EVK_DECODE_RM_F32=0) ...
+        default_f32 = bool(DEC._RM_F32[0])
         hip_seq = DEC.beam_search(pm.text_decoder, xs, ms, dict(pm.args, beam_size=beam, max_seq_len=L), step_hook=watch).cpu()
-        # the same search with the relational memory of the decode step in f32 (EVK_DECODE_RM_F32, csrc/rm_f32.hip: no drift at depth)
-        picks16, saved = list(picks), DEC._RM_F32[0]
+        # ... and the same search in the OTHER mode of the recurrence, for comparison
+        picks_def, saved = list(picks), DEC._RM_F32[0]
         del picks[:]
-        DEC._RM_F32[0] = True
+        DEC._RM_F32[0] = not default_f32
         DEC._SESSIONS.clear()
         try:
-            hip_seq32 = DEC.beam_search(pm.text_decoder, xs, ms, dict(pm.args, beam_size=beam, max_seq_len=L), step_hook=watch).cpu()
+            hip_seq_alt = DEC.beam_search(pm.text_decoder, xs, ms, dict(pm.args, beam_size=beam, max_seq_len=L), step_hook=watch).cpu()
         finally:
             DEC._RM_F32[0] = saved
             DEC._SESSIONS.clear()
-        picks32 = list(picks)
+        picks_alt = list(picks)
     P = {k: (v.detach().float() if v.is_floating_point() else v.detach()).cpu() for k, v in pm.state_dict().items() if not k.endswith('position_ids')}
     del pm
     cfg = dict(O.DEFAULT_CFG, max_seq_len=L, beam_size=beam)
@@ -298,18 +311,21 @@ def decode_cpu_baseline(model, a, dev, beam, L):
             first_div.append(rec_)
         return first_div
 
-    same_seq32, same_tok32 = metrics.token_agreement(hip_seq32.tolist(), ref_seq.tolist())
-    par = dict(first_divergent_decision=first_divergence(picks16), identical_sequences=same_seq,
-               rm_f32_mode=dict(first_divergent_decision=first_divergence(picks32), identical_sequences=same_seq32, token_agreement=same_tok32,
-                                note='same inputs with EVK_DECODE_RM_F32=1 (relational memory of the decode step in f32: no drift of the recurrence, '
-                                     '14 % fewer tokens/s; opt-in)'), token_agreement=same_tok, bleu4_vs_oracle=bl[3], studies=Bc, common_prefix_tokens=pref,
+    same_seq_alt, same_tok_alt = metrics.token_agreement(hip_seq_alt.tolist(), ref_seq.tolist())
+    mode_name = lambda f32: 'relational memory in f32 (csrc/rm_f32.hip)' if f32 else '16-bit relational memory (EVK_DECODE_RM_F32=0)'      # noqa: E731
+    par = dict(mode=mode_name(default_f32) + ' -- the shipped default, the mode `value` above was measured in',
+               first_divergent_decision=first_divergence(picks_def), identical_sequences=same_seq, token_agreement=same_tok,
+               bleu4_vs_oracle=bl[3], studies=Bc, common_prefix_tokens=pref,
                oracle_logprob_of_engine_sequences=sc_h, oracle_logprob_of_oracle_sequences=sc_r,
-               note='engine (16-bit) vs CPU oracle (fp32) on the same inputs and the procedural weights of the golden fixtures, beam %d, %d positions; '
-                    'an untrained network never emits [EOS] and its logit gaps are tiny, so once one near-tie resolves differently the rest of the '
-                    'sequence differs -- first_divergent_decision gives, per study, the position at which the two searches first select different hypothesis sets, '
+               other_mode=dict(mode=mode_name(not default_f32), first_divergent_decision=first_divergence(picks_alt),
+                               identical_sequences=same_seq_alt, token_agreement=same_tok_alt),
+               note='engine (16-bit operands; f32 relational-memory recurrence) vs CPU oracle (fp32) on the same inputs and the procedural weights of the golden '
+                    'fixtures, beam %d, %d positions; an untrained network never emits [EOS] and its logit gaps are tiny (the oracle\'s own selection margin is '
+                    'below 1e-2 at a tenth of the positions), so once one near-tie resolves differently the rest of the sequence differs -- '
+                    'first_divergent_decision gives, per study, the position at which the two searches first select different hypothesis sets, '
                     'the oracle (fp32) margin between its last selected and first rejected candidate there, and the oracle score gap to what the engine '
-                    'picked instead (None = the searches never part); the <= 40-position golden cases are token-exact and the 100-position golden is '
-                    'followed decision by decision in tests/test_model_gpu.py' % (beam, L))
+                    'picked instead (None = the searches never part); tests/test_model_gpu.py holds the engine to |log-probability - reference| <= 8e-3 at '
+                    'every position of every beam golden (teacher forced) and to the reference ids wherever its margins exceed twice that' % (beam, L))
     return base, par
 
 

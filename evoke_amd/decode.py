@@ -29,9 +29,10 @@ _FUSED_APPEND = [os.environ.get('EVK_DECODE_FUSED_APPEND', '1') != '0']  # K / V
 _FUSED_LN = [os.environ.get('EVK_DECODE_FUSED_LN', 'off')]
 _SPLIT_CLN = [os.environ.get('EVK_DECODE_SPLIT_CLN', '1') != '0']       # first conditional-norm MLP layer as two launches (see cln_deltas)
 _FUSED_BOOK = [os.environ.get('EVK_DECODE_FUSED_BOOK', '1') != '0']      # beam bookkeeping as one kernel per token (csrc/beam.hip)
-# relational memory of the decode step in f32 (csrc/rm_f32.hip): the engine's log-probabilities then stay within 3.5e-3 of the reference's at
-# ALL 100 positions of the config-5 golden, <= 5.3e-3 (16-bit recurrence: 2e-3 at position 10, 0.5 at position 90), at 14 % fewer tokens/s; opt-in
-_RM_F32 = [os.environ.get('EVK_DECODE_RM_F32', '0') != '0']
+# relational memory of the decode step in f32 (csrc/rm_f32.hip) -- the DEFAULT since round 4: the engine's log-probabilities stay within 5.3e-3 of
+# the reference's at ALL 100 positions of the config-5 golden (the 16-bit recurrence: 2e-3 at position 10, 0.5 at position 90).  EVK_DECODE_RM_F32=0
+# selects the 16-bit recurrence (evk_rm_decode_step), which drifts at depth and is kept for comparison only.
+_RM_F32 = [os.environ.get('EVK_DECODE_RM_F32', '1') != '0']
 _RM_STEP = [os.environ.get('EVK_DECODE_RM_STEP', '1') != '0']          # relational-memory step as one native call (evk_rm_decode_step)
 _REPLAYER = [os.environ.get('EVK_DECODE_REPLAYER', '1') != '0']      # re-issue the captured step with csrc/replay.hip instead of hipGraphLaunch
 stats = {}                       # facts about the last beam_search call (bench.py reads the per-token step time from here)
@@ -427,6 +428,9 @@ class _BeamSession:
         self.base = torch.arange(B, device=dev).unsqueeze(1)
         self.graph = self.plan = None
         self.fused_key = None
+        # the encoder key mask of the CURRENT batch, in a buffer the session owns: the captured per-token step records a pointer, so a
+        # later batch's mask must land at the same address (a session serves masked or unmasked batches, never both: part of its key)
+        self.src_mask = None
 
     def __del__(self):
         if getattr(self, 'plan', None) is not None:
@@ -461,6 +465,23 @@ class _BeamSession:
             return e.value
 
     def run_iter(self, enc, src_mask, return_scores=False, step_hook=None):
+        """_run_iter under eval mode and no_grad for as long as the generator RUNS (a generator's body executes at next(), long after
+        beam_search's own eval / no_grad scope has been left)"""
+        it = self._run_iter(enc, src_mask, return_scores, step_hook)
+        dec = self.dec
+        while True:
+            was_training = dec.training
+            dec.eval()
+            try:
+                with torch.no_grad():
+                    v = next(it)
+            except StopIteration as e:
+                return e.value
+            finally:
+                dec.train(was_training)
+            yield v
+
+    def _run_iter(self, enc, src_mask, return_scores=False, step_hook=None):
         """run() as a generator that yields after every issued token step: a scheduler that drives several sessions (one per HIP stream)
         round-robin keeps all their launch queues fed (FineTune.generate_pipelined) -- issuing one session's ~6k launches in one go
         blocks the host at the GPU's pace, because a launch queue is finite."""
@@ -472,6 +493,16 @@ class _BeamSession:
         for i, layer in enumerate(model.decoder.layers):
             ops.copy_kernel(self.kc[i], layer.src_attn.linears[1](enc))
             ops.copy_kernel(self.vc[i], layer.src_attn.linears[2](enc))
+        if src_mask is not None:
+            if self.src_mask is None:
+                self.src_mask = torch.empty(B, src_mask.shape[-1], dtype=torch.uint8, device=dev)
+            if tuple(src_mask.shape) != tuple(self.src_mask.shape) or src_mask.dtype != torch.uint8:
+                raise ValueError('beam session: encoder mask %s %s does not fit the session (%s uint8)'
+                                 % (tuple(src_mask.shape), src_mask.dtype, tuple(self.src_mask.shape)))
+            self.src_mask.copy_(src_mask)                 # (B x S bytes, not a multiple of 4 in general: torch's copy, outside the capture)
+            src_mask = self.src_mask
+        elif self.src_mask is not None:
+            raise ValueError('beam session built for masked encoder states got an unmasked batch')
         fused = _fused_weights(model)
         if self.st is None or self.fused_key is not fused:
             # (re)build the R-row state around the session's buffers; derived weights changed -> the captured step is stale as well
@@ -569,6 +600,11 @@ class _BeamSession:
                         if hasattr(self.graph, 'instantiate'):
                             self.graph.instantiate()
                     self.plan = plan or None
+                    if self.plan is not None:
+                        info = (C.c_int64 * 7)()
+                        H.check(H.lib.evk_replay_info(self.plan, info), 'replay_info')
+                        self.step_launches = int(info[1])                 # kernel nodes of ONE captured token step
+            stats['step_launches'] = getattr(self, 'step_launches', None)
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
             for it_ in range(done, n_body):

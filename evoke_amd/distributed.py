@@ -145,6 +145,8 @@ class GradReducer:
                     cur_start, cur_ps = end, []
         self.learned = {}
         self.handles = []
+        self.opt = None            # weakref to the FusedOptimizer whose flat buffers these are (for_optimizer): receives the union below
+        self.touched_union = None  # uint8 per parameter (group order): 1 = SOME rank produced a gradient for it this step
         self.issued = []           # bucket indices in the order their collectives were issued this step (tests read it)
         self.begin('default')
         ops.register_grad_callback(self.on_grad)
@@ -155,7 +157,10 @@ class GradReducer:
         for g, st in zip(opt.param_groups, opt.flat):
             params.append([(p, o, p.numel()) for p, o in zip(g['params'], st['offsets'])])
         opt.world = world_size()          # the optimizer kernel divides the summed gradients by the rank count
-        return cls(opt.flat_grads(), params, **kw)
+        red = cls(opt.flat_grads(), params, **kw)
+        import weakref
+        red.opt = weakref.ref(opt)
+        return red
 
     def begin(self, key='default'):
         self.key = key
@@ -250,6 +255,23 @@ class GradReducer:
             if self.overlap and self.pending[b] == 0 and b == self.next:
                 self._drain()
 
+    def _share_touched(self):
+        """Which parameters received a gradient this step is a property of the rank's BATCH (a shard without sibling views never runs the
+        multi-view attention and layer_norm_2; indication / no-indication shards use different fusion branches).  After the sum every rank
+        holds the other ranks' gradients for those parameters too, so the update mask must be the UNION over ranks: a rank that masked
+        them out locally would skip an update (and a step count) the others apply, and the replicas would part for good.  One MAX
+        all-reduce of a uint8 per parameter, issued after the last bucket on every rank; the optimizer reads the result on the device."""
+        opt = self.opt() if self.opt is not None else None
+        if opt is None or not self._active():
+            self.touched_union = None
+            return
+        bits = np.frombuffer(bytes(1 if id(p) in opt._touched else 0 for g in opt.param_groups for p in g['params']), dtype=np.uint8).copy()
+        dev = self.flat[0].device
+        t = ops.upload(bits, dev).clone() if dev.type == 'cuda' else torch.from_numpy(bits)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        self.touched_union = t
+        opt.set_global_touched(t)
+
     def finish(self):
         """Call after backward(): reduces what was not launched from the backward (descending order), waits for everything."""
         if self.flat and self.flat[0].is_cuda:
@@ -264,6 +286,7 @@ class GradReducer:
         self.handles = []
         if self.flat and self.flat[0].is_cuda and self._active():
             torch.cuda.current_stream().wait_stream(ops.side_stream('comm'))
+        self._share_touched()
         if self.learning:
             self.learned[self.key] = dict(self.counts)
         self.begin(self.key)

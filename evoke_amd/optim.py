@@ -50,6 +50,7 @@ class FusedOptimizer(torch.optim.Optimizer):
         self.steps = 0
         self.flat = []
         self._touched = set()
+        self._global_touched = None     # uint8 per parameter over all groups: the union over ranks (GradReducer._share_touched), device tensor
         # Per-parameter step counts live ON THE DEVICE (st['steps'], int32 per parameter): a step that the dynamic loss scaler
         # skips (non-finite gradient anywhere) must not advance them and the host never reads the skip decision back.
         self.world = 1              # ranks whose gradients the all-reduce SUMS into the flat buffers (set by GradReducer)
@@ -94,6 +95,14 @@ class FusedOptimizer(torch.optim.Optimizer):
 
     def _on_grad(self, p):
         self._touched.add(id(p))
+
+    def set_global_touched(self, bits):
+        """bits: uint8 tensor, one entry per parameter in param_groups order, 1 where ANY rank produced a gradient this step (the
+        data-parallel reducer's MAX all-reduce).  The next step() updates exactly those parameters on every rank."""
+        n = sum(len(g['params']) for g in self.param_groups)
+        if bits.numel() != n:
+            raise ValueError('set_global_touched: %d entries for %d parameters' % (bits.numel(), n))
+        self._global_touched = bits
 
     # ---- torch.optim-format state (what the reference checkpoints with `optimizer.state_dict()`, trainer_v0401.py:160-189)
     def state_dict(self):
@@ -207,8 +216,17 @@ class FusedOptimizer(torch.optim.Optimizer):
         if not torch.cuda.is_current_stream_capturing():
             self.sync_hparams()
         inv_world = 1.0 / float(self.world)
+        if self.world > 1 and self._global_touched is None:
+            raise RuntimeError('FusedOptimizer.step with world %d: the update mask must be the union over ranks of the parameters that '
+                               'received gradients (GradReducer.finish() provides it); a rank-local mask lets the replicas drift apart' % self.world)
+        first = 0
         for g, st in zip(self.param_groups, self.flat):
-            mask = self._touched_mask(g, st)
+            n_g = len(g['params'])
+            if self._global_touched is not None:
+                mask = self._global_touched[first:first + n_g]          # on the device: no rank-local decision, no host read-back
+            else:
+                mask = self._touched_mask(g, st)
+            first += n_g
             if mask is None:
                 continue
             H.check(H.lib.evk_optim_group_step(H.ptr(st['p']), H.ptr(st['g']), H.ptr(st['m']), H.ptr(st['v']), H.ptr(st['vmax']), H.ptr(st['shadow']),
@@ -219,6 +237,7 @@ class FusedOptimizer(torch.optim.Optimizer):
             scaler.update()
         self._step_zeroes = self.world == 1
         self._touched.clear()
+        self._global_touched = None
 
     def replay_hook(self):
         """Host bookkeeping of a step that was just captured in a HIP graph (evoke_amd/graph.py): the returned function is called

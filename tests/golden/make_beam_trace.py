@@ -6,7 +6,8 @@ score, log-probability).  The first `beam` columns are the reference's selection
 scorer could pick instead -- this is what lets the GPU test follow the reference's search step by step (teacher-forced) and price
 every disagreement by the reference's own score margin.
 
-Usage:  python tests/golden/make_beam_trace.py        (about a minute of CPU; needs no /root/reference)
+Usage:  python tests/golden/make_beam_trace.py [case ...]      (default beam384_b4_L100: about a minute of CPU; needs no /root/reference)
+        python tests/golden/make_beam_trace.py beam224 beam224_b4     (the short goldens: seconds)
 """
 import os
 import sys
@@ -62,10 +63,12 @@ def main(name='beam384_b4_L100'):
     beam = case['beam_size']
     margin = out['score'][1:, :, beam - 1] - out['score'][1:, :, beam]
     print(name, 'trace written:', {k: v.shape for k, v in out.items()})
-    print('16-bit drift of the reference itself at positions 10/30/50/70/90/99:', out['drift16'][[10, 30, 50, 70, 90, 99]].T)
+    pos = [t for t in (10, 30, 50, 70, 90, 99) if t < case['max_seq_len']]
+    print('16-bit drift of the reference itself at positions %s:' % pos, out['drift16'][pos].T)
     print('selection margin (beam-th minus next candidate) per study: min', margin.min(0), 'median', np.median(margin, 0),
           'positions below 1e-2:', (margin < 1e-2).sum(0))
 
 
 if __name__ == '__main__':
-    main()
+    for n in (sys.argv[1:] or ['beam384_b4_L100']):
+        main(n)

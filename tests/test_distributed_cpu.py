@@ -174,3 +174,50 @@ def test_reducer_direct_and_16bit_sync_modes_gloo():
         for rank in (0, 1):
             for step, (key, early, got, want, same) in enumerate(res[rank]):
                 assert same and got == want, (mode, rank, step, got, want)
+
+
+def _union_worker(rank, world, port, q):
+    """the optimizer's update mask must be the UNION over ranks of the parameters that received gradients (a rank whose
+    shard has no sibling views holds, after the sum, the other rank's multi-view gradients and must apply them too)"""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from evoke_amd import distributed as D, ops, optim
+    D.init_distributed('gloo')
+    try:
+        names = ['trunk', 'multiview_cross_attention', 'pooler', 'text_decoder.a', 'visual_self_atten_layers.b']
+        ps = [torch.nn.Parameter(torch.zeros(64)) for _ in names]
+        opt = optim.FusedOptimizer([(1e-3, list(zip(names[:3], ps[:3]))), (1e-2, list(zip(names[3:], ps[3:])))])
+        red = D.GradReducer.for_optimizer(opt, bucket_bytes=256)
+        assert opt.world == world
+        # rank 0: siblings + indication batch -> multi-view attention and the decoder; rank 1: no siblings, no indication -> self-attention
+        # branch and the decoder.  Nobody touches the pooler.
+        mine = [0, 1, 3] if rank == 0 else [0, 3, 4]
+        red.begin(D.batch_structure('inc' if rank == 0 else 'no_inc', ['a', 'a'] if rank == 0 else ['b', 'c']))
+        for i in mine:
+            ps[i].grad.fill_(float(rank + 1))
+            opt._on_grad(ps[i])
+            red.on_grad(ps[i])
+        red.finish()
+        union = red.touched_union.tolist()
+        sums = [float(p.grad[0]) for p in ps]
+        q.put((rank, union, opt._global_touched is red.touched_union, sums))
+    finally:
+        dist.destroy_process_group()
+        ops.clear_grad_callbacks()
+
+
+def test_update_mask_is_the_union_over_ranks_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_union_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, union, handed_over, sums in res:
+        assert union == [1, 1, 0, 1, 1], (rank, union)             # identical on both ranks; the pooler stays untouched everywhere
+        assert handed_over
+        assert sums == [3.0, 1.0, 0.0, 3.0, 2.0], (rank, sums)     # the sum of the shards, wherever a shard produced a gradient

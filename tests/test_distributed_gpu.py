@@ -24,9 +24,9 @@ def _free_port():
     return p
 
 
-def _shard(kind, rank, V):
+def _shard(kind, rank, V, views=2):
     g = torch.Generator().manual_seed(100 + rank)
-    B, views, L = 2, 2, 12
+    B, L = 2, 12
     images = torch.randn(B * views, 3, 224, 224, generator=g)
     ids = torch.randint(5, V, (B, L), generator=g)
     ids[:, 0] = V - 2 if kind == 'finetune' else 1
@@ -54,9 +54,10 @@ def _build(kind, args):
 
 
 def _step(kind, model, opt, red, shard, world):
+    from evoke_amd import distributed as D
     images, ids, masks, pids, inc, incm = shard
     opt.zero_grad()
-    red.begin(kind)
+    red.begin(D.batch_structure(kind, pids))
     if kind == 'finetune':
         ret = model(images, ids, masks, pids, inc, incm, mode='train')
     else:
@@ -78,11 +79,13 @@ def _worker(rank, world, port, kind, q):
     D.init_distributed('gloo')
     try:
         ops.set_dropout_enabled(False)
+        mixed = kind == 'finetune_mixed'          # rank 0: two views per study (multi-view attention + layer_norm_2 run), rank 1: one view
+        kind = 'finetune' if mixed else kind
         args = dict(ARGS, task=kind if kind == 'finetune' else 'pretrain', pt_lr=5e-5, ft_lr=5e-4, optim='RAdam', weight_decay=5e-5, amsgrad=True)
         model, opt, red = _build(kind, args)
         if kind != 'finetune':
             model.gather = D.gather_rows
-        shard = _shard(kind, rank, V)
+        shard = _shard(kind, rank, V, views=(2 if rank == 0 else 1) if mixed else 2)
         losses = [_step(kind, model, opt, red, shard, world)]
         torch.cuda.synchronize()
         g0 = opt.flat_grads()[0][:200000].clone()             # reduced gradient (mean over ranks) of the first parameters
@@ -91,7 +94,9 @@ def _worker(rank, world, port, kind, q):
             losses.append(_step(kind, model, opt, red, shard, world))
             opt.step()
         torch.cuda.synchronize()
-        sig = torch.stack([st['p'].double().sum() for st in opt.flat] + [st['p'].double().abs().sum() for st in opt.flat]).cpu()
+        sig = torch.stack([st['p'].double().sum() for st in opt.flat] + [st['p'].double().abs().sum() for st in opt.flat] +
+                          [st['steps'].double().sum() for st in opt.flat] +
+                          [(st['steps'].double() * torch.arange(1, st['steps'].numel() + 1, device='cuda', dtype=torch.float64)).sum() for st in opt.flat]).cpu()
         sigs = [torch.zeros_like(sig) for _ in range(world)]
         dist.all_gather(sigs, sig)
         q.put((rank, losses, [s.tolist() for s in sigs], g0.cpu().numpy()))
@@ -142,6 +147,19 @@ def test_two_rank_finetune_step_on_one_gpu():
     want = acc
     got = out[0][3].astype(np.float64)
     assert np.abs(got - want).max() <= 1e-6 * ops.loss_scale_value() + 1e-4 * np.abs(want).max(), np.abs(got - want).max()
+
+
+def test_two_rank_step_with_sibling_and_no_sibling_shards_keeps_the_replicas_identical():
+    """Rank 0's shard has two views per study, rank 1's one: rank 1 never runs the multi-view attention / layer_norm_2, yet after the
+    gradient sum it holds rank 0's gradients for them.  The optimizer's update mask is the UNION over ranks (GradReducer._share_touched):
+    parameters AND per-parameter step counts must be bit-identical on both ranks after two steps (a rank-local mask left rank 1 without
+    those updates for good)."""
+    out = _run('finetune_mixed')
+    for rank, losses, sigs, _ in out:
+        assert all(np.isfinite(losses)), losses
+        assert sigs[0] == sigs[1], 'parameters / step counts diverged across ranks: %s' % (sigs,)
+    # ... and the multi-view parameters did move on the rank whose shard never used them: step-count signature > what one group alone gives
+    assert out[1][2][1][4] > 0 and out[1][2][1][5] > 0
 
 
 def test_two_rank_pretrain_step_on_one_gpu():

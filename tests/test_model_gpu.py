@@ -190,15 +190,21 @@ def test_trunk_follows_bf16_emulation(train):
     assert e_ref <= 1.3 * emu_vs_ref + 1e-2
 
 
+LOGP_TOL = 8e-3 if F16 else 6e-2          # flat, at every position: |engine log-probability - reference| in the default decode mode (f32 relational memory)
+
+
 @pytest.mark.parametrize('name', [n for n, c in CASES.items() if c['kind'] == 'beam' and c['max_seq_len'] <= 40])
 def test_beam_search_matches_reference(name):
-    """Incremental device-side beam search vs the reference's full re-decode.  Default (fp16-storage) build: the token ids
-    must be IDENTICAL to the reference's on every sample.  bf16-storage build only: a bf16 logit can flip a near-tie, so
-    there the assertion falls back to the score of the returned beam (re-scored by the fp32 oracle)."""
+    """FineTune.forward(mode='inference') end to end (incremental device-side beam search vs the reference's full re-decode) on the
+    short goldens.  The engine's log-probabilities carry <= LOGP_TOL of 16-bit noise (asserted position by position in
+    test_beam_search_follows_the_reference_decisions), and the reference's OWN margin between the last selected and the first rejected
+    candidate is below that at several of these goldens' decisions (tests/golden/<name>_trace.npz: down to 5e-4 / 1.6e-3), so a study's
+    token ids must be IDENTICAL to the reference's whenever every decision of that study was taken with a margin >= 2 x LOGP_TOL; for the
+    others a different report is accepted only if the fp32 oracle scores it within 2 % of the reference's (teacher forced)."""
     from evoke_amd import ops
     from evoke_amd.model_pretrain_finetune import FineTune
     from oracle import beam as OB, functional as O, spec as S
-    case, gold = CASES[name], _gold(name)
+    case, gold, tr = CASES[name], _gold(name), _gold(name + '_trace')
     inp = make_inputs(case, V)
     args = dict(ARGS, max_seq_len=case['max_seq_len'], beam_size=case['beam_size'])
     tok = load_tokenizer()
@@ -211,15 +217,21 @@ def test_beam_search_matches_reference(name):
     seq = seq.cpu()
     want = torch.from_numpy(gold['eval/seq'])
     same = (seq == want).all(dim=1)
-    print('\n[%s] identical sequences: %d / %d' % (name, int(same.sum()), len(same)))
+    beam = case['beam_size']
+    min_margin = (tr['score'][:, :, beam - 1] - tr['score'][:, :, beam]).min(0)            # per study, over all decisions
+    final_margin = tr['score'][-1, :, 0] - tr['score'][-1, :, 1]                            # ... and the choice of the returned beam
+    decisive = np.minimum(min_margin, final_margin) >= 2 * LOGP_TOL
+    print('\n[%s] identical sequences: %d / %d; smallest reference margin per study %s (final ranking %s)' % (
+        name, int(same.sum()), len(same), np.round(min_margin, 5), np.round(final_margin, 5)))
     print('   hip', seq.tolist())
     print('   ref', want.tolist())
     assert seq.shape == want.shape and seq.dtype == torch.long
     assert texts == tok.decode_batch(seq.tolist()) or all(len(t) > 0 for t in texts)
-    if F16:
-        assert torch.equal(seq, want), 'beam search token ids differ from the reference'
+    for b in range(len(same)):
+        if decisive[b]:
+            assert bool(same[b]), 'study %d: every reference decision had a margin >= %g, yet the ids differ' % (b, 2 * LOGP_TOL)
     if not bool(same.all()):
-        # score both sequences with the fp32 oracle (teacher forced): the engine's choice must be within bf16 noise of the reference's
+        # score both sequences with the fp32 oracle (teacher forced): the engine's choice must be as good as the reference's
         P = S.procedural_state(S.finetune_spec(V))
         cfg = dict(O.DEFAULT_CFG, max_seq_len=case['max_seq_len'], beam_size=case['beam_size'])
         with torch.no_grad():
@@ -242,36 +254,53 @@ def test_beam_search_matches_reference(name):
             s_h, s_r = score(seq), score(want)
         print('   oracle score of hip seq', s_h, ' of ref seq', s_r)
         for a, b in zip(s_h, s_r):
-            assert a >= b - 0.05 * max(1.0, abs(b)), (a, b)
+            assert a >= b - (0.02 if F16 else 0.05) * max(1.0, abs(b)), (a, b)
 
 
-@pytest.mark.parametrize('rm_f32', [False, True])
-def test_beam_search_at_100_positions_follows_the_reference_decisions(rm_f32):
-    """BASELINE config 5 at its real decode length (384^2, two views, beam 4, max_seq_len 100) against the imported reference's token
-    ids (tests/golden/beam384_b4_L100.npz) and the decision trace the oracle wrote after reproducing those ids bit for bit
-    (tests/golden/beam384_b4_L100_trace.npz: the 12 best candidates per position and study, with the reference's running scores).
+BEAM_TRACED = [n for n, c in CASES.items() if c['kind'] == 'beam' and os.path.exists(os.path.join(GOLDEN, n + '_trace.npz'))]
+
+
+@pytest.mark.parametrize('name', BEAM_TRACED)
+def test_beam_search_follows_the_reference_decisions(name):
+    """Every beam golden -- BASELINE config 5 at its real decode length (384^2, two views, beam 4, max_seq_len 100) and the short 224^2
+    cases -- against the imported reference's token ids (tests/golden/<name>.npz) and the decision trace the oracle wrote after
+    reproducing those ids bit for bit (tests/golden/<name>_trace.npz: the best candidates per position and study, with the reference's
+    running scores), in the engine's DEFAULT decode mode (relational memory in f32, csrc/rm_f32.hip).
 
     An untrained network never emits [EOS] and its candidates lie close together: the reference's OWN margin between the last selected
-    and the first rejected candidate falls below 1e-2 at 9 / 15 of the 100 positions of the two studies (minimum 3.4e-3 / 2.6e-4), which
-    no 16-bit engine can resolve.  So the test pins the search the way it can be pinned exactly:
+    and the first rejected candidate falls below 1e-2 at 9 / 15 of the 100 positions of the two config-5 studies (minimum 3.4e-3 /
+    2.6e-4), which no engine with 16-bit operands can resolve.  So the test pins the search the way it can be pinned exactly:
       1. TEACHER-FORCED: the engine's beam search runs its product path (graph-replayed step, evk_beam_step bookkeeping) while a hook
-         replaces every step's log-probabilities by the reference's selection, so that at all 100 positions the engine holds exactly
-         the reference's hypotheses.  At every position the engine's log-probabilities of the 12 traced candidates must agree with the
-         reference's (<= LOGP_TOL), the engine's own top-beam set must equal the reference's wherever the reference's margin exceeds
-         2 x LOGP_TOL, and the forced search must return the reference's ids exactly (bookkeeping, cache row tables, memory re-order).
+         replaces every step's log-probabilities by the reference's selection, so that at all positions the engine holds exactly
+         the reference's hypotheses.  At EVERY position the engine's log-probabilities of the traced candidates must agree with the
+         reference's to the FLAT tolerance LOGP_TOL = 8e-3 (measured <= 5.3e-3), the engine's own top-beam set must equal the reference's
+         wherever the reference's margin exceeds 2 x LOGP_TOL and at all but two positions of each study in any case, and the forced
+         search must return the reference's ids exactly (bookkeeping, cache row tables, memory re-order).
       2. FREE-RUNNING: the ids must be identical to the reference's up to the first position whose margin is below 2 x LOGP_TOL, and
-         the first divergent decision must be between candidates the reference scored within 2 x LOGP_TOL of each other.
-    rm_f32 = True runs the same test with the relational memory of the decode step in f32 (EVK_DECODE_RM_F32, csrc/rm_f32.hip): the
-    recurrence no longer drifts, so the tolerance is FLAT -- 8e-3 at every one of the 100 positions (measured <= 5.3e-3; the 16-bit
-    recurrence reaches 0.5) -- and the engine's own top-4 set must equal the reference's at >= 98 of the 100 positions of each study."""
+         the first divergent decision must be between candidates the reference scored within 2 x LOGP_TOL of each other."""
     from evoke_amd import decode
     from evoke_amd.model_pretrain_finetune import FineTune
     from oracle import spec as S
-    name = 'beam384_b4_L100'
-    saved_rm = decode._RM_F32[0]
-    decode._RM_F32[0] = bool(rm_f32)
+    assert decode._RM_F32[0], 'the default decode mode carries the relational memory in f32'
     try:
-        _beam100(decode, FineTune, S, name, rm_f32)
+        _beam100(decode, FineTune, S, name, True)
+    finally:
+        decode._SESSIONS.clear()
+
+
+def test_beam_search_16bit_recurrence_stays_within_the_reference_16bit_drift():
+    """The opt-in 16-bit relational-memory recurrence (EVK_DECODE_RM_F32=0; the default until round 3) on the 100-position golden: its
+    log-probabilities drift with depth (0.5 nats at position 90) and are only held to four times what the REFERENCE's own arithmetic
+    moves by on 16-bit operands (tests/golden/make_beam_trace.py::drift16).  Kept so that the mode stays correct; it is not the product
+    default and no parity claim rests on it."""
+    from evoke_amd import decode
+    from evoke_amd.model_pretrain_finetune import FineTune
+    from oracle import spec as S
+    saved_rm = decode._RM_F32[0]
+    decode._RM_F32[0] = False
+    decode._SESSIONS.clear()
+    try:
+        _beam100(decode, FineTune, S, 'beam384_b4_L100', False)
     finally:
         decode._RM_F32[0] = saved_rm
         decode._SESSIONS.clear()
@@ -294,8 +323,8 @@ def _beam100(decode, FineTune, S, name, rm_f32):
     # operands (tests/golden/make_beam_trace.py::drift16: 4e-3 at position 10, 0.2 - 0.45 at position 99 -- the relational memory is
     # an expanding recurrence on these weights), never below 5e-3 (4e-2 in the bf16 build)
     tol = 4.0 * np.maximum.accumulate(tr['drift16'], axis=0) * (1.0 if F16 else 8.0) + (5e-3 if F16 else 4e-2)
-    if rm_f32 and F16:
-        tol = np.full_like(tol, 8e-3)
+    if rm_f32:
+        tol = np.full_like(tol, LOGP_TOL)
     rec = {'err': [], 'same': []}
 
     def forced(t, logp, beam_sum):
@@ -342,7 +371,7 @@ def _beam100(decode, FineTune, S, name, rm_f32):
     if os.environ.get('EVK_TEST_DUMP'):
         np.savez(os.path.join(os.environ['EVK_TEST_DUMP'], 'beam_forced.npz'), err=err, same=same, margin=margin, seq_forced=seq_forced.cpu().numpy(),
                  seq_free=seq_free.cpu().numpy(), first=np.array(state['first']))
-    pos = [10, 30, 50, 70, 90, 99]
+    pos = [t for t in (10, 30, 50, 70, 90, 99) if t < T] or [T - 1]
     print('\n[%s] teacher-forced |logp - reference| (max over the 12 traced candidates) at positions %s:\n   engine    %s\n   tolerance %s\n'
           '   largest error / tolerance ratio %.2f; own top-%d set equals the reference at %s of %d positions'
           % (name, pos, np.array2string(err[pos].T, precision=4), np.array2string(tol[pos].T, precision=4), float((err / tol).max()), beam,
@@ -351,7 +380,7 @@ def _beam100(decode, FineTune, S, name, rm_f32):
     bad = ~same & (margin > 2 * tol)
     assert not bad.any(), 'the engine selects another beam set where the reference margin is %s' % margin[bad]
     if rm_f32 and F16:
-        assert (same.sum(0) >= 98).all(), same.sum(0)
+        assert (same.sum(0) >= T - 2).all(), same.sum(0)
     assert torch.equal(seq_forced.cpu(), want), 'forced search does not return the reference ids: bookkeeping / state re-order differ'
     np.testing.assert_allclose(p_forced.cpu().numpy(), tr['best_p'], atol=2e-2, rtol=0)
     assert torch.equal(seq_free, seq_plain), 'a read-only hook changed the search'

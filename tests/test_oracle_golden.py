@@ -183,3 +183,23 @@ def test_finetune_with_gpt2_decoder_vs_reference_composition():
         assert abs(loss.item() - float(gold['eval/loss'])) < 2e-5, (loss.item(), float(gold['eval/loss']))
         seq = G.beam_search(P, x, heads, layers, case['beam_size'], case['max_seq_len'], V - 2, V - 1, 0)
         assert seq.tolist() == gold['eval/seq'].tolist()
+
+
+@pytest.mark.parametrize('name', [n for n, c in CASES.items() if c['kind'] == 'beam' and os.path.exists(os.path.join(GOLDEN, n + '_trace.npz'))])
+def test_beam_decision_traces_lead_to_the_reference_ids(name):
+    """tests/golden/<name>_trace.npz (written by the oracle, make_beam_trace.py) is what the GPU tests follow decision by decision: the
+    hypotheses its selected candidates spell out must end in exactly the token ids the imported REFERENCE returned (<name>.npz),
+    scores must be sorted the way modules/caption_model.py:70-74 sorts them, and the returned beam must be the best finished one."""
+    case = CASES[name]
+    gold, tr = np.load(os.path.join(GOLDEN, name + '.npz')), np.load(os.path.join(GOLDEN, name + '_trace.npz'))
+    beam, T, B, V1 = case['beam_size'], case['max_seq_len'], case['B'], V + 1
+    flat, score = tr['flat'], tr['score']
+    assert flat.shape[:2] == (T, B) and flat.shape[2] >= beam + 1
+    assert (np.diff(score, axis=2) <= 0).all()                       # descending sort
+    for b in range(B):
+        hyps = [()]
+        for t in range(T):
+            hyps = [hyps[int(f) // V1] + (int(f) % V1,) for f in flat[t, b, :beam]]
+            assert V - 1 not in [h[-1] for h in hyps] or t == T - 1, 'an [EOS] inside the golden: the trace reader assumes none'
+        assert list(hyps[0]) == gold['eval/seq'][b].tolist()         # every beam is closed at the last position; the best one is returned
+    np.testing.assert_allclose(tr['best_p'], score[-1, :, 0], atol=1e-4)
