@@ -391,7 +391,7 @@ def main():
     def step_eager():
         ops.advance_seed_epoch()
         opt.zero_grad()
-        red.begin(kind)
+        red.begin(D.batch_structure(kind, batch['pids']))       # the structure key the trainer uses: ragged per-rank batches (config 4) differ in it
         if kind == 'finetune':
             ret = model(batch['images'], batch['ids'], batch['masks'], batch['pids'], batch['inc'], batch['inc_masks'], mode='train')
         else:
@@ -491,7 +491,8 @@ def main():
         'vs_baseline': None, 'dtype': H.STORE, 'data': 'synthetic',
         'config': {'workload': 'EVOKE-%d %s-view %s train step (fwd+bwd+allreduce+clip+RAdam), %d studies (%d images) per GPU, '
                                'L=%d, Li=%d, V=%d, random-init weights' % (a.res, a.views, kind, a.batch, int(batch['images'].shape[0]), L, Li, V),
-                   'parallelism': 'dp%d' % world, 'loss_last': float(losses[-1].item()),
+                   'parallelism': 'dp%d' % world, 'rccl_ranks': D.world_size(), 'grad_sync': red.mode if world > 1 else 'none (1 rank)',
+                   'loss_last': float(losses[-1].item()),
                    'host_launch_ms_per_step': host_issue_ms, 'host_loop_ms_per_step': 1e3 * host_dt / a.steps,
                    'step_graph': bool(use_graph and getattr(step, 'graph', None) is not None),
                    'step_replay_plan': getattr(step, 'info', None)},

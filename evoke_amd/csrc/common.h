@@ -91,6 +91,12 @@ struct ProfScope {
 // gemm.hip: C[z][m][n] += sum over `splitk` f32 slabs [z][split][M][N] (z = zo * bi + zi -> C + zo * sCo + zi * sCi + m * ldc + n), N % 4 == 0
 int evk_splitk_reduce_launch(const float* slab, float* C, long mn, int M, int N, int splitk, int bi, long ldc, long sCo, long sCi, int batch, hipStream_t s);
 
+// gemm_tn.hip: C[M][N] (+)= A[k][m]^T B[k][n] (both operands K-strided: weight gradients), deep-pipelined 128 x 128 tiles; K-slices leave
+// as f32 slabs [batch][nsplit][M][N] (summed by evk_splitk_reduce_launch) or, with one slice and slab == null, are added to C directly
+bool evk_gemm_tn_supported(int M, int N, int K, long lda, long ldb, long ldc, long sAo, long sAi, long sBo, long sBi, long sCo, long sCi);
+int evk_gemm_tn_launch(const void* A, const void* B, float* C, float* slab, int M, int N, int K, long lda, long ldb, long ldc, int nsplit,
+                       int steps_per_split, int batch, int bi, long sAo, long sAi, long sBo, long sBi, long sCo, long sCi, hipStream_t s);
+
 static inline int ilog2_exact(int64_t v) {
   int l = 0;
   while ((int64_t(1) << l) < v) ++l;

@@ -219,6 +219,27 @@ __global__ __launch_bounds__(256) void grad_nonfinite_kernel(const float* __rest
   if (__any(bad) && (threadIdx.x & 63) == 0) state[2] = 1.f;
 }
 
+// forward-overflow guard of the fp16-storage build: count[0] += number of 8-element groups of a 16-bit activation tensor that hold an inf / NaN
+// (exponent all ones: 0x7c00 in fp16, 0x7f80 in bf16).  The loss scale protects the backward only; a forward activation beyond +-65504
+// (e.g. an eval-mode network whose BN running statistics are untrained) is not repairable and must be reported.
+__global__ __launch_bounds__(256) void act_nonfinite_kernel(const bf16_t* __restrict__ x, long n, int* __restrict__ count) {
+#ifdef EVK_STORE_BF16
+  const unsigned m = 0x7f807f80u;
+#else
+  const unsigned m = 0x7c007c00u;
+#endif
+  const unsigned lo = m & 0xffffu, hi = m & 0xffff0000u;
+  const long n8 = n >> 3;
+  bool bad = false;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const uint4 t = reinterpret_cast<const uint4*>(x)[i];
+    bad |= ((t.x & lo) == lo) | ((t.x & hi) == hi) | ((t.y & lo) == lo) | ((t.y & hi) == hi) | ((t.z & lo) == lo) | ((t.z & hi) == hi) |
+           ((t.w & lo) == lo) | ((t.w & hi) == hi);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) bad |= ((unsigned)reinterpret_cast<const unsigned short*>(x)[(n8 << 3) + threadIdx.x] & lo) == lo;
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicAdd(count, 1);
+}
+
 __global__ void loss_scale_update_kernel(float* __restrict__ state, float growth, float backoff, int interval, float lo, float hi) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   if (state[2] != 0.f) {
@@ -613,6 +634,14 @@ int evk_grad_nonfinite(const float* g, int64_t n, float* scale_state, evk_stream
   ProfScope ps(EVK_FAM_OPTIM, s);
   hipLaunchKernelGGL(grad_nonfinite_kernel, dim3(ew_blocks(n / 4 + 1)), dim3(256), 0, s, g, (long)n, scale_state);
   return evk_check_launch("grad_nonfinite");
+}
+
+int evk_act_nonfinite(const void* x, int64_t n, int32_t* count, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(x && n > 0 && count && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "act_nonfinite: bad args (16-byte aligned 16-bit tensor)");
+  ProfScope ps(EVK_FAM_ELTWISE, s);
+  hipLaunchKernelGGL(act_nonfinite_kernel, dim3(ew_blocks(n / 8 + 1)), dim3(256), 0, s, (const bf16_t*)x, (long)n, count);
+  return evk_check_launch("act_nonfinite");
 }
 
 int evk_grads_multi(const void* chunk_table, int32_t n_chunks, int32_t mode, float* scale_state, evk_stream_t stream) {

@@ -1134,6 +1134,20 @@ int launch_modes(GemmP& p, int batch, int splitk_req, void* ws, long ws_bytes, c
   p.group_m = group_m >= 0 ? group_m : (big ? 4 : 8);
   dim3 grid(tilesM * p.tilesN, splitk, batch);
   int rc;
+  if constexpr (AMODE == EVK_A_KSTR && BMODE == EVK_B_KSTR) {
+    // weight gradients of the pointwise convolutions and the linear layers: the deep-pipelined kernel of gemm_tn.hip (same tile, same
+    // K-slicing and slab layout as the launch below, 72 KB of loads in flight per CU instead of 32)
+    if (p.accumulate && p.c_f32 && p.alpha == 1.f && !narrow && d->b_klog <= 0 && d->b_tapstride == 0 && (p.slab || splitk == 1) &&
+        evk_gemm_tn_supported(p.M, p.N, p.K, p.lda, p.ldb, p.ldc, p.sAo, p.sAi, p.sBo, p.sBi, p.sCo, p.sCi)) {
+      rc = evk_gemm_tn_launch(p.A, p.B, reinterpret_cast<float*>(p.C), p.slab, p.M, p.N, p.K, p.lda, p.ldb, p.ldc, splitk, p.ksteps_per_split, batch,
+                              p.bi, p.sAo, p.sAi, p.sBo, p.sBi, p.sCo, p.sCi, s);
+      if (rc == EVK_OK && p.slab) {
+        SkrP r{p.slab, reinterpret_cast<float*>(p.C), p.slab_mn, p.M, p.N, splitk, p.bi, p.ldc, p.sCo, p.sCi};
+        rc = launch_splitk_reduce(r, batch, s);
+      }
+      return rc;
+    }
+  }
   if constexpr (AMODE == EVK_A_PLAIN && BMODE == EVK_B_PLAIN) {
     rc = narrow ? launch_cfg<4, 1, AMODE, BMODE>(p, grid, s)
                 : (big ? launch_cfg_sb<4, 4, AMODE, BMODE, false>(p, grid, s) : launch_cfg<2, 2, AMODE, BMODE>(p, grid, s));

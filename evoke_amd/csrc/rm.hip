@@ -12,6 +12,14 @@
 #include <stdlib.h>
 #include "common.h"
 
+// csrc/rm_f32.hip
+int rmf32_gemm(const float* A, long lda, const float* W, const float* bias, const float* resid, long ldr, float* C, long ldc, int M, int N, int act,
+               int a_tanh, bf16_t* C16, long ldc16, hipStream_t s);
+int rmf32_attn_train(const float* qkv, const float* xp, long x_bstride, float* a, bf16_t* a16, float* P, float p_drop, unsigned long long seed, int B,
+                     hipStream_t s);
+int rmf32_gate_train(const float* xp, long x_bstride, const float* gu, const float* nm1, const float* h2, float* m, bf16_t* m16_next, bf16_t* tm16_next,
+                     bf16_t* out, long out_bstride, bf16_t* si, bf16_t* sf, bf16_t* tnm, int B, hipStream_t s);
+
 namespace {
 
 __device__ __forceinline__ uint32_t hash32(uint64_t x) {
@@ -693,6 +701,63 @@ int evk_rm_forward(const void* xk, const void* xv, const void* gw, const void* m
   if (m_last)
     if (int e = evk_cast(w.m + (long)L * RD, EVK_BF16, m_last, EVK_BF16, RD, stream)) return e;
   return evk_check_launch("rm_forward");
+}
+
+/* evk_rm_forward with the RECURRENCE IN F32 (the default of the training / teacher-forced forward since round 4).  On the weights the parity
+ * fixtures use the memory is an expanding recurrence: with 16-bit operands and a 16-bit carried state the teacher-forced log-probabilities of
+ * the training pass drift from the reference's by 0.2-0.3 nats at positions 60-100 of a 100-token report (tests/test_model_gpu.py::
+ * test_training_forward_log_probabilities_per_position), exactly as generation did.  Here everything that feeds back into the memory is
+ * f32 -- the token embeddings x32 (B, L, 512), their three projections (one f32 product with the stacked MASTER weights Wx32 = [attn.linears.1;
+ * attn.linears.2; W], 2048 x 512), the memory, the six f32 master matrices, every intermediate (csrc/rm_f32.hip: v_mfma_f32_16x16x4_f32) -- and
+ * 16-bit copies of the intermediates land in the SAME workspace layout as evk_rm_forward's, so evk_rm_backward (16-bit BPTT) runs unchanged.
+ *   m0 (B, 3, 512) 16-bit initial memory; out (B, L, 1536) 16-bit memories for the conditional layer norms; ws: evk_rm_ws_bytes;
+ *   ws32: evk_rm_f32_ws_bytes(B, L) bytes of f32 scratch. */
+int64_t evk_rm_f32_ws_bytes(int32_t B, int32_t L) {
+  const long R = (long)B * S_;
+  return ((long)B * L * 2048 + R * D_ + R * 1536 + 4 * R * D_ + R * 2 * D_ + 1024) * 4;
+}
+
+int evk_rm_forward_f32(const float* x32, const float* Wx32, const float* bx, const void* m0, const float* Wqkv32, const float* bqkv, const float* Wo32,
+                       const float* bo, const float* W032, const float* b0, const float* W232, const float* b2, const float* U32, const float* bU,
+                       void* out, void* m_last, void* ws, int64_t ws_bytes, void* ws32, int64_t ws32_bytes, int32_t B, int32_t L, float p_drop,
+                       uint64_t seed, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(x32 && Wx32 && bx && m0 && Wqkv32 && bqkv && Wo32 && bo && W032 && b0 && W232 && b2 && U32 && bU && out && ws && ws32 && B > 0 && L > 0,
+              "rm_forward_f32: null/empty argument");
+  EVK_REQUIRE(ws_bytes >= evk_rm_ws_bytes(B, L) && ws32_bytes >= evk_rm_f32_ws_bytes(B, L), "rm_forward_f32: workspace too small");
+  EVK_REQUIRE(((reinterpret_cast<uintptr_t>(x32) | reinterpret_cast<uintptr_t>(Wx32) | reinterpret_cast<uintptr_t>(Wqkv32) | reinterpret_cast<uintptr_t>(Wo32) |
+                reinterpret_cast<uintptr_t>(W032) | reinterpret_cast<uintptr_t>(W232) | reinterpret_cast<uintptr_t>(U32) | reinterpret_cast<uintptr_t>(ws32)) & 15) == 0,
+              "rm_forward_f32: 16-byte aligned buffers");
+  Ws w = carve(ws, B, L);
+  const long R = w.R, RD = R * D_;
+  float* fp = reinterpret_cast<float*>(ws32);
+  auto take = [&](long n) { float* r = fp; fp += (n + 63) / 64 * 64; return r; };
+  float* xp = take((long)B * L * 2048);            // keys | values | gates of every token, f32
+  float* mem = take(RD);
+  float* qkv = take(R * 1536);
+  float* a = take(RD); float* nm1 = take(RD); float* h1 = take(RD); float* h2 = take(RD);
+  float* gu = take(R * 2 * D_);
+  ProfScope ps(EVK_FAM_GEMM, s);
+  if (int e = rmf32_gemm(x32, D_, Wx32, bx, nullptr, 0, xp, 2048, B * L, 2048, EVK_ACT_NONE, 0, nullptr, 0, s)) return e;
+  if (int e = evk_cast(m0, EVK_BF16, mem, EVK_F32, RD, stream)) return e;
+  if (int e = evk_cast(m0, EVK_BF16, w.m, EVK_BF16, RD, stream)) return e;
+  if (int e = evk_act_fwd(w.m, w.tm, RD, EVK_ACT_TANH, stream)) return e;
+  const long xrow = (long)L * 2048;                 // sample stride of xp
+  for (int t = 0; t < L; ++t) {
+    const float* xt = xp + (long)t * 2048;
+    if (int e = rmf32_gemm(mem, D_, Wqkv32, bqkv, nullptr, 0, qkv, 1536, (int)R, 1536, EVK_ACT_NONE, 0, w.qkv + (long)t * R * 1536, 1536, s)) return e;
+    if (int e = rmf32_attn_train(qkv, xt, xrow, a, w.a + t * RD, w.P + (long)t * B * HEADS * S_ * KEYS, p_drop,
+                                 (unsigned long long)(seed + 0x51ED27ULL * (uint64_t)(t + 1)), B, s)) return e;
+    if (int e = rmf32_gemm(a, D_, Wo32, bo, mem, D_, nm1, D_, (int)R, D_, EVK_ACT_NONE, 0, w.nm1 + t * RD, D_, s)) return e;
+    if (int e = rmf32_gemm(nm1, D_, W032, b0, nullptr, 0, h1, D_, (int)R, D_, EVK_ACT_RELU, 0, w.h1 + t * RD, D_, s)) return e;
+    if (int e = rmf32_gemm(h1, D_, W232, b2, nullptr, 0, h2, D_, (int)R, D_, EVK_ACT_RELU, 0, w.h2 + t * RD, D_, s)) return e;
+    if (int e = rmf32_gemm(mem, D_, U32, bU, nullptr, 0, gu, 2 * D_, (int)R, 2 * D_, EVK_ACT_NONE, 1, nullptr, 0, s)) return e;      // U tanh(m)
+    if (int e = rmf32_gate_train(xt, xrow, gu, nm1, h2, mem, w.m + (t + 1) * RD, w.tm + (t + 1) * RD, (bf16_t*)out + (long)t * S_ * D_, (long)L * S_ * D_,
+                                 w.si + t * RD, w.sf + t * RD, w.tnm + t * RD, B, s)) return e;
+  }
+  if (m_last)
+    if (int e = evk_cast(w.m + (long)L * RD, EVK_BF16, m_last, EVK_BF16, RD, stream)) return e;
+  return evk_check_launch("rm_forward_f32");
 }
 
 /* ONE generated token of the relational memory for R hypotheses (RelationalMemory.forward_step, modules/encoder_decoder.py:274-291, as

@@ -19,7 +19,7 @@ namespace {
 constexpr int S3 = 3, KEYS4 = 4, HEADS8 = 8, DH64 = 64, D512 = 512;
 constexpr int TM = 32, TN = 32, KP = 512, LDK = KP + 4;      // + 4 floats: rows 16 bytes apart in the banks
 
-struct GemmF { const float* A; const float* W; const float* bias; const float* resid; float* C; int M, N; long lda, ldc, ldr; int act, a_tanh; };
+struct GemmF { const float* A; const float* W; const float* bias; const float* resid; float* C; int M, N; long lda, ldc, ldr; int act, a_tanh; bf16_t* C16; long ldc16; };
 
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -64,11 +64,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF p) {
     if (p.act == EVK_ACT_RELU) v = fmaxf(v, 0.f);
     if (p.resid) v += p.resid[(long)m * p.ldr + col];
     p.C[(long)m * p.ldc + col] = v;
+    if (p.C16) p.C16[(long)m * p.ldc16 + col] = f2bf(v);          // what the 16-bit backward of the training recurrence reads
   }
 }
 
 int gemm_f32(const float* A, long lda, const float* W, const float* bias, const float* resid, long ldr, float* C, long ldc, int M, int N, int act,
-             int a_tanh, hipStream_t s) {
+             int a_tanh, hipStream_t s, bf16_t* C16 = nullptr, long ldc16 = 0) {
   EVK_REQUIRE(N % TN == 0 && M > 0, "rm f32 gemm: N must be a multiple of 32");
   static bool attr_done = false;
   constexpr int LDS = 2 * TM * LDK * 4;
@@ -76,7 +77,7 @@ int gemm_f32(const float* A, long lda, const float* W, const float* bias, const 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_done = true;
   }
-  GemmF p{A, W, bias, resid, C, M, N, lda, ldc, ldr, act, a_tanh};
+  GemmF p{A, W, bias, resid, C, M, N, lda, ldc, ldr, act, a_tanh, C16, ldc16};
   hipLaunchKernelGGL(gemm_f32_kernel, dim3(N / TN, (M + TM - 1) / TM), dim3(256), LDS, s, p);
   return evk_check_launch("rm f32 gemm");
 }
@@ -131,7 +132,97 @@ __global__ __launch_bounds__(256) void rm_gate_f32_kernel(const float* __restric
   }
 }
 
+// ---- the TRAINING recurrence in f32 (RelationalMemory.forward, modules/encoder_decoder.py:293-300): same arithmetic as above plus what
+// the 16-bit BPTT of rm.hip reads back -- attention probabilities, dropout (the stateless hash of rm.hip: forward and backward draw the
+// same mask), 16-bit copies of every saved intermediate.
+__device__ __forceinline__ uint32_t hash32f(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+  return (uint32_t)x;
+}
+__device__ __forceinline__ float keep_scale_f(uint64_t seed, uint64_t idx, float p) {          // == rm.hip keep_scale
+  if (p <= 0.f) return 1.f;
+  return (hash32f(seed * 0x9E3779B97F4A7C15ULL + idx) >> 8) * (1.f / 16777216.f) >= p ? 1.f / (1.f - p) : 0.f;
+}
+
+struct AttT { const float* qkv; const float* xp; long x_bstride; float* a; bf16_t* a16; float* P; float p_drop; unsigned long long seed; const unsigned long long* epoch; };
+__global__ __launch_bounds__(256) void rm_attn_f32_train_kernel(const AttT p) {
+  const int b = blockIdx.x, h = threadIdx.x >> 5, l = threadIdx.x & 31;
+  const int c = h * DH64 + 2 * l;
+  float q[S3][2], k[KEYS4][2], v[KEYS4][2];
+#pragma unroll
+  for (int i = 0; i < S3; ++i) {
+    const float* r = p.qkv + (long)(b * S3 + i) * 1536 + c;
+    q[i][0] = r[0]; q[i][1] = r[1]; k[i][0] = r[512]; k[i][1] = r[513]; v[i][0] = r[1024]; v[i][1] = r[1025];
+  }
+  const float* x = p.xp + (long)b * p.x_bstride + c;
+  k[3][0] = x[0]; k[3][1] = x[1]; v[3][0] = x[512]; v[3][1] = x[513];
+  const unsigned long long seed = evk_mix_seed(p.seed, p.epoch);
+#pragma unroll
+  for (int i = 0; i < S3; ++i) {
+    float s[KEYS4], mx = -INFINITY, sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < KEYS4; ++j) { s[j] = half_sum32(q[i][0] * k[j][0] + q[i][1] * k[j][1]) * 0.125f; mx = fmaxf(mx, s[j]); }
+#pragma unroll
+    for (int j = 0; j < KEYS4; ++j) { s[j] = expf(s[j] - mx); sum += s[j]; }
+    float o0 = 0.f, o1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < KEYS4; ++j) {
+      const float pr = s[j] / sum;
+      if (l == 0 && p.P) p.P[((long)(b * HEADS8 + h) * S3 + i) * KEYS4 + j] = pr;
+      const float w = pr * keep_scale_f(seed, ((uint64_t)(b * HEADS8 + h) * S3 + i) * KEYS4 + j, p.p_drop);
+      o0 += w * v[j][0]; o1 += w * v[j][1];
+    }
+    const long o = (long)(b * S3 + i) * D512 + c;
+    p.a[o] = o0; p.a[o + 1] = o1;
+    *reinterpret_cast<uint32_t*>(p.a16 + o) = pack2bf(o0, o1);
+  }
+}
+
+struct GateT {
+  const float* xp; long x_bstride; const float* gu; const float* nm1; const float* h2; float* m;
+  bf16_t* m16_next; bf16_t* tm16_next; bf16_t* out; long out_bstride; bf16_t* si; bf16_t* sf; bf16_t* tnm; int B;
+};
+__global__ __launch_bounds__(256) void rm_gate_f32_train_kernel(const GateT p) {
+  const long total = (long)p.B * S3 * D512;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % D512);
+    const long bs = i / D512;
+    const long b = bs / S3;
+    const int sl = (int)(bs - b * S3);
+    const float ig = p.xp[b * p.x_bstride + 1024 + c] + p.gu[bs * 1024 + c];
+    const float fg = p.xp[b * p.x_bstride + 1536 + c] + p.gu[bs * 1024 + 512 + c];
+    const float si = 1.f / (1.f + expf(-ig)), sf = 1.f / (1.f + expf(-fg));
+    const float t = tanhf(p.nm1[i] + p.h2[i]);
+    const float nx = si * t + sf * p.m[i];
+    p.m[i] = nx;                                        // the carried state stays in f32
+    const bf16_t n16 = f2bf(nx);
+    p.m16_next[i] = n16;
+    p.tm16_next[i] = f2bf(tanhf(nx));
+    p.out[b * p.out_bstride + sl * D512 + c] = n16;
+    p.si[i] = f2bf(si); p.sf[i] = f2bf(sf); p.tnm[i] = f2bf(t);
+  }
+}
+
 }  // namespace
+
+// launchers used by rm.hip's evk_rm_forward_f32 (which owns the workspace layout the 16-bit backward reads)
+int rmf32_gemm(const float* A, long lda, const float* W, const float* bias, const float* resid, long ldr, float* C, long ldc, int M, int N, int act,
+               int a_tanh, bf16_t* C16, long ldc16, hipStream_t s) {
+  return gemm_f32(A, lda, W, bias, resid, ldr, C, ldc, M, N, act, a_tanh, s, C16, ldc16);
+}
+int rmf32_attn_train(const float* qkv, const float* xp, long x_bstride, float* a, bf16_t* a16, float* P, float p_drop, unsigned long long seed, int B,
+                     hipStream_t s) {
+  AttT p{qkv, xp, x_bstride, a, a16, P, p_drop, seed, evk_seed_epoch_ptr()};
+  hipLaunchKernelGGL(rm_attn_f32_train_kernel, dim3(B), dim3(256), 0, s, p);
+  return evk_check_launch("rm f32 attention (train)");
+}
+int rmf32_gate_train(const float* xp, long x_bstride, const float* gu, const float* nm1, const float* h2, float* m, bf16_t* m16_next, bf16_t* tm16_next,
+                     bf16_t* out, long out_bstride, bf16_t* si, bf16_t* sf, bf16_t* tnm, int B, hipStream_t s) {
+  GateT p{xp, x_bstride, gu, nm1, h2, m, m16_next, tm16_next, out, out_bstride, si, sf, tnm, B};
+  const long total = (long)B * S3 * D512;
+  hipLaunchKernelGGL(rm_gate_f32_train_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
+  return evk_check_launch("rm f32 gate (train)");
+}
 
 extern "C" {
 

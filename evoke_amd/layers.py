@@ -565,11 +565,14 @@ class PositionalEncodingP(nn.Module):
         self.register_buffer('pe', pe.unsqueeze(0))
 
 
+RM_F32 = [os.environ.get('EVK_RM_F32', '1') != '0']          # relational-memory recurrence of whole sequences in f32 (csrc/rm.hip: evk_rm_forward_f32)
+
+
 class _RMRecurrence(torch.autograd.Function):
     """The token recurrence of RelationalMemory.forward as ONE native call each way (evk_rm_forward / evk_rm_backward)."""
 
     @staticmethod
-    def forward(ctx, xk, xv, gw, m0, rm, p_drop, seed):
+    def forward(ctx, xk, xv, gw, m0, rm, p_drop, seed, emb32=None):
         B, L, d = xk.shape
         dev = xk.device
         lin = rm.attn.linears
@@ -588,10 +591,24 @@ class _RMRecurrence(torch.autograd.Function):
         ws = torch.empty(nb, dtype=torch.uint8, device=dev)
         out = torch.empty(B, L, rm.num_slots * d, dtype=BF16, device=dev)
         m_last = torch.empty(B, rm.num_slots, d, dtype=BF16, device=dev)
-        H.check(H.lib.evk_rm_forward(H.ptr(xk), H.ptr(xv), H.ptr(gw), H.ptr(m0), H.ptr(wqkv), H.ptr(bqkv), H.ptr(ops.shadow(lin[3].weight)),
-                                     H.ptr(lin[3].bias), H.ptr(ops.shadow(rm.mlp[0].weight)), H.ptr(rm.mlp[0].bias),
-                                     H.ptr(ops.shadow(rm.mlp[2].weight)), H.ptr(rm.mlp[2].bias), H.ptr(ops.shadow(rm.U.weight)),
-                                     H.ptr(rm.U.bias), H.ptr(out), H.ptr(m_last), H.ptr(ws), nb, B, L, p_drop, seed, H.stream()), 'rm_forward')
+        if emb32 is not None:
+            # the recurrence in f32 (csrc/rm.hip: evk_rm_forward_f32): token embeddings, their projections, the memory and the MASTER weights
+            # all stay f32; xk / xv / gw (16-bit, computed by the caller with autograd) only carry the gradients back
+            f32 = lambda p_: p_.detach() if p_.dtype == F32 and p_.is_contiguous() else p_.detach().float().contiguous()      # noqa: E731
+            wx32 = torch.cat([f32(lin[1].weight), f32(lin[2].weight), f32(rm.W.weight)], 0)
+            bx = torch.cat([lin[1].bias.detach(), lin[2].bias.detach(), rm.W.bias.detach()], 0).float().contiguous()
+            wqkv32 = torch.cat([f32(lin[i].weight) for i in range(3)], 0)
+            nb32 = H.lib.evk_rm_f32_ws_bytes(B, L)
+            ws32 = torch.empty(nb32, dtype=torch.uint8, device=dev)
+            H.check(H.lib.evk_rm_forward_f32(H.ptr(emb32), H.ptr(wx32), H.ptr(bx), H.ptr(m0), H.ptr(wqkv32), H.ptr(bqkv), H.ptr(f32(lin[3].weight)),
+                                             H.ptr(lin[3].bias), H.ptr(f32(rm.mlp[0].weight)), H.ptr(rm.mlp[0].bias), H.ptr(f32(rm.mlp[2].weight)),
+                                             H.ptr(rm.mlp[2].bias), H.ptr(f32(rm.U.weight)), H.ptr(rm.U.bias), H.ptr(out), H.ptr(m_last), H.ptr(ws), nb,
+                                             H.ptr(ws32), nb32, B, L, p_drop, seed, H.stream()), 'rm_forward_f32')
+        else:
+            H.check(H.lib.evk_rm_forward(H.ptr(xk), H.ptr(xv), H.ptr(gw), H.ptr(m0), H.ptr(wqkv), H.ptr(bqkv), H.ptr(ops.shadow(lin[3].weight)),
+                                         H.ptr(lin[3].bias), H.ptr(ops.shadow(rm.mlp[0].weight)), H.ptr(rm.mlp[0].bias),
+                                         H.ptr(ops.shadow(rm.mlp[2].weight)), H.ptr(rm.mlp[2].bias), H.ptr(ops.shadow(rm.U.weight)),
+                                         H.ptr(rm.U.bias), H.ptr(out), H.ptr(m_last), H.ptr(ws), nb, B, L, p_drop, seed, H.stream()), 'rm_forward')
         ctx.save_for_backward(xk, xv, wqkv, ws)
         ctx.rm, ctx.cfg = rm, (B, L, d, p_drop, seed, nb)
         ctx.mark_non_differentiable(m_last)
@@ -625,7 +642,7 @@ class _RMRecurrence(torch.autograd.Function):
         for p in (lin[0], lin[1], lin[2], lin[3], rm.mlp[0], rm.mlp[2], rm.U):
             ops.grad_done(p.weight)
             ops.grad_done(p.bias)
-        return dxk, dxv, dgw, None, None, None, None
+        return dxk, dxv, dgw, None, None, None, None, None
 
 
 class RelationalMemory(nn.Module):
@@ -648,12 +665,21 @@ class RelationalMemory(nn.Module):
         return eye.unsqueeze(0).expand(batch_size, -1, -1).contiguous()
 
     def run(self, emb, m0):
-        """emb (B, L, d), m0 (B, slots, d) -> (memories (B, L, slots*d), last memory (B, slots, d))."""
+        """emb (B, L, d), m0 (B, slots, d) -> (memories (B, L, slots*d), last memory (B, slots, d)).
+        Whole sequences (the training / teacher-forced forward) carry the recurrence in f32 (RM_F32, default on; EVK_RM_F32=0 selects the
+        16-bit recurrence of rounds 1-3, which drifts from the reference by 0.2-0.3 nats at positions 60-100 of a 100-token report): the
+        unrounded token embeddings ride on `emb` as emb.evk_f32 (Transformer.embed), or are taken from the 16-bit ones."""
         xk = self.attn.linears[1](emb)
         xv = self.attn.linears[2](emb)
         gw = self.W(emb)
         p = self.attn.p if (self.training and ops.DROPOUT_ENABLED[0]) else 0.0
-        return _RMRecurrence.apply(xk, xv, gw, m0.contiguous(), self, float(p), ops.next_seed() if p > 0 else 0)
+        emb32 = None
+        if RM_F32[0] and emb.shape[1] > 1:
+            emb32 = getattr(emb, 'evk_f32', None)
+            if emb32 is None or emb32.shape != emb.shape:
+                emb32 = emb.detach().float()
+            emb32 = emb32.contiguous()
+        return _RMRecurrence.apply(xk, xv, gw, m0.contiguous(), self, float(p), ops.next_seed() if p > 0 else 0, emb32)
 
     def forward(self, emb):
         return self.run(emb, self.init_memory(emb.shape[0], emb.device))[0]
@@ -673,9 +699,16 @@ class Transformer(nn.Module):
                 nn.init.xavier_uniform_(prm)
 
     def embed(self, ids):
-        x = ops.embedding(ids.contiguous(), self.tgt_embed[0].lut.weight, pos=self.tgt_embed[1].pe[0],
-                          scale=math.sqrt(self.d_model))
-        return ops.dropout(x, self.p, self.training)
+        ids = ids.contiguous()
+        drop = self.p > 0 and self.training and ops.DROPOUT_ENABLED[0]
+        # the unrounded embeddings for the f32 relational memory (a second output of the same launch); with an active embedding dropout the
+        # recurrence falls back to the dropped 16-bit rows (config/finetune_config.yaml: dropout 0.0)
+        e32 = torch.empty(*ids.shape, self.d_model, dtype=F32, device=ids.device) if (RM_F32[0] and ids.is_cuda and ids.shape[-1] > 1 and not drop) else None
+        x = ops.embedding(ids, self.tgt_embed[0].lut.weight, pos=self.tgt_embed[1].pe[0], scale=math.sqrt(self.d_model), out32=e32)
+        x = ops.dropout(x, self.p, self.training)
+        if e32 is not None:
+            x.evk_f32 = e32
+        return x
 
     def decode(self, enc, src_mask, ids, tgt_key_mask):
         emb = self.embed(ids)

@@ -259,8 +259,10 @@ def global_alignment(global_image_embed, global_text_embed, patient_ids, temp, g
     v, t = global_image_embed.to(F32), global_text_embed.to(F32)
     pid = np.asarray(patient_ids)[:v.shape[0]]
     if gather is not None:
-        v, _ = gather(v, pid)
-        t, pid = gather(t, pid)
+        # image and text globals of the SAME studies: one exchange of [v | t] rows (one id exchange + one row all-gather instead of two each)
+        d = v.shape[1]
+        vt, pid = gather(torch.cat([v, t], 1), pid)
+        v, t = vt[:, :d].contiguous(), vt[:, d:].contiguous()
     labels = _same_study(pid)
     labels = labels / labels.sum(1, keepdims=True)
     tg = ops.upload(labels, v.device)

@@ -34,6 +34,7 @@ class _Base(nn.Module):
 
     def visual_forward_mimic_cxr(self, images):
         att_feats, fc_feats = self.visual_extractor(images)
+        ops.guard_finite(att_feats, 'the visual extractor output (ResNet-101 patch features)')      # fp16 storage: forward range guard
         return fc_feats, att_feats
 
     @staticmethod
@@ -103,6 +104,7 @@ class FineTune(_Base):
             return self.text_decoder(encoder_hidden_states, encoder_attention_mask, input_ids, attention_mask, stage='train')
         output = self.text_decoder(encoder_hidden_states, encoder_attention_mask, stage='test')
         gen_texts = self.tokenizer.decode_batch(output.cpu().tolist())
+        ops.check_forward_guard(output.device, block=True)
         gt_texts = self.tokenizer.decode_batch(input_ids.cpu().tolist())
         if mode == 'sample':
             return [[t if len(t) > 0 else NO_FINDING for t in gen_texts], gt_texts]
@@ -153,6 +155,7 @@ class FineTune(_Base):
         from .decode import beam_search
         output = beam_search(self.text_decoder, encoder_hidden_states, encoder_attention_mask, self.args)
         gen_texts = self.tokenizer.decode_batch(output.cpu().tolist())
+        ops.check_forward_guard(output.device, block=True)          # (the .cpu() above has synchronised: the verdict is there)
         gt_texts = self.tokenizer.decode_batch(input_ids.cpu().tolist())
         if mode == 'sample':
             return [[t if len(t) > 0 else NO_FINDING for t in gen_texts], gt_texts]
@@ -189,6 +192,13 @@ class FineTune(_Base):
 
         def encode(batch):
             images, report_ids, report_masks, patient_ids, inc_ids, inc_masks = batch
+            # the batch was produced on the CALLER's stream (a loader's `.to(device, non_blocking=True)`, a pre-processing kernel) after
+            # this generator started: the encoder stream must wait for that work, batch by batch, and the caching allocator must know that
+            # enc_s reads these blocks -- or a block the caller drops is handed to the next upload while the ResNet still reads it
+            enc_s.wait_stream(torch.cuda.current_stream())
+            for t in (images, report_ids, report_masks, inc_ids, inc_masks):
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(enc_s)
             with torch.cuda.stream(enc_s):
                 x, enc_mask = self.encoder_states(images, patient_ids, report_ids.shape[0], inc_ids, inc_masks)
                 ev = torch.cuda.Event()
@@ -225,6 +235,7 @@ class FineTune(_Base):
             seq, report_ids = job[3], job[2]
             with torch.cuda.stream(dec_s[job[0]]):
                 ids = seq.cpu()                      # waits for that decode stream only
+            ops.check_forward_guard(seq.device)      # verdicts of the encoder passes that have finished
             gen_texts = self.tokenizer.decode_batch(ids.tolist())
             gen_texts = [t if len(t) > 0 else NO_FINDING for t in gen_texts]
             if mode == 'sample':

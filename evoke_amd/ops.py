@@ -156,14 +156,102 @@ def _unowned_backward_begin(owner, device):
     if old:
         _grads_multi(old, 2, scaler)
 
+    # Mixed ownership: when a live FusedOptimizer holds OTHER parameters of this model, the step's overflow verdict and the scale
+    # update belong to ITS step() -- it scans its flat buffers, divides by state[0] and then updates.  Updating here as well would clear
+    # the overflow flag (or move the scale) before that division: owned gradients unscaled by the wrong factor, an overflow unseen,
+    # update() twice per step.  So this callback only unscales / zeroes and leaves state[1:] alone in that case.
+    mixed = any(grads_owned(p) for p in owner.parameters() if p.requires_grad)
+
     def finish():
         join_side_streams()
         grads = [p.grad for p in params if p.grad is not None and p.grad.is_cuda]
         if grads:
             _grads_multi(grads, 0, scaler)
             _grads_multi(grads, 1, scaler)
-        scaler.update()
+        if not mixed:
+            scaler.update()
     torch.autograd.Variable._execution_engine.queue_callback(finish)
+
+
+def overflow_steps(device=None):
+    """How many backward passes / optimizer steps so far hit a non-finite gradient (host sync; 0 without a scaler).  Semantics for
+    gradients NO FusedOptimizer owns (the reference's own step: backward -> clip_grad_value_ -> torch.optim step): on overflow they
+    are ZEROED and the scale is halved -- the torch optimizer that follows still runs, i.e. it applies weight decay and momentum with
+    a zero gradient and advances its step count (torch.cuda.amp.GradScaler would skip optimizer.step() instead).  A caller that wants the
+    GradScaler behaviour compares this counter before and after backward() and skips its optimizer.step() when it moved."""
+    sc = loss_scaler(device)
+    return sc.skipped() if sc is not None else 0
+
+
+# ----------------------------------------------------------------------------------------------------
+# forward-overflow guard (fp16 storage)
+# ----------------------------------------------------------------------------------------------------
+FWD_GUARD = [H.STORE == 'f16' and os.environ.get('EVK_FWD_GUARD', '1') != '0']
+_guards = {}          # device index -> {'slots': int32[K] device counters, 'host': pinned int32[K], 'next': i, 'pending': [(slot, event, what)]}
+_GUARD_SLOTS = 16
+
+
+class ForwardOverflow(RuntimeError):
+    pass
+
+
+def _guard_state(dev):
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    g = _guards.get(key)
+    if g is None:
+        g = _guards[key] = dict(slots=torch.zeros(_GUARD_SLOTS, dtype=torch.int32, device=dev),
+                                host=torch.zeros(_GUARD_SLOTS, dtype=torch.int32).pin_memory(), next=0, pending=[])
+    return g
+
+
+def guard_finite(t, what):
+    """fp16 storage only: scan the 16-bit activation tensor `t` (the trunk output) for inf / NaN WITHOUT stalling the pipeline -- one scan
+    launch, one 4-byte copy into pinned memory and an event; the verdict is read by check_forward_guard() once the event has passed (at
+    the next guarded forward, at every optimizer step, and -- blocking -- wherever the host synchronises anyway: generation results,
+    trainer read-backs).  A forward activation beyond fp16's +-65504 cannot be repaired by the loss scale (that guards the backward)."""
+    if not FWD_GUARD[0] or not t.is_cuda or t.dtype != BF16 or torch.cuda.is_current_stream_capturing():
+        return
+    check_forward_guard(t.device)
+    g = _guard_state(t.device)
+    if len(g['pending']) >= _GUARD_SLOTS - 1:
+        check_forward_guard(t.device, block=True)
+    i = g['next']
+    g['next'] = (i + 1) % _GUARD_SLOTS
+    cnt = g['slots'][i:i + 1]
+    cnt.zero_()
+    x = t if t.is_contiguous() else t.contiguous()
+    H.check(H.lib.evk_act_nonfinite(H.ptr(x), x.numel(), H.ptr(cnt), H.stream()), 'act_nonfinite')
+    g['host'][i:i + 1].copy_(cnt, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    g['pending'].append((i, ev, what))
+
+
+def check_forward_guard(device=None, block=False):
+    """Raise ForwardOverflow if a guarded forward tensor held inf / NaN.  block=False only looks at scans the GPU has already finished."""
+    if not FWD_GUARD[0] or not _guards:
+        return
+    keys = list(_guards) if device is None else [torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()]
+    for key in keys:
+        g = _guards.get(key)
+        if g is None:
+            continue
+        keep, bad = [], None
+        for i, ev, what in g['pending']:
+            if block:
+                ev.synchronize()
+            if block or ev.query():
+                if int(g['host'][i]) != 0 and bad is None:
+                    bad = what
+            else:
+                keep.append((i, ev, what))
+        g['pending'] = keep
+        if bad is not None:
+            raise ForwardOverflow(
+                'evoke_amd: %s holds inf / NaN in the FORWARD pass of the fp16-storage build: an activation left fp16\'s range (+-65504).  The '
+                'dynamic loss scale protects the backward only.  Typical cause: batch-norm running statistics that were never trained (a freshly '
+                'initialised network in eval mode) or weights far from a trained checkpoint.  Run with EVK_STORE=bf16 (libevoke_hip_bf16.so: fp32\'s '
+                'exponent range, no loss scaling) or load trained weights.' % bad)
 
 
 # ----------------------------------------------------------------------------------------------------

@@ -208,6 +208,8 @@ class FusedOptimizer(torch.optim.Optimizer):
         if not on_gpu:
             raise RuntimeError('FusedOptimizer.step: the update runs in libevoke_hip.so; parameters must live on the GPU')
         ops.join_side_streams()
+        if not torch.cuda.is_current_stream_capturing():
+            ops.check_forward_guard(self.flat[0]['p'].device)          # (non-blocking: forward scans the GPU has already finished)
         scaler = ops.loss_scaler(self.flat[0]['p'].device)
         sstate = H.ptr(scaler.state) if scaler is not None else None
         if scaler is not None:

@@ -21,6 +21,7 @@ from math import inf
 import torch
 
 from . import distributed as D
+from . import ops
 
 
 def filter_state_for(model_state, loaded_state):
@@ -180,6 +181,7 @@ class Trainer:
         self.model.train()
         sums = {k: None for k in self.LOSS_KEYS}
         n = self._run(loader, sums, log_every, 'pretrain', epoch)
+        ops.check_forward_guard(block=True)          # fp16 storage: a forward activation that left the range is an error, not a NaN loss in a log
         return {'epoch': epoch, **{'train_' + k: (float(v) if v is not None else 0.0) / max(n, 1) for k, v in sums.items()}}
 
     def train_epoch_finetune(self, loader_inc, loader_not_inc, epoch=1, log_every=2000):
@@ -190,6 +192,7 @@ class Trainer:
         if loader_inc is not None:
             n += self._run(loader_inc, sums, log_every, 'indication', epoch)
         n += self._run(loader_not_inc, sums, log_every, 'no-indication', epoch)
+        ops.check_forward_guard(block=True)
         return {'train_loss': (float(sums['all_loss']) if sums['all_loss'] is not None else 0.0) / max(n, 1), 'epoch': epoch}
 
     @torch.no_grad()

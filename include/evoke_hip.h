@@ -517,6 +517,11 @@ int evk_optim_group_step(float* p, float* g, float* m, float* v, float* vmax, vo
 int evk_grad_nonfinite(const float* g, int64_t n, float* scale_state, evk_stream_t stream);
 int evk_loss_scale_update(float* scale_state, float growth, float backoff, int32_t interval, float min_scale, float max_scale,
                           evk_stream_t stream);
+/* Forward-overflow guard (no counterpart: the reference's forward is fp32, modules/visual_extractor.py:37-43 cannot overflow): *count +=
+ * the number of wave-level hits of inf / NaN in a 16-bit activation tensor (the trunk output).  fp16 storage has a range cliff at
+ * 65504 that the loss scale cannot repair in the FORWARD -- a network whose batch-norm running statistics are untrained, run in eval
+ * mode, reaches it; the host raises and names EVK_STORE=bf16 (evoke_amd/ops.py: guard_finite). */
+int evk_act_nonfinite(const void* x, int64_t n, int32_t* count, evk_stream_t stream);
 /* Gradients of a model whose parameters NO fused optimizer owns -- the reference's own step, modules/trainer_v0401.py:432-435
  * `loss.backward(); clip_grad_value_(model.parameters(), 0.1); optimizer.step()` with a torch.optim optimizer (modules/optimizers.py:
  * 27-46): the gradients must leave backward() UNSCALED.  chunk_table = device array of {float* g; int32 n; int32 pad} (one entry per
@@ -566,6 +571,14 @@ int evk_rm_backward(const void* dout, const void* xk, const void* xv, const void
                     const void* Ut, void* dxk, void* dxv, void* dgw, float* dWqkv, float* dbqkv, float* dWo, float* dbo, float* dW0,
                     float* db0, float* dW2, float* db2, float* dU, float* dbU, void* ws, int64_t ws_bytes, int32_t B, int32_t L,
                     float p_drop, uint64_t seed, evk_stream_t stream);
+/* evk_rm_forward with the recurrence carried in f32 (same reference lines; the training / teacher-forced default): x32 (B, L, 512) f32 token
+ * embeddings, Wx32 [2048][512] = [attn.linears.1; attn.linears.2; W] and the six f32 MASTER matrices; out / m_last / ws as evk_rm_forward (the
+ * 16-bit BPTT of evk_rm_backward reads the same workspace), ws32 = evk_rm_f32_ws_bytes(B, L) bytes of f32 scratch. */
+int64_t evk_rm_f32_ws_bytes(int32_t B, int32_t L);
+int evk_rm_forward_f32(const float* x32, const float* Wx32, const float* bx, const void* m0, const float* Wqkv32, const float* bqkv, const float* Wo32,
+                       const float* bo, const float* W032, const float* b0, const float* W232, const float* b2, const float* U32, const float* bU,
+                       void* out, void* m_last, void* ws, int64_t ws_bytes, void* ws32, int64_t ws32_bytes, int32_t B, int32_t L, float p_drop,
+                       uint64_t seed, evk_stream_t stream);
 
 #ifdef __cplusplus
 }

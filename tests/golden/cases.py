@@ -12,6 +12,10 @@ CASES = {
     'ft224_inc': dict(kind='finetune', res=224, pids=[0, 1, 2, 0, 2, 0], B=3, L=16, Li=12, modes=['eval', 'train']),
     'ft224_noinc': dict(kind='finetune', res=224, pids=[0, 1, 2, 0, 2, 0], B=3, L=16, Li=0, modes=['eval', 'train']),
     'ft384_inc': dict(kind='finetune', res=384, pids=[0, 1, 0], B=2, L=12, Li=8, modes=['eval', 'train']),
+    # the TRAINING forward at the real report length (config 3's L = 100): per-position log-probabilities of the teacher-forced pass
+    # (`logp` = the fixture also holds, per position, the target token's log-probability and those of PROBE_IDS) -- the relational memory is a
+    # 100-step recurrence in the training pass exactly as in generation (modules/encoder_decoder.py:293-300)
+    'ft384_L100': dict(kind='finetune', res=384, pids=[0, 1, 0, 1], B=2, L=100, Li=6, modes=['eval'], logp=True),
     'ft224_nomv': dict(kind='finetune', res=224, pids=[0, 1], B=2, L=10, Li=6, modes=['eval'], multiview=False),
     'pt224': dict(kind='pretrain', res=224, pids=[0, 1, 2, 0, 2, 0], B=3, L=10, Li=0, modes=['eval', 'train']),
     'pt224_nosib': dict(kind='pretrain', res=224, pids=[0, 1, 2], B=3, L=8, Li=0, modes=['eval']),
@@ -29,6 +33,9 @@ CASES = {
     # emits [EOS], so every hypothesis runs the full 100 positions: modules/caption_model.py:142-196, modules/att_model.py:98-137)
     'beam384_b4_L100': dict(kind='beam', res=384, pids=[0, 1, 0, 1], B=2, L=8, Li=6, modes=['eval'], max_seq_len=100, beam_size=4),
 }
+
+
+PROBE_IDS = [5, 6, 17, 250, 537, 603, 950, 1253, 1442, 1443, 1444, 0]      # vocabulary entries whose log-probability `logp` cases record at every position
 
 
 def _u(seed, n):

@@ -219,6 +219,12 @@ def run_case(name, case, tmp, tokenizer):
             out['%s/tap/vhead' % mode] = reduce_tensor(taps['vhead'])
             out['%s/tap/enc_states' % mode] = reduce_tensor(taps['fusion'][0])
             out['%s/tap/logp' % mode] = reduce_tensor(taps['logp'])
+            if case.get('logp'):
+                from tests.golden.cases import PROBE_IDS
+                lp = taps['logp'].detach().double()                                   # (B, L, V+1) log-probabilities of the teacher-forced pass
+                tgt = torch.cat([inp['ids'][:, 1:], torch.zeros(inp['ids'].shape[0], 1, dtype=torch.long)], 1)
+                out['%s/logp_target' % mode] = lp.gather(2, tgt.unsqueeze(-1)).squeeze(-1).numpy()      # position t predicts ids[:, t + 1]
+                out['%s/logp_probe' % mode] = lp[:, :, PROBE_IDS].numpy()
             ret['all_loss'].backward()
             g = dict(model.named_parameters())
             for k in GRAD_KEYS:

@@ -131,6 +131,43 @@ def test_gemm_tn_dw_accumulate(H, M, N, K):
     close(c, want, 2e-4, 3e-3 * K ** 0.5)
 
 
+@pytest.mark.parametrize('M,N,K,batch', [
+    (256, 1024, 9216, 1),        # layer3 conv1 / conv3 weight gradient (K = a quarter of bs 64 x 24 x 24): 16 tiles x 16 K-slices
+    (1024, 256, 4672, 1),        # ... the expanding one, K-slices with a ragged last step (4672 = 73 x 64)
+    (512, 2048, 1200, 1),        # layer4 shape, few steps per slice
+    (128, 128, 70, 1),           # one tile, two steps, the second with 6 rows of data
+    (128, 256, 40, 1),           # a single, partly filled step
+    (2048, 2048, 4640, 1),       # a head / fusion linear: 256 tiles, ONE K-slice -> the tile is added to C directly (no slabs)
+    (512, 512, 3200, 3),         # q | k | v of a transformer block as one batched product (batch strides on A, B and C)
+])
+def test_weight_gradient_kernel_tn(H, M, N, K, batch):
+    """csrc/gemm_tn.hip through evk_gemm_launch (A_KSTR x B_KSTR, accumulate): dW[z][M][N] += dY[z][K][M]^T . X[z][K][N] on the shapes of
+    the trunk's pointwise convolutions and of the linear layers, against fp32 CPU math on the same 16-bit
+    operands; C starts non-zero (accumulation), K tails are ragged, and the routed kernel must be the new one."""
+    import os
+    g = torch.Generator().manual_seed(31)
+    dy = (torch.randn(batch, K, M, generator=g)).to(STORE_DTYPE)
+    x = (torch.randn(batch, K, N, generator=g)).to(STORE_DTYPE)
+    c0 = torch.randn(batch, M, N, generator=g)
+    for forced_off in (False, True):
+        # second pass: the tile path of gemm.hip on the same problem (EVK_GEMM_TN is read once per process, so it is compared through the
+        # public switch of the router: a K-strided tap stride of 0 with b_klog = 0 is what selects the new kernel)
+        c = c0.clone().cuda()
+        dyd, xd = dy.cuda(), x.cuda()
+        d = base_desc(H, dyd, xd, c, M, N, K, a_mode=H.A_KSTR, b_mode=H.B_KSTR, lda=M, ldb=N, ldc=N)
+        d.accumulate = 1
+        d.batch_outer, d.batch_inner = batch, 1
+        d.sAo, d.sBo, d.sCo = K * M, K * N, M * N
+        if forced_off:
+            d.alpha = 1.0000001192092896        # any alpha != 1 keeps the launch on the tile path (alpha is applied there)
+        nb = H.lib.evk_gemm_workspace_bytes(C.byref(d))
+        ws = torch.empty(max(nb // 4, 1), dtype=torch.float32, device='cuda')
+        d.workspace, d.workspace_bytes = ws.data_ptr(), nb
+        H.gemm_launch(d)
+        want = c0 + torch.einsum('zkm,zkn->zmn', dy.float(), x.float())
+        close(c, want, 2e-4, 3e-3 * K ** 0.5)
+
+
 CONVS = [  # N, Hi, Wi, Ci, Co, KH, stride, pad
     (2, 12, 12, 64, 64, 3, 1, 1), (3, 14, 10, 128, 64, 3, 2, 1), (2, 8, 8, 256, 512, 1, 2, 0),
     (2, 9, 9, 64, 256, 1, 1, 0), (1, 24, 24, 256, 256, 3, 1, 1), (2, 7, 7, 512, 512, 3, 1, 1), (2, 11, 13, 256, 64, 1, 1, 0),

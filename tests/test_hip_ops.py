@@ -254,6 +254,41 @@ def test_embedding_and_nll():
     close(ops.log_softmax(lgd.detach(), Vn), F.log_softmax(lg[:, :Vn], -1), 1e-5, 1e-5, 'log_softmax')
 
 
+def test_embedding_ids_outside_the_table_never_touch_memory():
+    """C ABI: evk_embedding_fwd / evk_embedding_bwd with token ids outside [0, table_rows) -- negative, just past the end, 2^40 -- (a
+    corrupted batch, or a stale buffer read by a side stream: the GPU fault of round 3).  Documented behaviour (include/evoke_hip.h): such
+    rows are SKIPPED in both directions, the calls return 0 and nothing outside the output / the table gradient is read or written.  The
+    table gradient sits between two guard bands that must stay untouched."""
+    import ctypes as C
+    from evoke_amd import hip as H
+    Vv, D, R, L = 40, 64, 12, 4
+    table = rnd(Vv, D, seed=11).cuda()
+    pos = rnd(L, D, seed=12).cuda()
+    ids = torch.tensor([3, -1, Vv, 7, 1 << 40, Vv + 5, 0, -(1 << 33), Vv - 1, 5, -7, 2], dtype=torch.long)
+    ok = (ids >= 0) & (ids < Vv)
+    out = torch.full((R, D), 7.0, dtype=torch.float32, device='cuda')
+    H.check(H.lib.evk_embedding_fwd(H.ptr(table), H.ptr(ids.cuda()), H.ptr(pos), None, H.ptr(out), H.F32, R, D, L, C.c_float(2.0), Vv, None, None,
+                                    H.stream()), 'embedding_fwd')
+    want = pos.cpu()[torch.arange(R) % L].clone()
+    want[ok] += 2.0 * table.cpu()[ids[ok]]
+    torch.cuda.synchronize()
+    assert torch.allclose(out.cpu(), want, atol=1e-6), 'forward: rows with ids outside the table must hold the positional term only'
+    guard = 4096
+    buf = torch.full((guard + Vv * D + guard,), 123.0, dtype=torch.float32, device='cuda')
+    dtab = buf[guard:guard + Vv * D]
+    dtab.zero_()
+    dy = rnd(R, D, seed=13).cuda()
+    H.check(H.lib.evk_embedding_bwd(H.ptr(dy), H.F32, H.ptr(ids.cuda()), H.ptr(dtab), R, D, C.c_float(0.5), -100, Vv, H.stream()), 'embedding_bwd')
+    torch.cuda.synchronize()
+    ref = torch.zeros(Vv, D)
+    ref.index_add_(0, ids[ok], 0.5 * dy.cpu()[ok])
+    assert torch.allclose(dtab.cpu().view(Vv, D), ref, atol=1e-6)
+    assert bool((buf[:guard] == 123.0).all()) and bool((buf[guard + Vv * D:] == 123.0).all()), 'backward wrote outside the table gradient'
+    # and the malformed CALL (no table rows) is refused with an error code, not launched
+    rc = H.lib.evk_embedding_fwd(H.ptr(table), H.ptr(ids.cuda()), H.ptr(pos), None, H.ptr(out), H.F32, R, D, L, C.c_float(1.0), 0, None, None, H.stream())
+    assert rc != 0 and b'embedding_fwd' in H.lib.evk_last_error()
+
+
 def test_dropout_statistics_and_backward():
     from evoke_amd import ops
     x = torch.ones(1 << 16, dtype=BF).cuda().requires_grad_(True)

@@ -10,7 +10,7 @@ reference in fp32.  Tolerances of the DEFAULT build (fp16 storage, dynamic loss 
                  and cosine of the 61-sample vector >= 0.975 (measured <= 6.6e-2; 300 of 301 comparisons >= 0.99, the lowest 0.979):
                  a 16-bit forward flips a few ReLU gates per layer, so deep-network gradients are not point-wise reproducible
   train mode (BN batch statistics):
-     loss        |d| <= 2e-3        (measured 8e-5 .. 4.4e-4)
+     loss        |d| <= 1e-3        (measured 8e-5 .. 4.4e-4)
      BN running statistics vs the reference <= 2e-2
 The bf16-storage build of the same kernels (EVK_STORE=bf16) is run by the last test in a child interpreter with ITS tolerances:
 loss 5e-3 eval / 6e-2 train (bf16's 8-bit mantissa: a bias of the storage chain, amplified ~linearly in depth by train-mode BN on
@@ -29,7 +29,7 @@ pytestmark = pytest.mark.gpu
 
 F16 = os.environ.get('EVK_STORE', 'f16').lower() == 'f16'      # the default build
 LOSS_TOL = 1e-3 if F16 else 5e-3
-LOSS_TOL_TRAIN = 2e-3 if F16 else 6e-2
+LOSS_TOL_TRAIN = 1e-3 if F16 else 6e-2
 ACT_TOL = 2e-2 if F16 else 8e-2
 GRAD_TOL = 0.10 if F16 else 0.4
 # Pretrain: the contrastive losses send gradients ~1e-4 of FineTune's into the trunk; at the initial loss scale (1024) the first bottlenecks'
@@ -120,6 +120,50 @@ def test_finetune_matches_reference(name):
                 bad.append('running_var')
     ops.set_dropout_enabled(True)
     assert not bad, bad
+
+
+LOGP_TOL_TRAIN = 1e-2 if F16 else 8e-2
+
+
+@pytest.mark.parametrize('name', [n for n, c in CASES.items() if c.get('logp')])
+def test_training_forward_log_probabilities_per_position(name):
+    """The teacher-forced TRAINING forward at the real report length (L = 100, 384^2, two views): the engine's log-probabilities -- of the
+    target token and of 12 probe tokens -- against the imported reference's at EVERY position (tests/golden/ft384_L100.npz), not only
+    their mean (the loss).  The relational memory is the same 100-step recurrence as in generation (modules/encoder_decoder.py:293-300)
+    and expands perturbations on these weights, so a 16-bit recurrent state shows up here as an error that GROWS with the position;
+    asserted <= 1e-2 at every position of every row."""
+    from evoke_amd import ops
+    from evoke_amd.model_pretrain_finetune import FineTune
+    from tests.golden.cases import PROBE_IDS
+    from oracle import spec as S
+    case, gold = CASES[name], _gold(name)
+    inp = make_inputs(case, V)
+    model = FineTune(dict(ARGS), load_tokenizer(), 'iu_xray')
+    load_procedural(model, S.finetune_spec(V))
+    ops.set_dropout_enabled(False)
+    try:
+        model.eval()
+        ids, masks = inp['ids'].cuda(), inp['masks'].cuda()
+        with torch.no_grad():
+            x, enc_mask = model.encoder_states(inp['images'].cuda(), np.array(inp['patient_ids']), case['B'], inp['inc_ids'], inp['inc_masks'])
+            logits = model.text_decoder.forward_logits(ids, x, masks, enc_mask)
+            lp = torch.log_softmax(logits[..., :V + 1].float(), -1).cpu().double()
+    finally:
+        ops.set_dropout_enabled(True)
+    tgt = torch.cat([inp['ids'][:, 1:], torch.zeros(case['B'], 1, dtype=torch.long)], 1)
+    got_t = lp.gather(2, tgt.unsqueeze(-1)).squeeze(-1).numpy()
+    got_p = lp[:, :, PROBE_IDS].numpy()
+    valid = inp['masks'].numpy().astype(bool)                          # query positions inside the report
+    err_t = np.abs(got_t - gold['eval/logp_target']) * valid
+    err_p = np.abs(got_p - gold['eval/logp_probe']).max(-1) * valid
+    L = case['L']
+    pos = [t for t in (0, 10, 30, 50, 70, 90, L - 4) if t < L]
+    print('\n[%s] teacher-forced training forward, |log-probability - reference| per position %s:\n   target token %s\n   12 probe tokens (max) %s\n'
+          '   largest over all positions: target %.2e, probes %.2e (tolerance %.0e)'
+          % (name, pos, np.array2string(err_t[:, pos], precision=4), np.array2string(err_p[:, pos], precision=4), err_t.max(), err_p.max(), LOGP_TOL_TRAIN))
+    if os.environ.get('EVK_TEST_DUMP'):
+        np.savez(os.path.join(os.environ['EVK_TEST_DUMP'], 'train_logp_%s.npz' % name), err_t=err_t, err_p=err_p)
+    assert err_t.max() <= LOGP_TOL_TRAIN and err_p.max() <= LOGP_TOL_TRAIN, (np.argwhere(err_p > LOGP_TOL_TRAIN)[:8].tolist(), err_t.max(), err_p.max())
 
 
 @pytest.mark.parametrize('name', [n for n, c in CASES.items() if c['kind'] == 'pretrain'])
@@ -781,3 +825,90 @@ def test_pipelined_generation_equals_per_batch_inference():
         assert torch.equal(ws.cpu(), gs.cpu()), 'pipelined generation changed the token ids'
         assert wt == gt == st
         assert isinstance(sg, list) and len(sg) == len(gt)
+
+
+def test_pipelined_generation_with_asynchronously_uploaded_batches():
+    """The serving loop as a loader drives it: every batch is uploaded with `.to(device, non_blocking=True)` from pinned memory on the
+    CALLER's stream when the generator asks for it -- behind a long-running kernel, so that the copy lands late -- and dropped by the
+    caller at once.  generate_pipelined must order its encoder stream after that upload for EVERY batch (not once at the start) and keep
+    the blocks alive for the stream that reads them: results equal forward(mode='inference') batch for batch."""
+    from evoke_amd.model_pretrain_finetune import FineTune
+    from oracle import spec as S
+    args = dict(ARGS, max_seq_len=16, beam_size=3)
+    model = FineTune(args, load_tokenizer(), 'iu_xray')
+    load_procedural(model, S.finetune_spec(V))
+    model.eval()
+    host = []
+    for k, name in enumerate(('beam224', 'ft224_inc', 'beam224_b4', 'beam224')):
+        inp = make_inputs(CASES[name], V)
+        host.append(((inp['images'] * (1.0 + 0.07 * k)).pin_memory(), inp['ids'].pin_memory(), inp['masks'].pin_memory(), np.array(inp['patient_ids']),
+                     inp['inc_ids'], inp['inc_masks']))
+    with torch.no_grad():
+        want = [model(b[0].cuda(), b[1].cuda(), b[2].cuda(), *b[3:], mode='inference')[1].cpu() for b in host]
+
+        def loader():
+            for b in host:
+                torch.cuda._sleep(40_000_000)                    # ~20 ms of GPU time in front of the copies on the caller's stream
+                yield (b[0].to('cuda', non_blocking=True), b[1].to('cuda', non_blocking=True), b[2].to('cuda', non_blocking=True), *b[3:])
+                # (the caller keeps no reference: the blocks return to the allocator as soon as generate_pipelined lets go of them)
+        got = [seq.cpu() for _, seq in model.generate_pipelined(loader(), mode='inference')]
+    assert len(got) == len(want)
+    for k, (w, g) in enumerate(zip(want, got)):
+        assert torch.equal(w, g), 'batch %d: pipelined generation over asynchronously uploaded inputs changed the token ids' % k
+
+
+def test_beam_session_follows_the_encoder_mask_of_every_batch():
+    """A persistent beam session replays a captured per-token step that holds POINTERS: the encoder key mask must live in a buffer the
+    session owns and be refreshed per batch.  Two consecutive searches over the same encoder states with different non-trivial masks:
+    the second must equal what a fresh session returns for its mask (and differ from the first)."""
+    from evoke_amd import decode
+    from evoke_amd.model_pretrain_finetune import FineTune
+    from oracle import spec as S
+    case = CASES['beam224']
+    inp = make_inputs(case, V)
+    args = dict(ARGS, max_seq_len=12, beam_size=3)
+    model = FineTune(args, load_tokenizer(), 'iu_xray')
+    load_procedural(model, S.finetune_spec(V))
+    model.eval()
+    with torch.no_grad():
+        x, m = model.encoder_states(inp['images'].cuda(), np.array(inp['patient_ids']), case['B'], inp['inc_ids'], inp['inc_masks'])
+        T = x.shape[1]
+        m_a, m_b = torch.ones(x.shape[0], T, dtype=torch.long, device='cuda'), torch.ones(x.shape[0], T, dtype=torch.long, device='cuda')
+        m_a[:, T // 2:] = 0                                      # first batch: the second half of the patches is masked out
+        m_b[:, 1:T // 3] = 0                                     # second batch: the first third
+        decode._SESSIONS.clear()
+        seq_a = decode.beam_search(model.text_decoder, x, m_a, args).cpu()
+        del m_a                                                  # the first mask's memory may be reused
+        filler = torch.zeros(x.shape[0], T, dtype=torch.uint8, device='cuda')      # noqa: F841 -- takes the freed block
+        seq_b = decode.beam_search(model.text_decoder, x, m_b, args).cpu()          # same session (same geometry), new mask
+        decode._SESSIONS.clear()
+        fresh_b = decode.beam_search(model.text_decoder, x, m_b, args).cpu()
+        decode._SESSIONS.clear()
+    assert torch.equal(seq_b, fresh_b), 'the replayed step read a stale encoder mask'
+    assert not torch.equal(seq_a, seq_b), 'the two masks should lead to different reports (test is vacuous otherwise)'
+
+
+@pytest.mark.skipif(not F16, reason='the bf16-storage build has fp32\'s exponent range')
+def test_forward_overflow_of_the_fp16_build_is_reported_not_propagated():
+    """fp16 storage has a range cliff (+-65504) that the loss scale cannot repair in the FORWARD.  A freshly initialised network in eval
+    mode (batch-norm running statistics 0 / 1 through 33 un-normalised bottlenecks) reaches it: the engine must say so -- a RuntimeError
+    that names EVK_STORE=bf16 -- instead of returning reports decoded from NaN features; the same network in train mode (batch statistics)
+    stays in range and must NOT trip the guard."""
+    from evoke_amd import ops
+    from evoke_amd.model_pretrain_finetune import FineTune
+    torch.manual_seed(3)
+    case = CASES['beam224']
+    inp = make_inputs(case, V)
+    args = dict(ARGS, max_seq_len=6, beam_size=2)
+    model = FineTune(args, load_tokenizer(), 'iu_xray').cuda()
+    big = inp['images'].cuda() * 8.0
+    model.eval()
+    with pytest.raises(RuntimeError, match='EVK_STORE=bf16'):
+        with torch.no_grad():
+            model(big, inp['ids'].cuda(), inp['masks'].cuda(), np.array(inp['patient_ids']), inp['inc_ids'], inp['inc_masks'], mode='inference')
+    ops.check_forward_guard(block=True)              # the verdict was consumed: nothing pending
+    model.train()
+    ret = model(inp['images'].cuda(), inp['ids'].cuda(), inp['masks'].cuda(), np.array(inp['patient_ids']), inp['inc_ids'], inp['inc_masks'], mode='train')
+    torch.cuda.synchronize()
+    ops.check_forward_guard(block=True)              # train-mode batch statistics keep every activation O(1): no report
+    assert torch.isfinite(ret['all_loss']).item()
