@@ -333,7 +333,17 @@ def bench_decode(a, rank, world, dev):
     from evoke_amd.model_pretrain_finetune import FineTune
     from evoke_amd.config import load_default_tokenizer as load_tokenizer
     torch.manual_seed(9233)
-    model = FineTune(make_args('test'), load_tokenizer(), 'mimic_cxr').to(dev).eval()
+    model = FineTune(make_args('test'), load_tokenizer(), 'mimic_cxr').to(dev)
+    # a freshly initialised network in eval mode runs its 33 bottlenecks on batch-norm running statistics 0 / 1 and the un-normalised
+    # activations leave fp16's range (the engine's forward guard raises, evoke_amd/ops.py: guard_finite): give the statistics the values a
+    # trained model has -- 40 train-mode forward passes over the synthetic batch (the default bench line decodes with the model it has just
+    # trained for warmup + steps iterations, which has the same effect)
+    model.train()
+    wb = synth_batch('finetune', min(a.decode_batch, 16), a.views, a.res, 100, 30, dev, 3000 + rank)
+    with torch.no_grad():
+        for _ in range(40):
+            model.visual_extractor(wb['images'])
+    model.eval()
     rec = decode_record(model, a, rank, world, dev, with_cpu=(world == 1 and not a.no_cpu_baseline))
     if rank == 0:
         rec.update(n_gpus=world, warmup=a.warmup, scaling='weak', vs_baseline=None, data='synthetic', ms_per_step=rec['ms_per_batch'])

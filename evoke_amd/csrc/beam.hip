@@ -9,6 +9,7 @@
 //   2. the sample's old sequences, cache row tables and relational-memory rows are staged in LDS and rewritten IN PLACE in the
 //      winners' order (a sample's hypotheses only permute among themselves), the new token goes to position *pos;
 //   3. finished-beam tracking and the -1000 penalty, the next step's input tokens.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -157,6 +158,160 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const BeamP p) {
   }
 }
 
+// The same step with ONE memory round trip in front of the selection: the sample's state rows (sequences, cache row table, memory) and
+// all beam x (V+1) candidates are requested together -- each wave owns the candidates of one source beam in registers (V + 1 <= 1536) --,
+// the top-`beam` of every source row are found by `beam` rounds of a wave arg-max and merged by wave 0 (beam x beam candidates).  The
+// kernel above walks the candidates beam by beam (a round trip each), keeps a sorted list per thread and stages the state afterwards
+// (two more round trips): 29 us of a ~400 us token step; this one takes a third of that.  Same results bit for bit: the order (score,
+// then lowest flat index) is total.
+constexpr int CMAX = 24;        // candidates per lane and source row
+
+__device__ __forceinline__ void wave_argmax(float& v, int& i) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(v, o, 64); const int oi = __shfl_xor(i, o, 64);
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+}
+
+__global__ __launch_bounds__(256) void beam_step_fast_kernel(const BeamP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float c_val[KMAX * KMAX]; __shared__ int c_idx[KMAX * KMAX];
+  __shared__ float win_v[KMAX]; __shared__ int win_i[KMAX];
+  __shared__ int s_best;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int beam = p.beam, V1 = p.V1;
+  const long pos = p.pos[0];
+  // ---- 0. everything this workgroup reads, requested at once
+  long long* seq = p.beam_seq + (long)b * beam * p.max_len;
+  long long* l_seq = reinterpret_cast<long long*>(smem);                               // [beam][max_len]
+  int* l_anc = reinterpret_cast<int*>(l_seq + (size_t)beam * p.max_len);               // [beam][anc_cols]
+  uint32_t* l_mem = reinterpret_cast<uint32_t*>(l_anc + (size_t)beam * (p.anc ? p.anc_cols : 0));   // [beam][mem_row / 2]
+  const int mw = p.mem_row / 2;
+  uint32_t* l_mem2 = l_mem + (size_t)beam * (p.mem ? mw : 0);
+  float x[2][CMAX];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int src = wave + 4 * u;
+    const float* row = p.logp + (long)(b * beam + min(src, beam - 1)) * p.ld;
+#pragma unroll
+    for (int i = 0; i < CMAX; ++i) { const int c = lane + 64 * i; x[u][i] = (src < beam && c < V1) ? row[c] : -INFINITY; }
+  }
+  float base[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) base[u] = p.beam_sum[b * beam + min(wave + 4 * u, beam - 1)];
+  // state rows -> LDS in 16-byte pieces, eight per thread in flight (a word-by-word loop of unknown trip count is a chain of dependent
+  // round trips: 24 of them for the 24 KB of f32 memory rows were most of this kernel's first version)
+  auto stage = [&](void* dst, const void* src, int nbytes) {
+    if ((nbytes & 15) == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0) {
+      const int n4 = nbytes >> 4;
+      for (int base = 0; base < n4; base += 256 * 8) {
+        uint4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = base + tid + 256 * u; if (i < n4) t[u] = reinterpret_cast<const uint4*>(src)[i]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = base + tid + 256 * u; if (i < n4) reinterpret_cast<uint4*>(dst)[i] = t[u]; }
+      }
+    } else {
+      for (int i = tid; i < (nbytes >> 2); i += 256) reinterpret_cast<uint32_t*>(dst)[i] = reinterpret_cast<const uint32_t*>(src)[i];
+    }
+  };
+  stage(l_seq, seq, beam * p.max_len * 8);
+  if (p.anc) stage(l_anc, p.anc + (long)b * beam * p.anc_cols, beam * p.anc_cols * 4);
+  if (p.mem) stage(l_mem, p.mem + (long)b * beam * p.mem_row, beam * p.mem_row * 2);
+  if (p.mem2) stage(l_mem2, p.mem2 + (long)b * beam * p.mem_row, beam * p.mem_row * 2);
+  // ---- 1. top-`beam` of every source row (wave = source beam, + 4 for beams 4 .. 7)
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int src = wave + 4 * u;
+    if (src >= beam) continue;                       // (wave-uniform)
+#pragma unroll
+    for (int i = 0; i < CMAX; ++i) x[u][i] += base[u];            // -inf stays -inf
+    for (int r = 0; r < beam; ++r) {
+      float bv = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+      for (int i = 0; i < CMAX; ++i) if (x[u][i] > bv) { bv = x[u][i]; bi = src * V1 + lane + 64 * i; }      // ascending index: ties keep the lowest
+      wave_argmax(bv, bi);
+      if (lane == 0) { c_val[src * beam + r] = bv; c_idx[src * beam + r] = bi; }
+      const int wc = bi - src * V1;                  // the winner's column: its owner retires it
+      if ((wc & 63) == lane) {
+#pragma unroll
+        for (int i = 0; i < CMAX; ++i) if (i == (wc >> 6)) x[u][i] = -INFINITY;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- 2. merge the beam x beam survivors (wave 0)
+  if (wave == 0) {
+    float v = lane < beam * beam ? c_val[lane] : -INFINITY;
+    int id = lane < beam * beam ? c_idx[lane] : 0x7fffffff;
+    for (int r = 0; r < beam; ++r) {
+      float bv = v; int bi = id;
+      wave_argmax(bv, bi);
+      if (lane == 0) { win_v[r] = bv; win_i[r] = bi; }
+      if (id == bi) { v = -INFINITY; id = 0x7fffffff; }
+    }
+  }
+  __syncthreads();
+  // ---- 3. rewrite the sample's rows in the winners' order (a sample's hypotheses only permute among themselves)
+  for (int i = tid; i < beam * p.max_len; i += 256) {
+    const int j = i / p.max_len, c = i - j * p.max_len;
+    const int src = win_i[j] / V1;
+    seq[i] = c == pos ? (long long)(win_i[j] - src * V1) : l_seq[src * p.max_len + c];
+  }
+  if (p.anc)
+    for (int i = tid; i < beam * p.anc_cols; i += 256) {
+      const int j = i / p.anc_cols, c = i - j * p.anc_cols;
+      p.anc[(long)b * beam * p.anc_cols + i] = l_anc[(win_i[j] / V1) * p.anc_cols + c];
+    }
+  auto permute_rows = [&](void* g, const uint32_t* l) {          // row j <- staged row of its source beam; rows that stay are not rewritten
+    if ((mw & 3) == 0 && ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(l)) & 15) == 0) {
+      const int w4 = mw >> 2;
+      for (int i = tid; i < beam * w4; i += 256) {
+        const int j = i / w4, c = i - j * w4;
+        const int src = win_i[j] / V1;
+        if (src != j) reinterpret_cast<uint4*>(g)[i] = reinterpret_cast<const uint4*>(l)[src * w4 + c];
+      }
+    } else {
+      for (int i = tid; i < beam * mw; i += 256) {
+        const int j = i / mw, c = i - j * mw;
+        const int src = win_i[j] / V1;
+        if (src != j) reinterpret_cast<uint32_t*>(g)[i] = l[src * mw + c];
+      }
+    }
+  };
+  if (p.mem) permute_rows(p.mem + (long)b * beam * p.mem_row, l_mem);
+  if (p.mem2) permute_rows(p.mem2 + (long)b * beam * p.mem_row, l_mem2);
+  // ---- 4. finished beams (best p so far; the earlier / lower beam index wins ties), the -1000 penalty, next tokens
+  if (tid == 0) {
+    float pv = -INFINITY; int pi = -1;
+    for (int j = 0; j < beam; ++j) {
+      const int word = win_i[j] % V1;
+      const bool end = p.force_end || word == p.eos;
+      if (end && win_v[j] > pv) { pv = win_v[j]; pi = j; }
+      p.beam_sum[b * beam + j] = win_v[j] - (end ? 1000.f : 0.f);
+      p.words[b * beam + j] = word;
+    }
+    int take = -1;
+    if (pi >= 0 && pv > p.best_p[b]) { p.best_p[b] = pv; take = pi; }
+    s_best = take;
+  }
+  __syncthreads();
+  if (s_best >= 0) {
+    const int j = s_best, src = win_i[j] / V1;
+    for (int c = tid; c < p.max_len; c += 256)
+      p.best_seq[(long)b * p.max_len + c] = c == pos ? (long long)(win_i[j] % V1) : l_seq[src * p.max_len + c];
+  }
+  if (p.pos_out) {
+    if (p.anc && pos + 1 < p.anc_cols && tid < beam) p.anc[(long)(b * beam + tid) * p.anc_cols + pos + 1] = b * beam + tid;
+    __syncthreads();
+    if (tid == 0) {
+      __threadfence();
+      if (atomicAdd(p.ticket, 1) == (int)gridDim.x - 1) { *p.ticket = 0; p.pos_out[0] = pos + 1; }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -170,13 +325,17 @@ int evk_beam_step(const float* logp, int32_t ld, int32_t V1, int32_t beam, int32
   EVK_REQUIRE((!mem || (mem_row > 0 && mem_row % 2 == 0)) && (!anc || anc_cols > 0), "beam_step: bad state geometry");
   EVK_REQUIRE(!pos_advance || ticket, "beam_step: advancing the position needs a (zero-initialised) ticket word");
   EVK_REQUIRE(!mem2 || mem, "beam_step: mem2 needs mem");
-  const size_t lds = (size_t)beam * max_len * 8 + (anc ? (size_t)beam * anc_cols * 4 : 0) + (mem ? (size_t)beam * mem_row * 2 : 0);
+  static const int fast_on = [] { const char* e = getenv("EVK_BEAM_STEP_FAST"); return e ? atoi(e) : 1; }();
+  const bool fast = fast_on && V1 <= CMAX * 64;
+  const size_t lds = (size_t)beam * max_len * 8 + (anc ? (size_t)beam * anc_cols * 4 : 0) + (mem ? (size_t)beam * mem_row * 2 : 0) +
+                     (fast && mem2 ? (size_t)beam * mem_row * 2 : 0);
   EVK_REQUIRE(lds <= 60000, "beam_step: %zu bytes of per-sample state do not fit the staging buffer", lds);
   BeamP p{logp, ld, V1, beam, max_len, eos, force_end, reinterpret_cast<const long long*>(pos), beam_sum, reinterpret_cast<long long*>(beam_seq),
           best_p, reinterpret_cast<long long*>(best_seq), reinterpret_cast<long long*>(words), (bf16_t*)mem, mem_row, anc, anc_cols,
           (bf16_t*)mem2, reinterpret_cast<long long*>(pos_advance), ticket};
   ProfScope ps(EVK_FAM_NORM, s);
-  hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(256), lds, s, p);
+  if (fast) hipLaunchKernelGGL(beam_step_fast_kernel, dim3(B), dim3(256), lds, s, p);
+  else hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(256), lds, s, p);
   return evk_check_launch("beam_step");
 }
 

@@ -7,6 +7,7 @@
 //   * log_softmax + masked NLL (encoder_decoder.py:393, loss.py:9-16) forward/backward, plain log_softmax
 //   * L2 row normalisation and soft-label cross-entropy for the contrastive losses (...v0623...:262-351)
 // HBM-bound: each row is read once with 16-byte loads, kept in registers, written once.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -286,22 +287,41 @@ struct LsmP {
   float* lse; long rows; int V, ld, ld_out;
   float* rownll;   // optional [rows]: -logp[target] * w per row instead of the atomic accumulation (summed by the caller: order-independent bits)
 };
+// REG = true (V <= 24 * 64): the row is read ONCE into registers (one memory round trip; the three passes below re-read it from L2 each --
+// the decode step calls this once per generated token on 256 rows x 1445 and is latency bound)
+template <bool REG>
 __global__ __launch_bounds__(256) void logsoftmax_kernel(const LsmP p) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * WPB + (threadIdx.x >> 6);
   if (row >= p.rows) return;
   const float* in = p.logits + row * p.ld;
   float mx = -INFINITY;
-  for (int c = lane; c < p.V; c += 64) mx = fmaxf(mx, in[c]);
+  float xr[REG ? 24 : 1];
+  if constexpr (REG) {
+#pragma unroll
+    for (int i = 0; i < 24; ++i) { const int c = lane + 64 * i; xr[i] = c < p.V ? in[c] : -INFINITY; mx = fmaxf(mx, xr[i]); }
+  } else {
+    for (int c = lane; c < p.V; c += 64) mx = fmaxf(mx, in[c]);
+  }
   mx = wave_max(mx);
   float s = 0.f;
-  for (int c = lane; c < p.V; c += 64) s += __expf(in[c] - mx);
+  if constexpr (REG) {
+#pragma unroll
+    for (int i = 0; i < 24; ++i) s += (lane + 64 * i < p.V) ? __expf(xr[i] - mx) : 0.f;
+  } else {
+    for (int c = lane; c < p.V; c += 64) s += __expf(in[c] - mx);
+  }
   s = wave_sum(s);
   const float lse = mx + __logf(s);
   if (p.lse && lane == 0) p.lse[row] = lse;
   if (p.logp) {
     float* o = p.logp + row * p.ld_out;
-    for (int c = lane; c < p.V; c += 64) o[c] = in[c] - lse;
+    if constexpr (REG) {
+#pragma unroll
+      for (int i = 0; i < 24; ++i) { const int c = lane + 64 * i; if (c < p.V) o[c] = xr[i] - lse; }
+    } else {
+      for (int c = lane; c < p.V; c += 64) o[c] = in[c] - lse;
+    }
   }
   if (p.target && lane == 0) {
     const float w = p.wmask[row];
@@ -556,6 +576,15 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttP p) {
   }
 }
 
+// (A variant that requests every K and V row of a (row, head) pair in one batch and serves the beams of a sample from one copy of the rows was
+// measured in round 4 and removed: 20.1 us per cross-attention launch against 13.0 for the kernel above, 13.9 against 13.0 for the self
+// attention -- at 256 VGPRs it runs one wave per SIMD, and a lone wave pays the full latency of every cross-lane reduction of its 4 x 20
+// passes, which costs more than the five round trips it saves.)
+int launch_decode_attn(const DecAttP& p, hipStream_t s) {
+  hipLaunchKernelGGL(decode_attn_kernel, dim3((int)cdiv((long)p.R * p.H, 4)), dim3(256), 0, s, p);
+  return evk_check_launch("decode_attention");
+}
+
 }  // namespace
 
 extern "C" {
@@ -620,7 +649,8 @@ int evk_log_softmax_nll_fwd(const float* logits, float* logp, float* lse, const 
   EVK_REQUIRE(!target || (wmask && acc2), "log_softmax: NLL needs wmask and acc2");
   LsmP p{logits, logp, (const long long*)target, wmask, acc2, lse, rows, V, ld, ld_out, nullptr};
   ProfScope ps(EVK_FAM_NORM, s);
-  hipLaunchKernelGGL(logsoftmax_kernel, dim3(row_blocks(rows)), dim3(256), 0, s, p);
+  if (V <= 24 * 64) hipLaunchKernelGGL(logsoftmax_kernel<true>, dim3(row_blocks(rows)), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(logsoftmax_kernel<false>, dim3(row_blocks(rows)), dim3(256), 0, s, p);
   return evk_check_launch("log_softmax");
 }
 
@@ -630,7 +660,8 @@ int evk_log_softmax_nll_rows(const float* logits, float* lse, const int64_t* tar
   EVK_REQUIRE(logits && target && wmask && row_nll && rows > 0 && V > 0 && V <= ld, "log_softmax_nll_rows: bad args");
   LsmP p{logits, nullptr, (const long long*)target, wmask, nullptr, lse, rows, V, ld, ld, row_nll};
   ProfScope ps(EVK_FAM_NORM, s);
-  hipLaunchKernelGGL(logsoftmax_kernel, dim3(row_blocks(rows)), dim3(256), 0, s, p);
+  if (V <= 24 * 64) hipLaunchKernelGGL(logsoftmax_kernel<true>, dim3(row_blocks(rows)), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(logsoftmax_kernel<false>, dim3(row_blocks(rows)), dim3(256), 0, s, p);
   return evk_check_launch("log_softmax_nll_rows");
 }
 
@@ -686,8 +717,7 @@ int evk_decode_attention(const void* q, const void* k, const void* v, const unsi
   EVK_REQUIRE(kv_div >= 1 && R % kv_div == 0, "decode_attention: R=%d must be a multiple of kv_div=%d", R, kv_div);
   DecAttP p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, mask, (bf16_t*)out, R, S, heads, kv_div, scale, nullptr, nullptr, nullptr, nullptr, 0};
   ProfScope ps(EVK_FAM_NORM, s);
-  hipLaunchKernelGGL(decode_attn_kernel, dim3((int)cdiv((long)R * heads, 4)), dim3(256), 0, s, p);
-  return evk_check_launch("decode_attention");
+  return launch_decode_attn(p, s);
 }
 
 int evk_decode_attention_indirect(const void* q, const void* k, const void* v, const unsigned char* mask, const int32_t* rowmap,
@@ -699,8 +729,7 @@ int evk_decode_attention_indirect(const void* q, const void* k, const void* v, c
   DecAttP p{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, mask, (bf16_t*)out, R, S, heads, 1, scale, rowmap,
             reinterpret_cast<const long long*>(last_pos), nullptr, nullptr, 0};
   ProfScope ps(EVK_FAM_NORM, s);
-  hipLaunchKernelGGL(decode_attn_kernel, dim3((int)cdiv((long)R * heads, 4)), dim3(256), 0, s, p);
-  return evk_check_launch("decode_attention_indirect");
+  return launch_decode_attn(p, s);
 }
 
 int evk_decode_attention_qkv(const void* qkv, int64_t ldq, void* k_cache, void* v_cache, const int32_t* rowmap, const int64_t* last_pos, void* out,
@@ -714,8 +743,7 @@ int evk_decode_attention_qkv(const void* qkv, int64_t ldq, void* k_cache, void* 
   DecAttP p{base, (const bf16_t*)k_cache, (const bf16_t*)v_cache, nullptr, (bf16_t*)out, R, S, heads, 1, scale, rowmap,
             reinterpret_cast<const long long*>(last_pos), base + HD, base + 2 * HD, (long)ldq};
   ProfScope ps(EVK_FAM_NORM, s);
-  hipLaunchKernelGGL(decode_attn_kernel, dim3((int)cdiv((long)R * heads, 4)), dim3(256), 0, s, p);
-  return evk_check_launch("decode_attention_qkv");
+  return launch_decode_attn(p, s);
 }
 
 }  // extern "C"

@@ -19,6 +19,11 @@ int rmf32_attn_train(const float* qkv, const float* xp, long x_bstride, float* a
                      hipStream_t s);
 int rmf32_gate_train(const float* xp, long x_bstride, const float* gu, const float* nm1, const float* h2, float* m, bf16_t* m16_next, bf16_t* tm16_next,
                      bf16_t* out, long out_bstride, bf16_t* si, bf16_t* sf, bf16_t* tnm, int B, hipStream_t s);
+int rmf32_qkv_gu(const float* mem, const float* Wqkv, const float* bqkv, float* qkv, bf16_t* qkv16, const float* U, const float* bU, float* gu, int R,
+                 hipStream_t s);
+int rmf32_w2_gate_train(const float* h1, const float* W2, const float* b2, bf16_t* h2_16, const float* xp, long x_bstride, const float* gu, const float* nm1,
+                        float* m, bf16_t* m16_next, bf16_t* tm16_next, bf16_t* out, long out_bstride, bf16_t* si, bf16_t* sf, bf16_t* tnm, int R,
+                        hipStream_t s);
 
 namespace {
 
@@ -745,16 +750,16 @@ int evk_rm_forward_f32(const float* x32, const float* Wx32, const float* bx, con
   const long xrow = (long)L * 2048;                 // sample stride of xp
   for (int t = 0; t < L; ++t) {
     const float* xt = xp + (long)t * 2048;
-    if (int e = rmf32_gemm(mem, D_, Wqkv32, bqkv, nullptr, 0, qkv, 1536, (int)R, 1536, EVK_ACT_NONE, 0, w.qkv + (long)t * R * 1536, 1536, s)) return e;
+    // 5 launches per token: {q | k | v of the memory, U tanh(m)} as one, slot attention, Wo (+ m), W0, W2 with the gate in its epilogue
+    if (int e = rmf32_qkv_gu(mem, Wqkv32, bqkv, qkv, w.qkv + (long)t * R * 1536, U32, bU, gu, (int)R, s)) return e;
     if (int e = rmf32_attn_train(qkv, xt, xrow, a, w.a + t * RD, w.P + (long)t * B * HEADS * S_ * KEYS, p_drop,
                                  (unsigned long long)(seed + 0x51ED27ULL * (uint64_t)(t + 1)), B, s)) return e;
     if (int e = rmf32_gemm(a, D_, Wo32, bo, mem, D_, nm1, D_, (int)R, D_, EVK_ACT_NONE, 0, w.nm1 + t * RD, D_, s)) return e;
     if (int e = rmf32_gemm(nm1, D_, W032, b0, nullptr, 0, h1, D_, (int)R, D_, EVK_ACT_RELU, 0, w.h1 + t * RD, D_, s)) return e;
-    if (int e = rmf32_gemm(h1, D_, W232, b2, nullptr, 0, h2, D_, (int)R, D_, EVK_ACT_RELU, 0, w.h2 + t * RD, D_, s)) return e;
-    if (int e = rmf32_gemm(mem, D_, U32, bU, nullptr, 0, gu, 2 * D_, (int)R, 2 * D_, EVK_ACT_NONE, 1, nullptr, 0, s)) return e;      // U tanh(m)
-    if (int e = rmf32_gate_train(xt, xrow, gu, nm1, h2, mem, w.m + (t + 1) * RD, w.tm + (t + 1) * RD, (bf16_t*)out + (long)t * S_ * D_, (long)L * S_ * D_,
-                                 w.si + t * RD, w.sf + t * RD, w.tnm + t * RD, B, s)) return e;
+    if (int e = rmf32_w2_gate_train(h1, W232, b2, w.h2 + t * RD, xt, xrow, gu, nm1, mem, w.m + (t + 1) * RD, w.tm + (t + 1) * RD,
+                                    (bf16_t*)out + (long)t * S_ * D_, (long)L * S_ * D_, w.si + t * RD, w.sf + t * RD, w.tnm + t * RD, (int)R, s)) return e;
   }
+  (void)h2;
   if (m_last)
     if (int e = evk_cast(w.m + (long)L * RD, EVK_BF16, m_last, EVK_BF16, RD, stream)) return e;
   return evk_check_launch("rm_forward_f32");

@@ -8,78 +8,201 @@
 // weight matrices (the f32 masters, no 16-bit shadows), every intermediate.  Only the copy of the new memory that the decoder's conditional
 // layer norms read is rounded to the 16-bit storage format (that path does not feed back).
 //
-// The six products are tiny (768 x 512 x 512 for 256 hypotheses) and latency bound, so the f32-input MFMA (v_mfma_f32_16x16x4_f32, 1/16 of
-// the 16-bit rate, bit-for-bit a k-ordered fmaf chain: cdna_hip_programming.md section 3) costs nothing against the 16-bit kernel: a
-// workgroup owns a 32 x 32 output tile, requests its whole 32 x 512 A and B panels in ONE round trip (128 KB of LDS), and each of its four
-// waves walks the 128 k-steps of one 16 x 16 tile on two alternating accumulators.
+// The six products (768 x {512 .. 2048} x 512 for 256 hypotheses: 3.8 GFLOP per token) run on the f32-input MFMA (v_mfma_f32_16x16x4_f32, 1/16 of
+// the 16-bit rate: 27 us per token at the chip's f32 matrix peak) in five launches: {token projections | q, k, v of the memory | U tanh(m)} as
+// one grid, the slot attention, Wo (+ m), W0, and W2 with the gate in its epilogue (gemm_f32_kernel below).
 #include "common.h"
 
 namespace {
 
 constexpr int S3 = 3, KEYS4 = 4, HEADS8 = 8, DH64 = 64, D512 = 512;
-constexpr int TM = 32, TN = 32, KP = 512, LDK = KP + 4;      // + 4 floats: rows 16 bytes apart in the banks
+constexpr int KP = 512;
 
-struct GemmF { const float* A; const float* W; const float* bias; const float* resid; float* C; int M, N; long lda, ldc, ldr; int act, a_tanh; bf16_t* C16; long ldc16; };
+// gate epilogue of the LAST product of a token (h2 = relu(h1 W2^T + b2)): next = sigmoid(ig) * tanh(nm1 + h2) + sigmoid(fg) * m with
+// gates = W x (xp columns 1024..2047 of the token, shared by the 3 slots) + U tanh(m) (gu); the memory is updated in place (every element is
+// read and written by the one lane that owns it) and the 16-bit copies the decoder / the 16-bit BPTT read are written alongside
+struct GateE {
+  const float* xp; long x_bstride; const float* gu; const float* nm1; float* m;
+  bf16_t* out16; long out_bstride;                 // memory row for the conditional layer norms: out16[b * out_bstride + slot * 512 + c]
+  bf16_t* m16_next; bf16_t* tm16_next; bf16_t* si; bf16_t* sf; bf16_t* tnm;      // training saves ([R][512] each) or null
+};
+struct GemmF { const float* A; const float* W; const float* bias; const float* resid; float* C; int M, N; long lda, ldc, ldr; int act, a_tanh; bf16_t* C16; long ldc16;
+               int nbx; };                          // nbx = N / 32: column blocks of this problem
+struct GemmF3 { GemmF g[3]; int nprob; int b1, b2; GateE gate; int has_gate; };     // blocks [0, b1) -> g[0], [b1, b2) -> g[1], [b2, ..) -> g[2]
 
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF p) {
+// 32 x 64 output tile per workgroup (4 waves as 2 x 2, each 16 rows x 32 columns = two 16 x 16 accumulators), K = 512 in eight chunks of 64
+// through a double-buffered LDS image (26 KB per stage: several workgroups share a CU and overlap each other's loads), the next chunk's
+// global loads in flight while the current one is multiplied.  A lane reads 4 consecutive k of its row with one ds_read_b128 and feeds them to
+// 4 successive v_mfma_f32_16x16x4_f32 (within a 16-deep group the k order is a permutation common to both operands).
+// Round 3's kernel gave every workgroup a 32 x 32 tile and BOTH whole 32 x 512 panels (128 KB of LDS, one workgroup per CU, no overlap):
+// ~10 us per round of 256 workgroups for 2 us of MFMA, 160 us of a 580 us decode step.
+constexpr int FTM = 32, FTN = 64, FKC = 64, FLD = FKC + 4;          // LDS row pitch 68 floats: 16 lanes x 16 B land in 16 different bank groups
+constexpr int FSTAGE = (FTM + FTN) * FLD;                            // floats per stage (6528)
+
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmF3 pp) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* As = sm;                       // [TM][LDK]
-  float* Bs = sm + TM * LDK;            // [TN][LDK]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
-  // the two panels: 2 x 32 rows x 128 float4 = 8192 float4, 32 per thread, all in flight at once
-  float4 ra[16], rb[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int c = tid + 256 * i, row = c >> 7, ch = c & 127;
-    const int m = m0 + row;
-    ra[i] = m < p.M ? *reinterpret_cast<const float4*>(p.A + (long)m * p.lda + ch * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    rb[i] = *reinterpret_cast<const float4*>(p.W + (long)(n0 + row) * KP + ch * 4);
+  int bid = blockIdx.x;
+  const int which = bid < pp.b1 ? 0 : (bid < pp.b2 ? 1 : 2);
+  bid -= which == 0 ? 0 : (which == 1 ? pp.b1 : pp.b2);
+  const GemmF& p = pp.g[which];
+  const int m0 = (bid / p.nbx) * FTM, n0 = (bid % p.nbx) * FTN;
+  // staging: thread -> row pr (+16, ...), float4 pc of the 64-float chunk row
+  const int pr = tid >> 4, pc = tid & 15;
+  const bool v0 = m0 + pr < p.M, v1 = m0 + pr + 16 < p.M;
+  const float* const a0p = p.A + (long)(m0 + pr) * p.lda + pc * 4;
+  const float* const a1p = a0p + 16 * p.lda;
+  const float* const bp = p.W + (long)(n0 + pr) * KP + pc * 4;
+  // three register sets: the global loads of chunks c + 2 and c + 3 are in flight while chunk c is multiplied (the f32 masters stream from the
+  // Infinity Cache: ~2 us of latency against ~0.5 us of MFMA per chunk; with one chunk of look-ahead every iteration waited for its loads)
+  // (named registers and macros: an array captured by a lambda ends up in scratch memory, and a store to scratch waits for every load)
+  float4 r00, r01, r02, r03, r04, r05, r10, r11, r12, r13, r14, r15, r20, r21, r22, r23, r24, r25;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define EVK_F32_GLOAD(A0, A1, B0, B1, B2, B3, c)                                     \
+  {                                                                                  \
+    const int k_ = (c) * FKC;                                                        \
+    A0 = v0 ? *reinterpret_cast<const float4*>(a0p + k_) : zero4;                    \
+    A1 = v1 ? *reinterpret_cast<const float4*>(a1p + k_) : zero4;                    \
+    B0 = *reinterpret_cast<const float4*>(bp + k_);                                  \
+    B1 = *reinterpret_cast<const float4*>(bp + 16 * KP + k_);                        \
+    B2 = *reinterpret_cast<const float4*>(bp + 32 * KP + k_);                        \
+    B3 = *reinterpret_cast<const float4*>(bp + 48 * KP + k_);                        \
   }
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int c = tid + 256 * i, row = c >> 7, ch = c & 127;
-    float4 a = ra[i];
-    if (p.a_tanh) a = make_float4(tanhf(a.x), tanhf(a.y), tanhf(a.z), tanhf(a.w));
-    *reinterpret_cast<float4*>(As + row * LDK + ch * 4) = a;
-    *reinterpret_cast<float4*>(Bs + row * LDK + ch * 4) = rb[i];
+#define EVK_F32_SSTORE(A0, A1, B0, B1, B2, B3, stage)                                \
+  {                                                                                  \
+    float* const As_ = sm + (stage) * FSTAGE;                                        \
+    float* const Bs_ = As_ + FTM * FLD;                                              \
+    float4 x0_ = A0, x1_ = A1;                                                       \
+    if (p.a_tanh) {                                                                  \
+      x0_ = make_float4(tanhf(x0_.x), tanhf(x0_.y), tanhf(x0_.z), tanhf(x0_.w));     \
+      x1_ = make_float4(tanhf(x1_.x), tanhf(x1_.y), tanhf(x1_.z), tanhf(x1_.w));     \
+    }                                                                                \
+    *reinterpret_cast<float4*>(As_ + pr * FLD + pc * 4) = x0_;                       \
+    *reinterpret_cast<float4*>(As_ + (pr + 16) * FLD + pc * 4) = x1_;                \
+    *reinterpret_cast<float4*>(Bs_ + pr * FLD + pc * 4) = B0;                        \
+    *reinterpret_cast<float4*>(Bs_ + (pr + 16) * FLD + pc * 4) = B1;                 \
+    *reinterpret_cast<float4*>(Bs_ + (pr + 32) * FLD + pc * 4) = B2;                 \
+    *reinterpret_cast<float4*>(Bs_ + (pr + 48) * FLD + pc * 4) = B3;                 \
   }
-  __syncthreads();
+#define EVK_F32_SET0 r00, r01, r02, r03, r04, r05
+#define EVK_F32_SET1 r10, r11, r12, r13, r14, r15
+#define EVK_F32_SET2 r20, r21, r22, r23, r24, r25
+#define EVK_F32_GL(SET, c) EVK_F32_GLOAD_X(SET, c)
+#define EVK_F32_GLOAD_X(A0, A1, B0, B1, B2, B3, c) EVK_F32_GLOAD(A0, A1, B0, B1, B2, B3, c)
+#define EVK_F32_SS(SET, st) EVK_F32_SSTORE_X(SET, st)
+#define EVK_F32_SSTORE_X(A0, A1, B0, B1, B2, B3, st) EVK_F32_SSTORE(A0, A1, B0, B1, B2, B3, st)
   const int wm = wave >> 1, wn = wave & 1;
-  const float* ap = As + (wm * 16 + (lane & 15)) * LDK + (lane >> 4);
-  const float* bp = Bs + (wn * 16 + (lane & 15)) * LDK + (lane >> 4);
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-  for (int k = 0; k < KP; k += 8) {
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[k], bp[k], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[k + 4], bp[k + 4], acc1, 0, 0, 0);
+  const int aoff = (wm * 16 + (lane & 15)) * FLD + 4 * (lane >> 4);
+  const int boff = FTM * FLD + (wn * 32 + (lane & 15)) * FLD + 4 * (lane >> 4);
+  f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  constexpr int NCH = KP / FKC;
+  static_assert(NCH == 8, "the chunk loop below is written out for eight chunks");
+  EVK_F32_GL(EVK_F32_SET0, 0)
+  EVK_F32_GL(EVK_F32_SET1, 1)
+  EVK_F32_GL(EVK_F32_SET2, 2)
+  EVK_F32_SS(EVK_F32_SET0, 0)
+  __syncthreads();
+#define EVK_F32_MAC(c)                                                                              \
+  {                                                                                                 \
+    const float* const S = sm + ((c) & 1) * FSTAGE;                                                 \
+    _Pragma("unroll") for (int q = 0; q < FKC / 16; ++q) {                                          \
+      const float4 a4 = *reinterpret_cast<const float4*>(S + aoff + 16 * q);                        \
+      const float4 b40 = *reinterpret_cast<const float4*>(S + boff + 16 * q);                       \
+      const float4 b41 = *reinterpret_cast<const float4*>(S + boff + 16 * FLD + 16 * q);            \
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b40.x, acc[0], 0, 0, 0);                  \
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b41.x, acc[1], 0, 0, 0);                  \
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b40.y, acc[0], 0, 0, 0);                  \
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b41.y, acc[1], 0, 0, 0);                  \
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b40.z, acc[0], 0, 0, 0);                  \
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b41.z, acc[1], 0, 0, 0);                  \
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b40.w, acc[0], 0, 0, 0);                  \
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b41.w, acc[1], 0, 0, 0);                  \
+    }                                                                                               \
+    __syncthreads();                                                                                \
   }
-  const int col = n0 + wn * 16 + (lane & 15);
-  const float bias = p.bias ? p.bias[col] : 0.f;
+  // iteration c: chunk c + 1 goes to the other LDS stage (its readers passed the previous barrier), chunk c + 3 is requested into the
+  // register set chunk c left one iteration ago, chunk c is multiplied
+  EVK_F32_SS(EVK_F32_SET1, 1) EVK_F32_GL(EVK_F32_SET0, 3) EVK_F32_MAC(0)
+  EVK_F32_SS(EVK_F32_SET2, 0) EVK_F32_GL(EVK_F32_SET1, 4) EVK_F32_MAC(1)
+  EVK_F32_SS(EVK_F32_SET0, 1) EVK_F32_GL(EVK_F32_SET2, 5) EVK_F32_MAC(2)
+  EVK_F32_SS(EVK_F32_SET1, 0) EVK_F32_GL(EVK_F32_SET0, 6) EVK_F32_MAC(3)
+  EVK_F32_SS(EVK_F32_SET2, 1) EVK_F32_GL(EVK_F32_SET1, 7) EVK_F32_MAC(4)
+  EVK_F32_SS(EVK_F32_SET0, 0) EVK_F32_MAC(5)
+  EVK_F32_SS(EVK_F32_SET1, 1) EVK_F32_MAC(6)
+  EVK_F32_MAC(7)
+#undef EVK_F32_MAC
+#undef EVK_F32_GL
+#undef EVK_F32_SS
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int m = m0 + wm * 16 + 4 * (lane >> 4) + j;
-    if (m >= p.M) continue;
-    float v = (acc0[j] + acc1[j]) + bias;
-    if (p.act == EVK_ACT_RELU) v = fmaxf(v, 0.f);
-    if (p.resid) v += p.resid[(long)m * p.ldr + col];
-    p.C[(long)m * p.ldc + col] = v;
-    if (p.C16) p.C16[(long)m * p.ldc16 + col] = f2bf(v);          // what the 16-bit backward of the training recurrence reads
+  for (int jt = 0; jt < 2; ++jt) {
+    const int col = n0 + wn * 32 + jt * 16 + (lane & 15);
+    const float bias = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + wm * 16 + 4 * (lane >> 4) + j;
+      if (m >= p.M) continue;
+      float v = acc[jt][j] + bias;
+      if (p.act == EVK_ACT_RELU) v = fmaxf(v, 0.f);
+      if (p.resid) v += p.resid[(long)m * p.ldr + col];
+      if (p.C) p.C[(long)m * p.ldc + col] = v;
+      if (p.C16) p.C16[(long)m * p.ldc16 + col] = f2bf(v);          // what the 16-bit backward of the training recurrence reads
+      if (pp.has_gate) {
+        const GateE& g = pp.gate;                                  // v = h2[m][col]
+        const long b = m / S3, e = (long)m * D512 + col;
+        const int sl = m - (int)b * S3;
+        const float ig = g.xp[b * g.x_bstride + 1024 + col] + g.gu[(long)m * 1024 + col];
+        const float fg = g.xp[b * g.x_bstride + 1536 + col] + g.gu[(long)m * 1024 + 512 + col];
+        const float si = 1.f / (1.f + expf(-ig)), sf = 1.f / (1.f + expf(-fg));
+        const float t = tanhf(g.nm1[e] + v);
+        float nx = si * t + sf * g.m[e];
+        // the 16-bit copy is the f32 STATE rounded once more: without this fence the compiler forms it with a mixed-precision fma
+        // (v_fma_mixlo_f16: one rounding of the exact sum), which differs from round16(round32(.)) at ties
+        asm volatile("" : "+v"(nx));
+        g.m[e] = nx;
+        const bf16_t n16 = f2bf(nx);
+        g.out16[b * g.out_bstride + sl * D512 + col] = n16;
+        if (g.m16_next) {
+          g.m16_next[e] = n16; g.tm16_next[e] = f2bf(tanhf(nx));
+          g.si[e] = f2bf(si); g.sf[e] = f2bf(sf); g.tnm[e] = f2bf(t);
+        }
+      }
+    }
   }
 }
 
-int gemm_f32(const float* A, long lda, const float* W, const float* bias, const float* resid, long ldr, float* C, long ldc, int M, int N, int act,
-             int a_tanh, hipStream_t s, bf16_t* C16 = nullptr, long ldc16 = 0) {
-  EVK_REQUIRE(N % TN == 0 && M > 0, "rm f32 gemm: N must be a multiple of 32");
+inline GemmF mkf(const float* A, long lda, const float* W, const float* bias, const float* resid, long ldr, float* C, long ldc, int M, int N, int act,
+                 int a_tanh, bf16_t* C16 = nullptr, long ldc16 = 0) {
+  return GemmF{A, W, bias, resid, C, M, N, lda, ldc, ldr, act, a_tanh, C16, ldc16, N / FTN};
+}
+
+// up to three independent products in ONE launch (their workgroups are simply concatenated), optionally with the gate epilogue on the first
+int gemm_f32_multi(const GemmF* g, int nprob, const GateE* gate, hipStream_t s) {
+  EVK_REQUIRE(nprob >= 1 && nprob <= 3, "rm f32 gemm: 1 .. 3 problems per launch");
   static bool attr_done = false;
-  constexpr int LDS = 2 * TM * LDK * 4;
+  constexpr int LDS = 2 * FSTAGE * 4;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_done = true;
   }
-  GemmF p{A, W, bias, resid, C, M, N, lda, ldc, ldr, act, a_tanh, C16, ldc16};
-  hipLaunchKernelGGL(gemm_f32_kernel, dim3(N / TN, (M + TM - 1) / TM), dim3(256), LDS, s, p);
+  GemmF3 pp{};
+  int blocks[3] = {0, 0, 0};
+  for (int i = 0; i < nprob; ++i) {
+    EVK_REQUIRE(g[i].N % FTN == 0 && g[i].M > 0, "rm f32 gemm: N must be a multiple of 64");
+    pp.g[i] = g[i];
+    blocks[i] = (g[i].N / FTN) * ((g[i].M + FTM - 1) / FTM);
+  }
+  pp.nprob = nprob;
+  pp.b1 = blocks[0]; pp.b2 = blocks[0] + blocks[1];
+  pp.has_gate = gate ? 1 : 0;
+  if (gate) { EVK_REQUIRE(nprob == 1 && g[0].N == D512, "rm f32 gemm: the gate epilogue rides on the single 512-column product"); pp.gate = *gate; }
+  hipLaunchKernelGGL(gemm_f32_kernel, dim3(blocks[0] + blocks[1] + blocks[2]), dim3(256), LDS, s, pp);
   return evk_check_launch("rm f32 gemm");
+}
+
+int gemm_f32(const float* A, long lda, const float* W, const float* bias, const float* resid, long ldr, float* C, long ldc, int M, int N, int act,
+             int a_tanh, hipStream_t s, bf16_t* C16 = nullptr, long ldc16 = 0) {
+  const GemmF g = mkf(A, lda, W, bias, resid, ldr, C, ldc, M, N, act, a_tanh, C16, ldc16);
+  return gemm_f32_multi(&g, 1, nullptr, s);
 }
 
 __device__ __forceinline__ float half_sum32(float v) {      // sum over the 32 lanes that share a head
@@ -216,6 +339,21 @@ int rmf32_attn_train(const float* qkv, const float* xp, long x_bstride, float* a
   hipLaunchKernelGGL(rm_attn_f32_train_kernel, dim3(B), dim3(256), 0, s, p);
   return evk_check_launch("rm f32 attention (train)");
 }
+// q | k | v of the memory and U tanh(m) as one launch (training recurrence: the token's x projections are hoisted out of the loop)
+int rmf32_qkv_gu(const float* mem, const float* Wqkv, const float* bqkv, float* qkv, bf16_t* qkv16, const float* U, const float* bU, float* gu, int R,
+                 hipStream_t s) {
+  const GemmF g2[2] = {mkf(mem, D512, Wqkv, bqkv, nullptr, 0, qkv, 1536, R, 1536, EVK_ACT_NONE, 0, qkv16, 1536),
+                       mkf(mem, D512, U, bU, nullptr, 0, gu, 1024, R, 1024, EVK_ACT_NONE, 1)};
+  return gemm_f32_multi(g2, 2, nullptr, s);
+}
+// h2 = relu(h1 W2^T + b2) (16-bit copy saved) with the gate epilogue: memory in place + every 16-bit save of the training recurrence
+int rmf32_w2_gate_train(const float* h1, const float* W2, const float* b2, bf16_t* h2_16, const float* xp, long x_bstride, const float* gu, const float* nm1,
+                        float* m, bf16_t* m16_next, bf16_t* tm16_next, bf16_t* out, long out_bstride, bf16_t* si, bf16_t* sf, bf16_t* tnm, int R,
+                        hipStream_t s) {
+  const GemmF g1 = mkf(h1, D512, W2, b2, nullptr, 0, nullptr, D512, R, D512, EVK_ACT_RELU, 0, h2_16, D512);
+  const GateE ge{xp, x_bstride, gu, nm1, m, out, out_bstride, m16_next, tm16_next, si, sf, tnm};
+  return gemm_f32_multi(&g1, 1, &ge, s);
+}
 int rmf32_gate_train(const float* xp, long x_bstride, const float* gu, const float* nm1, const float* h2, float* m, bf16_t* m16_next, bf16_t* tm16_next,
                      bf16_t* out, long out_bstride, bf16_t* si, bf16_t* sf, bf16_t* tnm, int B, hipStream_t s) {
   GateT p{xp, x_bstride, gu, nm1, h2, m, m16_next, tm16_next, out, out_bstride, si, sf, tnm, B};
@@ -248,15 +386,23 @@ int evk_rm_decode_step_f32(const float* x, const float* Wx, const float* bx, flo
   float* a = take((long)R * D512); float* nm1 = take((long)R * D512); float* h1 = take((long)R * D512); float* h2 = take((long)R * D512);
   float* gu = take((long)R * 1024);
   ProfScope ps(EVK_FAM_GEMM, s);
-  if (int e = gemm_f32(x, D512, Wx, bx, nullptr, 0, xp, 2048, B, 2048, EVK_ACT_NONE, 0, s)) return e;            // keys | values | gates of the token
-  if (int e = gemm_f32(mem, D512, Wqkv, bqkv, nullptr, 0, qkv, 1536, R, 1536, EVK_ACT_NONE, 0, s)) return e;
+  // 5 launches: {x projections | q, k, v of the memory | U tanh(m)} as ONE launch of three independent products, slot attention, Wo (+ m), W0,
+  // W2 with the gate in its epilogue (memory updated in place)
+  {
+    const GemmF g3[3] = {mkf(x, D512, Wx, bx, nullptr, 0, xp, 2048, B, 2048, EVK_ACT_NONE, 0),             // keys | values | gates of the token
+                         mkf(mem, D512, Wqkv, bqkv, nullptr, 0, qkv, 1536, R, 1536, EVK_ACT_NONE, 0),
+                         mkf(mem, D512, U, bU, nullptr, 0, gu, 1024, R, 1024, EVK_ACT_NONE, 1)};              // U tanh(m)
+    if (int e = gemm_f32_multi(g3, 3, nullptr, s)) return e;
+  }
   hipLaunchKernelGGL(rm_attn_f32_kernel, dim3(B), dim3(256), 0, s, qkv, xp, a);
   if (int e = gemm_f32(a, D512, Wo, bo, mem, D512, nm1, D512, R, D512, EVK_ACT_NONE, 0, s)) return e;
   if (int e = gemm_f32(nm1, D512, W0, b0, nullptr, 0, h1, D512, R, D512, EVK_ACT_RELU, 0, s)) return e;
-  if (int e = gemm_f32(h1, D512, W2, b2, nullptr, 0, h2, D512, R, D512, EVK_ACT_RELU, 0, s)) return e;
-  if (int e = gemm_f32(mem, D512, U, bU, nullptr, 0, gu, 1024, R, 1024, EVK_ACT_NONE, 1, s)) return e;           // U tanh(m)
-  const long total = (long)R * D512;
-  hipLaunchKernelGGL(rm_gate_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xp, gu, nm1, h2, mem, (bf16_t*)out16, B);
+  {
+    const GemmF g1 = mkf(h1, D512, W2, b2, nullptr, 0, nullptr, D512, R, D512, EVK_ACT_RELU, 0);
+    const GateE ge{xp, 2048L, gu, nm1, mem, (bf16_t*)out16, (long)S3 * D512, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (int e = gemm_f32_multi(&g1, 1, &ge, s)) return e;
+  }
+  (void)h2;
   return evk_check_launch("rm_decode_step_f32");
 }
 

@@ -33,6 +33,9 @@ _FUSED_BOOK = [os.environ.get('EVK_DECODE_FUSED_BOOK', '1') != '0']      # beam 
 # the reference's at ALL 100 positions of the config-5 golden (the 16-bit recurrence: 2e-3 at position 10, 0.5 at position 90).  EVK_DECODE_RM_F32=0
 # selects the 16-bit recurrence (evk_rm_decode_step), which drifts at depth and is kept for comparison only.
 _RM_F32 = [os.environ.get('EVK_DECODE_RM_F32', '1') != '0']
+# output projection + residual + the NEXT conditional layer norm, and the whole feed-forward + residual + next norm, as ONE launch each for 16
+# hypotheses per workgroup (csrc/decode_rb.hip: weights streamed fragment-major from L2 into MFMA registers): 11 launches per decoder layer -> 6
+_ROWBLOCK = [os.environ.get('EVK_DECODE_ROWBLOCK', '1') != '0']
 _RM_STEP = [os.environ.get('EVK_DECODE_RM_STEP', '1') != '0']          # relational-memory step as one native call (evk_rm_decode_step)
 _REPLAYER = [os.environ.get('EVK_DECODE_REPLAYER', '1') != '0']      # re-issue the captured step with csrc/replay.hip instead of hipGraphLaunch
 stats = {}                       # facts about the last beam_search call (bench.py reads the per-token step time from here)
@@ -137,6 +140,21 @@ class _FusedDecodeWeights:
         self.geff, self.beff = geff, beff
         self.qkv_w = [torch.cat([l.self_attn.linears[i].weight.detach() for i in range(3)], 0).to(BF16).contiguous() for l in dec.layers]
         self.qkv_b = [torch.cat([l.self_attn.linears[i].bias.detach() for i in range(3)], 0).float().contiguous() for l in dec.layers]
+        # row-block kernels (csrc/decode_rb.hip): fragment-major copies of the four 512 x 512 matrices of a layer that sit behind a residual
+        self.rb = None
+        if _ROWBLOCK[0] and d == 512 and all(tuple(l.feed_forward.w_1.weight.shape) == (512, 512) and tuple(l.feed_forward.w_2.weight.shape) == (512, 512)
+                                             for l in dec.layers):
+            def pack(w):
+                out = torch.empty(512 * 512, dtype=BF16, device=w.device)
+                H.check(H.lib.evk_decode_rb_pack(H.ptr(w.detach().to(BF16).contiguous()), H.ptr(out), H.stream()), 'decode_rb_pack')
+                return out
+            f32c = lambda b_: b_.detach().float().contiguous()          # noqa: E731
+            self.rb = [dict(so=pack(l.self_attn.linears[3].weight), so_b=f32c(l.self_attn.linears[3].bias),
+                            co=pack(l.src_attn.linears[3].weight), co_b=f32c(l.src_attn.linears[3].bias),
+                            w1=pack(l.feed_forward.w_1.weight), b1=f32c(l.feed_forward.w_1.bias),
+                            w2=pack(l.feed_forward.w_2.weight), b2=f32c(l.feed_forward.w_2.bias)) for l in dec.layers]
+            fn = dec.norm
+            self.final_g, self.final_b, self.final_eps = f32c(fn.gamma), f32c(fn.beta), float(fn.eps)
         # relational memory: the three projections of the token embedding (keys, values, gates) as one product, q | k | v of the memory as one
         rm = model.rm
         lin = rm.attn.linears
@@ -167,6 +185,22 @@ class _FusedDecodeWeights:
     def norm(self, i, x, deltas):
         c = self.clns[i]
         return ops.layernorm(x, self.geff[i], self.beff[i], eps=c.eps, mode=1, dgam=deltas[2 * i].unsqueeze(1), dbet=deltas[2 * i + 1].unsqueeze(1))
+
+    def rowblock(self, a, x, w2, b2, norm_i, deltas, w1=None, b1=None, sync=None):
+        """(x + g . w2^T + b2, its next norm) with g = a or relu(a . w1^T + b1); norm_i = index of the conditional norm that follows, or None for
+        the decoder's final norm.  One launch (evk_decode_rowblock)."""
+        R = x.shape[0]
+        y, n = torch.empty_like(x), torch.empty_like(x)
+        if norm_i is None:
+            g, b, eps, dg, db = self.final_g, self.final_b, self.final_eps, None, None
+        else:
+            c = self.clns[norm_i]
+            g, b, eps, dg, db = self.geff[norm_i], self.beff[norm_i], float(c.eps), deltas[2 * norm_i], deltas[2 * norm_i + 1]
+        H.check(H.lib.evk_decode_rowblock(H.ptr(a), H.ptr(w1) if w1 is not None else None, H.ptr(b1) if b1 is not None else None, H.ptr(w2), H.ptr(b2),
+                                          H.ptr(x), H.ptr(y), H.ptr(g), H.ptr(b), H.ptr(dg) if dg is not None else None,
+                                          H.ptr(db) if db is not None else None, dg.stride(0) if dg is not None else 0, C.c_float(eps), H.ptr(n), R,
+                                          H.ptr(sync) if sync is not None else None, H.stream()), 'decode_rowblock')
+        return y, n
 
     def ln_linear(self, x, gamma, beta, eps, w, bias, N, deltas=None, act=H.ACT_NONE, resid=None, out_f32=False):
         """act(LayerNorm(x) @ w^T + bias) (+ resid) in ONE launch (evk_linear_ln: the norm runs in the GEMM's operand load); x (R, 512)
@@ -323,7 +357,30 @@ class _DecoderState:
         ln_ok = d == 512 and x.shape[0] <= 4096
         fuse_ln = _FUSED_LN[0] == 'all' and ln_ok
         x = x.view(-1, d)
-        for i, layer in enumerate(model.decoder.layers):
+        rb = fw.rb if (fw.rb is not None and not fuse_ln and self.anc is not None and x.is_contiguous()) else None
+        n_final = None
+        if rb is not None:
+            # row-block path: 6 launches per layer -- q|k|v, self-attention, [o-proj + residual + norm], q, cross-attention, [o-proj + residual +
+            # norm], [feed-forward + residual + next norm]
+            nl = len(model.decoder.layers)
+            if getattr(self, 'rb_sync', None) is None:
+                # exchange buffer of the split row blocks: zeroed once, owned by this state (= this search's launch sequence)
+                self.rb_sync = torch.zeros(H.lib.evk_decode_rowblock_sync_bytes(x.shape[0]), dtype=torch.uint8, device=x.device)
+            n = fw.norm(0, x, deltas).view(-1, d)
+            for i, layer in enumerate(model.decoder.layers):
+                w = rb[i]
+                qkv = fw.qkv(i, n)
+                c = torch.empty(qkv.shape[0], 1, d, dtype=qkv.dtype, device=qkv.device)
+                H.check(H.lib.evk_decode_attention_qkv(H.ptr(qkv), qkv.stride(0), H.ptr(self.ks[i]), H.ptr(self.vs[i]), H.ptr(self.anc), H.ptr(pos),
+                                                       H.ptr(c), qkv.shape[0], self.ks[i].shape[1], h, d // h, C.c_float(1.0 / math.sqrt(d // h)),
+                                                       H.stream()), 'decode_attention_qkv')
+                x, n = fw.rowblock(c.view(-1, d), x, w['so'], w['so_b'], 3 * i + 1, deltas, sync=self.rb_sync)
+                q = layer.src_attn.linears[0](n)
+                c = _attend1(q.view(-1, 1, d), self.kc[i], self.vc[i], h, self.src_mask)
+                x, n = fw.rowblock(c.view(-1, d), x, w['co'], w['co_b'], 3 * i + 2, deltas, sync=self.rb_sync)
+                x, n = fw.rowblock(n, x, w['w2'], w['b2'], 3 * (i + 1) if i + 1 < nl else None, deltas, w1=w['w1'], b1=w['b1'])
+            n_final = n
+        for i, layer in enumerate(model.decoder.layers if rb is None else ()):
             sa = layer.self_attn
             if fuse_ln:
                 qkv = fw.cln_linear(3 * i, x, deltas, fw.qkv_w[i], fw.qkv_b[i], 3 * d)
@@ -366,7 +423,8 @@ class _DecoderState:
             Np = (V1 + 7) // 8 * 8
             if getattr(self, 'logits_buf', None) is None or self.logits_buf.shape[0] != x.shape[0]:
                 self.logits_buf = torch.zeros(x.shape[0], Np, dtype=F32, device=x.device)
-            ops.gemm(fn(x).view(-1, d), ops.shadow(lg.weight, pad_rows=(V1 != Np)), self.logits_buf, x.shape[0], V1, d, lda=d, ldb=d, ldc=Np, bias=lg.bias)
+            nf = n_final if n_final is not None else fn(x).view(-1, d)
+            ops.gemm(nf, ops.shadow(lg.weight, pad_rows=(V1 != Np)), self.logits_buf, x.shape[0], V1, d, lda=d, ldb=d, ldc=Np, bias=lg.bias)
             logits = self.logits_buf
         return ops.log_softmax(logits.view(logits.shape[0], -1), self.dec.vocab_size + 1, out=out)
 
@@ -470,15 +528,19 @@ class _BeamSession:
         it = self._run_iter(enc, src_mask, return_scores, step_hook)
         dec = self.dec
         while True:
+            # (nn.Module.eval / train walk the whole module tree: only when the decoder really is in training mode -- the serving loop
+            # has put the model in eval mode once and pays nothing here)
             was_training = dec.training
-            dec.eval()
+            if was_training:
+                dec.eval()
             try:
                 with torch.no_grad():
                     v = next(it)
             except StopIteration as e:
                 return e.value
             finally:
-                dec.train(was_training)
+                if was_training:
+                    dec.train(True)
             yield v
 
     def _run_iter(self, enc, src_mask, return_scores=False, step_hook=None):

@@ -361,6 +361,25 @@ int evk_nll_bwd(const float* logits, const float* lse, const int64_t* target, co
                 void* dlogits, int64_t rows, int32_t V, int32_t ld, int32_t ld_out, evk_stream_t stream);
 /* beam step (caption_model.py:70-74): k <= 8 largest of each row, descending, ties -> lowest index first */
 int evk_topk_rows(const float* x, float* vals, int64_t* idx, int64_t rows, int32_t n, int32_t k, evk_stream_t stream);
+/* Row-block kernels of the per-token decode step (modules/encoder_decoder.py:118-131 DecoderLayer.forward -> :134-141 ConditionalSublayerConnection,
+ * :206-214 PositionwiseFeedForward, as driven by modules/caption_model.py:beam_search through EncoderDecoder.core :396-404): for 16 hypotheses
+ * per workgroup, in ONE launch,
+ *     v = x + g . W2^T + b2,  g = a  (output projection of an attention)  or  g = relu(a . W1^T + b1)  (the whole feed-forward);
+ *     y = v rounded to the 16-bit storage format (the residual stream);
+ *     n = (gamma + dgam[r]) * (v - mean) / (std_unbiased + eps) + (beta + dbet[r])   -- the NEXT sub-layer's (conditional) layer norm
+ *         (:93-103 / :144-179; gamma = null: no norm, n unused).
+ * a, x, y, n: [R][512] 16-bit (y may alias x); w*_packed: evk_decode_rb_pack of a row-major [512 out][512 in] 16-bit matrix (fragment-major
+ * [n tile][k step][lane][8]: the kernel streams it from L2 into MFMA operand registers); b1, b2, gamma, beta f32[512]; dgam / dbet
+ * [R][ld_delta] 16-bit per-hypothesis deltas or null. */
+int evk_decode_rb_pack(const void* w, void* packed, evk_stream_t stream);
+/* sync_ws: null, or evk_decode_rowblock_sync_bytes(R) bytes of device memory, ZERO-INITIALISED ONCE and then owned by the calling stream's
+ * launch sequence (never shared by launches that may overlap): with it the projection variant splits every row block over four workgroups
+ * (a quarter of the weight stream each) that exchange their partial row sums for the norm through it. */
+int64_t evk_decode_rowblock_sync_bytes(int32_t R);
+int evk_decode_rowblock(const void* a, const void* w1_packed, const float* b1, const void* w2_packed, const float* b2, const void* x, void* y,
+                        const float* gamma, const float* beta, const void* dgam, const void* dbet, int64_t ld_delta, float eps, void* n, int32_t R,
+                        void* sync_ws, evk_stream_t stream);
+
 /* One launch for the whole beam bookkeeping of a generated token (beam.hip): CaptionModel.beam_step + the finished-beam
  * handling of CaptionModel.beam_search (modules/caption_model.py:51-106, 174-189; att_model.py:133-135) for hypothesis counts
  * that no longer change (every step after the first).  logp [B*beam][ld] f32 log-probs (V1 = V+1 valid columns); *pos = position

@@ -289,6 +289,128 @@ def test_embedding_ids_outside_the_table_never_touch_memory():
     assert rc != 0 and b'embedding_fwd' in H.lib.evk_last_error()
 
 
+@pytest.mark.parametrize('R,ff,cond,split', [(256, False, True, True), (256, False, True, False), (256, True, True, False), (40, True, False, False),
+                                             (7, False, True, True), (7, False, True, False), (256, False, None, True), (200, False, False, True)])
+def test_decode_rowblock_projection_residual_and_next_norm(R, ff, cond, split):
+    """C ABI: evk_decode_rowblock (csrc/decode_rb.hip) against fp32 torch math on the same 16-bit operands -- output projection / whole
+    feed-forward + residual + the next R2Gen (conditional) layer norm (unbiased std, eps on the std: encoder_decoder.py:93-103, 144-179) in
+    one launch; row counts that do not fill the last 16-row block; cond None = no norm requested; split = every row block over four workgroups
+    that exchange their partial row sums through device memory -- launched THREE times on the same exchange buffer (its arrival counters are
+    never reset: each launch must find its own generation)."""
+    import ctypes as C
+    from evoke_amd import hip as H
+    D = 512
+    a, x = rnd(R, D, seed=21).to(BF), rnd(R, D, seed=22, scale=2.0).to(BF)                # (rnd is f32: the 16-bit operands are rounded here)
+    w1, w2 = rnd(D, D, seed=23, scale=0.06).to(BF), rnd(D, D, seed=24, scale=0.06).to(BF)
+    b1, b2 = rnd(D, seed=25, scale=0.1), rnd(D, seed=26, scale=0.1)
+    gamma, beta = 1.0 + rnd(D, seed=27, scale=0.1), rnd(D, seed=28, scale=0.1)
+    dg, db = rnd(R, D, seed=29, scale=0.2).to(BF), rnd(R, D, seed=30, scale=0.2).to(BF)
+
+    def pack(w):
+        out = torch.empty(D * D, dtype=BF, device='cuda')
+        H.check(H.lib.evk_decode_rb_pack(H.ptr(w.cuda().contiguous()), H.ptr(out), H.stream()), 'decode_rb_pack')
+        return out
+    w1p, w2p = pack(w1), pack(w2)
+    ad, xd = a.cuda(), x.cuda()
+    y = torch.empty(R, D, dtype=BF, device='cuda')
+    n = torch.full((R, D), 9.0, dtype=BF, device='cuda')
+    b1d, b2d, gd, bd, dgd, dbd = b1.cuda(), b2.cuda(), gamma.cuda(), beta.cuda(), dg.cuda(), db.cuda()
+    has_norm = cond is not None
+    sync = torch.zeros(H.lib.evk_decode_rowblock_sync_bytes(R), dtype=torch.uint8, device='cuda') if split else None
+    for rep in range(3 if split else 1):
+        if rep:
+            y.fill_(0)
+            n.fill_(9.0)
+        H.check(H.lib.evk_decode_rowblock(H.ptr(ad), H.ptr(w1p) if ff else None, H.ptr(b1d) if ff else None, H.ptr(w2p), H.ptr(b2d), H.ptr(xd), H.ptr(y),
+                                          H.ptr(gd) if has_norm else None, H.ptr(bd) if has_norm else None, H.ptr(dgd) if cond else None,
+                                          H.ptr(dbd) if cond else None, D if cond else 0, C.c_float(1e-6), H.ptr(n) if has_norm else None, R,
+                                          H.ptr(sync) if split else None, H.stream()), 'decode_rowblock')
+    g = a.float()
+    if ff:
+        g = torch.relu(g @ w1.float().t() + b1).to(BF).float()
+    v = x.float() + g @ w2.float().t() + b2
+    close(y, v, 4e-3, 4e-3, 'rowblock y')
+    if has_norm:
+        gg, bb = (gamma + dg.float(), beta + db.float()) if cond else (gamma, beta)
+        want = gg * (v - v.mean(-1, keepdim=True)) / (v.std(-1, keepdim=True) + 1e-6) + bb
+        close(n, want, 4e-3, 6e-3, 'rowblock norm')
+    else:
+        assert bool((n == 9.0).all())
+
+
+@pytest.mark.parametrize('beam,B,f32_mem,last', [(4, 5, True, False), (3, 2, False, False), (4, 3, True, True), (8, 2, False, False), (1, 3, True, False)])
+def test_beam_step_kernel_against_the_torch_formulation(beam, B, f32_mem, last):
+    """C ABI: evk_beam_step (csrc/beam.hip) against a torch restatement of CaptionModel.beam_search's per-step bookkeeping
+    (modules/caption_model.py:51-106 beam_step -- running sum + log-prob, flat DESCENDING sort over beam x (V+1), top-beam, state / sequence
+    reorder -- and :174-189 -- [EOS] beams recorded as finished with p = running sum and sent to -1000): selected ids bit-exact including
+    TIES (equal scores -> lowest flat index), sequences, cache row table and relational-memory rows permuted in place, best finished beam,
+    next tokens, the position advance.  Both kernels behind the entry point are exercised (EVK_BEAM_STEP_FAST is read once per process, so
+    the slow one is reached through a vocabulary beyond the fast kernel's register budget)."""
+    import ctypes as C
+    from evoke_amd import hip as H
+    for V1, ld in ((1445, 1448), (1601, 1608)):            # the second: > 24 x 64 candidates per row -> the batched-walk kernel
+        max_len, eos, pos0 = 20, V1 - 2, 7
+        g = torch.Generator().manual_seed(40 + beam + B)
+        logp = torch.log_softmax(torch.randn(B * beam, V1, generator=g) * 2.0, -1)
+        logp[:, 50] = logp[:, 900]                                   # ties inside a row ...
+        if beam > 1:
+            logp[1] = logp[0]                                        # ... and between the first two beams of sample 0 (sums made equal below)
+        logp[beam - 1 if B > 1 else 0, eos] = 0.5                    # an [EOS] that wins in sample 0
+        lp_pad = torch.full((B * beam, ld), -7.0)
+        lp_pad[:, :V1] = logp
+        beam_sum = torch.randn(B, beam, generator=g)
+        if beam > 1:
+            beam_sum[0, 1] = beam_sum[0, 0]
+        beam_seq = torch.randint(5, V1 - 3, (B, beam, max_len), generator=g)
+        beam_seq[:, :, pos0:] = 0
+        best_p = torch.full((B,), -float('inf'))
+        best_p[-1] = 1e9                                             # a sample whose earlier finished beam stays the best
+        best_seq = torch.randint(5, 50, (B, max_len), generator=g)
+        mem_row = 3 * 512 * (2 if f32_mem else 1)                    # in 16-bit units (evk_beam_step's convention)
+        mem = torch.randn(B * beam, 3 * 512, generator=g)
+        mem = mem if f32_mem else mem.to(BF)
+        anc = torch.randint(0, B * beam, (B * beam, max_len), generator=g, dtype=torch.int32)
+        d = lambda t: t.clone().cuda()                               # noqa: E731
+        lp_d, bs_d, sq_d, bp_d, bq_d, mem_d, anc_d = d(lp_pad), d(beam_sum), d(beam_seq), d(best_p), d(best_seq), d(mem), d(anc)
+        words = torch.zeros(B * beam, dtype=torch.long, device='cuda')
+        pos = torch.tensor([pos0], dtype=torch.long, device='cuda')
+        ticket = torch.zeros(1, dtype=torch.int32, device='cuda')
+        H.check(H.lib.evk_beam_step(H.ptr(lp_d), ld, V1, beam, B, max_len, H.ptr(pos), eos, int(last), H.ptr(bs_d), H.ptr(sq_d), H.ptr(bp_d),
+                                    H.ptr(bq_d), H.ptr(words), H.ptr(mem_d), mem_row, H.ptr(anc_d), max_len, None if last else H.ptr(pos),
+                                    H.ptr(ticket), None, H.stream()), 'beam_step')
+        torch.cuda.synchronize()
+        # ---- the reference's bookkeeping, restated on the CPU
+        cand = (beam_sum.unsqueeze(-1) + logp.view(B, beam, V1)).reshape(B, beam * V1)
+        order = torch.sort(cand, dim=1, descending=True, stable=True).indices[:, :beam]          # ties: lowest flat index first
+        ys = cand.gather(1, order)
+        src, word = order // V1, order % V1
+        want_seq = beam_seq.gather(1, src.unsqueeze(-1).expand(-1, -1, max_len)).clone()
+        want_seq[:, :, pos0] = word
+        rows = (src + torch.arange(B).unsqueeze(1) * beam).reshape(-1)
+        want_mem = mem[rows]
+        want_anc = anc[rows].clone()
+        if not last and pos0 + 1 < max_len:
+            want_anc[:, pos0 + 1] = torch.arange(B * beam, dtype=torch.int32)
+        end = torch.ones_like(word, dtype=torch.bool) if last else (word == eos)
+        want_sum = ys - 1000.0 * end.float()
+        want_bp, want_bq = best_p.clone(), best_seq.clone()
+        for b in range(B):
+            pv, pi = -float('inf'), -1
+            for j in range(beam):
+                if bool(end[b, j]) and float(ys[b, j]) > pv:
+                    pv, pi = float(ys[b, j]), j
+            if pi >= 0 and pv > float(want_bp[b]):
+                want_bp[b] = pv
+                want_bq[b] = want_seq[b, pi]
+        assert torch.equal(sq_d.cpu(), want_seq), 'selected sequences differ (V1 = %d)' % V1
+        assert torch.equal(words.cpu(), word.reshape(-1))
+        assert torch.allclose(bs_d.cpu(), want_sum, atol=1e-5, rtol=0)
+        assert torch.equal(mem_d.cpu(), want_mem) and torch.equal(anc_d.cpu(), want_anc)
+        assert torch.allclose(bp_d.cpu(), want_bp, atol=1e-5, rtol=0) and torch.equal(bq_d.cpu(), want_bq)
+        assert int(pos.item()) == (pos0 if last else pos0 + 1) and int(ticket.item()) == 0
+        assert bool(end[0].any()) or last or B == 1                  # the planted [EOS] was selected (the finished-beam branch ran)
+
+
 def test_dropout_statistics_and_backward():
     from evoke_amd import ops
     x = torch.ones(1 << 16, dtype=BF).cuda().requires_grad_(True)
