@@ -166,12 +166,29 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const BeamP p) {
 // then lowest flat index) is total.
 constexpr int CMAX = 24;        // candidates per lane and source row
 
+// arg-max (value, then LOWEST index) over the 64 lanes, result in every lane: four DPP exchanges inside the rows of 16 lanes (a few cycles
+// each; __shfl_xor goes through the LDS crossbar, ~100 cycles per dependent step: 12 of them per round were most of this kernel), then the
+// four row results are read as scalars
+template <int CTRL>
+__device__ __forceinline__ void dpp_argmax_step(float& v, int& i) {
+  const float ov = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+  const int oi = __builtin_amdgcn_update_dpp(0, i, CTRL, 0xF, 0xF, true);
+  if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
 __device__ __forceinline__ void wave_argmax(float& v, int& i) {
+  dpp_argmax_step<0xB1>(v, i);       // quad_perm [1,0,3,2]
+  dpp_argmax_step<0x4E>(v, i);       // quad_perm [2,3,0,1]
+  dpp_argmax_step<0x141>(v, i);      // row_half_mirror
+  dpp_argmax_step<0x140>(v, i);      // row_mirror: every lane of a row holds the row's result
+  float bv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  int bi = __builtin_amdgcn_readlane(i, 0);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float ov = __shfl_xor(v, o, 64); const int oi = __shfl_xor(i, o, 64);
-    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+  for (int r = 1; r < 4; ++r) {
+    const float ov = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16 * r));
+    const int oi = __builtin_amdgcn_readlane(i, 16 * r);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
   }
+  v = bv; i = bi;
 }
 
 __global__ __launch_bounds__(256) void beam_step_fast_kernel(const BeamP p) {

@@ -463,17 +463,30 @@ struct DecAttP { const bf16_t* q; const bf16_t* k; const bf16_t* v; const unsign
                                                  // attends to them as position *last_pos and appends them to row r of the caches
 
 #ifndef EVK_DEC_ATTN_UNR
-#define EVK_DEC_ATTN_UNR 6
+#define EVK_DEC_ATTN_UNR 10
 #endif
 __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttP p) {
   // lane = (g, c): g = lane >> 3 picks one of 8 key rows per pass, c = lane & 7 one 16-byte chunk of the 128-byte head row, so
-  // every load instruction of the wave reads 8 whole rows and all passes are independent (no load waits on a shuffle)
-  __shared__ float sl[4][256];
+  // every load instruction of the wave reads 8 whole rows and all passes of a batch are independent (no load waits on a shuffle).
+  // The KEY and the VALUE rows of UNR passes (80 keys) are requested together and folded into a running (max, sum, output) triple --
+  // an online softmax --, so the 144 cross-attention keys cost two memory round trips and a self-attention over <= 80 positions one.
+  // (Round 3 walked the keys in batches of 48, stored the scores in LDS, normalised, then walked the values: six dependent round trips,
+  // most of the kernel's 13 us on a step that is latency bound.)
   __shared__ int sr[4][256];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int w = blockIdx.x * 4 + wv;
   if (w >= p.R * p.H) return;
-  const int r = w / p.H, h = w - r * p.H;
+  int r, h;
+  if (p.kv_div > 1 && (p.kv_div & 3) == 0) {
+    // hypotheses that share a K / V row (the beams of a sample in the cross attention): the four waves of a workgroup take four of them for
+    // ONE head -- they request the same key / value lines at the same time, which the CU's L1 serves once (measured before: 75 MB through
+    // L2 per launch at beam 4, 6 TB/s: bandwidth bound on re-reads)
+    const int grp = blockIdx.x;                        // (row quad, head)
+    h = grp % p.H;
+    r = (grp / p.H) * 4 + wv;
+  } else {
+    r = w / p.H; h = w - r * p.H;
+  }
   const int g = lane >> 3, c = lane & 7;
   const long HD = (long)p.H * 64;
   float qr[8];
@@ -504,72 +517,62 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const DecAttP p) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  // the key rows of UNR passes are requested before the first is used: one memory round trip per UNR x 8 keys, not per 8
-  // (the step is latency bound: 18 dependent round trips for the 144 cross-attention keys were most of this kernel's 17-21 us)
   constexpr int UNR = EVK_DEC_ATTN_UNR;
+  float mrun = -INFINITY, lrun = 0.f;               // running max (wave-uniform) and this lane group's share of the running sum
+  float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int it0 = 0; it0 < passes; it0 += UNR) {
-    uint4 ku[UNR];
+    uint4 ku[UNR], vu[UNR];
 #pragma unroll
     for (int j = 0; j < UNR; ++j) {
       const int s = (it0 + j) * 8 + g;
-      ku[j] = s < Seff ? *reinterpret_cast<const uint4*>(s == snew ? kn : kb + ((long)sr[wv][s] * p.S + s) * HD) : make_uint4(0, 0, 0, 0);
+      const bool ok = s < Seff;
+      const long off = ok ? ((long)sr[wv][s] * p.S + s) * HD : 0;
+      ku[j] = ok ? *reinterpret_cast<const uint4*>(s == snew ? kn : kb + off) : make_uint4(0, 0, 0, 0);
+      vu[j] = ok ? *reinterpret_cast<const uint4*>(s == snew ? vn : vb + off) : make_uint4(0, 0, 0, 0);
     }
+    float sc[UNR];
+    float bmax = -INFINITY;
 #pragma unroll
     for (int j = 0; j < UNR; ++j) {
       const int s = (it0 + j) * 8 + g;
       const uint4 u = ku[j];
       float a = lo_bf(u.x) * qr[0] + hi_bf(u.x) * qr[1] + lo_bf(u.y) * qr[2] + hi_bf(u.y) * qr[3] + lo_bf(u.z) * qr[4] + hi_bf(u.z) * qr[5] +
                 lo_bf(u.w) * qr[6] + hi_bf(u.w) * qr[7];
-      if (!(s < Seff)) a = 0.f;
       a += __shfl_xor(a, 1, 64);
       a += __shfl_xor(a, 2, 64);
       a += __shfl_xor(a, 4, 64);
-      if (c == 0 && s < Seff) sl[wv][s] = (mk && !mk[s]) ? -INFINITY : a * p.scale;
+      sc[j] = (s < Seff && !(mk && !mk[s])) ? a * p.scale : -INFINITY;
+      bmax = fmaxf(bmax, sc[j]);
     }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  float mx = -INFINITY;
-  for (int s = lane; s < Seff; s += 64) mx = fmaxf(mx, sl[wv][s]);
-  mx = wave_max(mx);
-  float sum = 0.f;
-  for (int s = lane; s < Seff; s += 64) {
-    const float x = sl[wv][s];
-    const float e = (x == -INFINITY || mx == -INFINITY) ? 0.f : __expf(x - mx);
-    sl[wv][s] = e;
-    sum += e;
-  }
-  sum = wave_sum(sum);
-  const float inv = sum > 0.f ? 1.f / sum : 0.f;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int it0 = 0; it0 < passes; it0 += UNR) {
-    uint4 vu[UNR];
+    bmax = fmaxf(bmax, __shfl_xor(bmax, 8, 64));
+    bmax = fmaxf(bmax, __shfl_xor(bmax, 16, 64));
+    bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
+    const float mnew = fmaxf(mrun, bmax);
+    const float resc = (mrun == -INFINITY) ? 0.f : __expf(mrun - mnew);          // (mnew == -inf only while every key so far is masked)
+    lrun *= resc;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] *= resc;
 #pragma unroll
     for (int j = 0; j < UNR; ++j) {
-      const int s = (it0 + j) * 8 + g;
-      vu[j] = s < Seff ? *reinterpret_cast<const uint4*>(s == snew ? vn : vb + ((long)sr[wv][s] * p.S + s) * HD) : make_uint4(0, 0, 0, 0);
+      const float e = (sc[j] == -INFINITY || mnew == -INFINITY) ? 0.f : __expf(sc[j] - mnew);
+      lrun += e;
+      const uint4 u = vu[j];
+      o[0] += e * lo_bf(u.x); o[1] += e * hi_bf(u.x); o[2] += e * lo_bf(u.y); o[3] += e * hi_bf(u.y);
+      o[4] += e * lo_bf(u.z); o[5] += e * hi_bf(u.z); o[6] += e * lo_bf(u.w); o[7] += e * hi_bf(u.w);
     }
-#pragma unroll
-    for (int j = 0; j < UNR; ++j) {
-      const int s = (it0 + j) * 8 + g;
-      if (s < Seff) {
-        const uint4 u = vu[j];
-        const float ps = sl[wv][s];
-        o[0] += ps * lo_bf(u.x); o[1] += ps * hi_bf(u.x); o[2] += ps * lo_bf(u.y); o[3] += ps * hi_bf(u.y);
-        o[4] += ps * lo_bf(u.z); o[5] += ps * hi_bf(u.z); o[6] += ps * lo_bf(u.w); o[7] += ps * hi_bf(u.w);
-      }
-    }
+    mrun = mnew;
   }
+  // every lane of a key group (8 lanes) added the same e to lrun; the groups hold disjoint keys
+  lrun += __shfl_xor(lrun, 8, 64);
+  lrun += __shfl_xor(lrun, 16, 64);
+  lrun += __shfl_xor(lrun, 32, 64);
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     o[j] += __shfl_xor(o[j], 8, 64);
     o[j] += __shfl_xor(o[j], 16, 64);
     o[j] += __shfl_xor(o[j], 32, 64);
   }
+  const float inv = lrun > 0.f ? 1.f / lrun : 0.f;
   if (g == 0) {
     *reinterpret_cast<uint4*>(p.out + (long)r * HD + h * 64 + c * 8) =
         make_uint4(pack2bf(o[0] * inv, o[1] * inv), pack2bf(o[2] * inv, o[3] * inv), pack2bf(o[4] * inv, o[5] * inv), pack2bf(o[6] * inv, o[7] * inv));

@@ -53,3 +53,22 @@ def chain(e):
 for e in evs:
     if e.name in ('hipMemcpyAsync', 'hipMemcpy2DAsync', 'hipMemsetAsync', 'hipMemcpyWithStream'):
         print('RT call %-18s issued by: %s' % (e.name, chain(e)))
+
+# aggregated: which host ops issue the step's memcpy / memset runtime calls, and the torch-native GPU kernels (glue) by the op that launched them
+import collections
+agg = collections.Counter()
+for e in evs:
+    if e.name in ('hipMemcpyAsync', 'hipMemcpy2DAsync', 'hipMemsetAsync', 'hipMemcpyWithStream'):
+        agg[(e.name, chain(e)[:160])] += 1
+print('---- aggregated runtime copies / memsets per step')
+for (n, c), k in agg.most_common(40):
+    print('%4d  %-18s %s' % (k, n, c))
+glue = collections.Counter()
+for e in evs:
+    if e.name == 'hipLaunchKernel' or e.name == 'hipExtModuleLaunchKernel':
+        par = e.cpu_parent
+        if par is not None and par.name.startswith('aten::'):
+            glue[(par.name, chain(par)[:120])] += 1
+print('---- aggregated aten:: kernel launches per step (torch glue)')
+for (n, c), k in glue.most_common(40):
+    print('%4d  %-24s %s' % (k, n, c))
