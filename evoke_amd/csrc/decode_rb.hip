@@ -29,8 +29,19 @@ struct RbP {
   const bf16_t* dgam; const bf16_t* dbet; long ld_delta;       // [R][ld_delta] 16-bit deltas or null
   bf16_t* n;                              // [R][512] normed rows out
   float eps; int R;
-  unsigned* sync_ctr; float* sync_part;   // split row blocks: arrival counters [row blocks], partial row sums [row blocks][4][2][16]
+  unsigned* sync_ctr; float* sync_part;   // split row blocks: arrival counters [2][row blocks], partial row sums [row blocks][4][2][16]
+  unsigned* sync_hid;                     // ... and the hidden rows of the split feed-forward [row blocks][16][256 dwords]
+  int rbs;
 };
+
+// one arrival on a monotone counter + wait for the generation it belongs to (see decode_rowblock_kernel): thread 0 only
+template <int NS>
+__device__ __forceinline__ void cluster_arrive_wait(unsigned* ctr) {
+  const unsigned old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned target = (old / NS + 1u) * NS;      // the multiple of NS that completes this launch's generation
+  while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
 
 // acc[j] += W[64 w + 16 j + .., :] . in[m, :] over K = 512: B fragments streamed from the packed weights, A fragments through `afrag(ks)`
 template <class AF>
@@ -69,9 +80,8 @@ __device__ __forceinline__ void gemm16(const uint4* __restrict__ wp, int wave, i
 // together (64 for 256 hypotheses); a workgroup that waits holds one CU, never a lock.
 template <bool FF, int NS>
 __global__ __launch_bounds__(NTH, 2) void decode_rowblock_kernel(const RbP p) {
-  static_assert(NS == 1 || (NS == 4 && !FF), "split row blocks: the projection variant only");
   constexpr int NT = 4 / NS;                             // MFMA column tiles per wave
-  __shared__ __attribute__((aligned(16))) unsigned char hs[FF ? TMR * HP : 16];
+  __shared__ __attribute__((aligned(16))) unsigned char hs[FF ? TMR * HP : 16];          // hidden rows of the feed-forward variant
   __shared__ float red[2][8][TMR];
   __shared__ float tot[2][TMR];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -101,13 +111,54 @@ __global__ __launch_bounds__(NTH, 2) void decode_rowblock_kernel(const RbP p) {
   for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   if constexpr (NS == 4) {
     // one column tile per wave: its 16 weight fragments (and the 16 activation fragments) are all in flight at once
-    const uint4* const base = p.w2p + ((long)(8 * sp + wave) * 16) * 64 + lane;
     uint4 bw[16], aw[16];
+    if constexpr (FF) {
+      // split feed-forward: this workgroup's 128 hidden columns first, exchanged with the three siblings through device memory
+      // (agent-scope dword stores / loads: they pass the non-coherent L2 of another XCD), then its 128 output columns over the whole hidden row
+      const uint4* const base1 = p.w1p + ((long)(8 * sp + wave) * 16) * 64 + lane;
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) { bw[ks] = base[(long)ks * 64]; aw[ks] = *reinterpret_cast<const uint4*>(arow + ks * 32); }
+      for (int ks = 0; ks < 16; ++ks) { bw[ks] = base1[(long)ks * 64]; aw[ks] = *reinterpret_cast<const uint4*>(arow + ks * 32); }
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks)
-      acc[0] = EVK_MFMA_16x16x32(__builtin_bit_cast(bf16x8, bw[ks]), __builtin_bit_cast(bf16x8, aw[ks]), acc[0], 0, 0, 0);
+      for (int ks = 0; ks < 16; ++ks)
+        acc[0] = EVK_MFMA_16x16x32(__builtin_bit_cast(bf16x8, bw[ks]), __builtin_bit_cast(bf16x8, aw[ks]), acc[0], 0, 0, 0);
+      const uint4* const base2 = p.w2p + ((long)(8 * sp + wave) * 16) * 64 + lane;
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) bw[ks] = base2[(long)ks * 64];          // the second product's weights travel during the exchange
+      const float4 bb = *reinterpret_cast<const float4*>(p.b1 + ncol);
+      const uint32_t h01 = pack2bf(fmaxf(acc[0][0] + bb.x, 0.f), fmaxf(acc[0][1] + bb.y, 0.f));
+      const uint32_t h23 = pack2bf(fmaxf(acc[0][2] + bb.z, 0.f), fmaxf(acc[0][3] + bb.w, 0.f));
+      acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<uint2*>(hs + m * HP + ncol * 2) = make_uint2(h01, h23);
+      unsigned* const xh = p.sync_hid + ((long)rbk * TMR + m) * (D / 2) + ncol / 2;      // hidden row m of the row block, as dwords
+      __hip_atomic_store(xh, h01, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(xh + 1, h23, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      if (tid == 0) cluster_arrive_wait<NS>(p.sync_ctr + p.rbs + rbk);
+      __syncthreads();
+      // the three other column slices of the 16 hidden rows: 3 x 16 x 64 dwords, 6 per thread
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int e = tid + NTH * i;                       // 0 .. 3071
+        const int q = e / (TMR * 64), rem = e - q * (TMR * 64);
+        const int rr = rem >> 6, cd = rem & 63;
+        const int so = (sp + 1 + q) % NS;                  // sibling slice
+        const unsigned val = __hip_atomic_load(p.sync_hid + ((long)rbk * TMR + rr) * (D / 2) + so * 64 + cd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *reinterpret_cast<unsigned*>(hs + rr * HP + (so * 64 + cd) * 4) = val;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const bf16x8 af = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(hs + m * HP + (ks * 32 + kg * 8) * 2));
+        acc[0] = EVK_MFMA_16x16x32(__builtin_bit_cast(bf16x8, bw[ks]), af, acc[0], 0, 0, 0);
+      }
+    } else {
+      const uint4* const base = p.w2p + ((long)(8 * sp + wave) * 16) * 64 + lane;
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) { bw[ks] = base[(long)ks * 64]; aw[ks] = *reinterpret_cast<const uint4*>(arow + ks * 32); }
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks)
+        acc[0] = EVK_MFMA_16x16x32(__builtin_bit_cast(bf16x8, bw[ks]), __builtin_bit_cast(bf16x8, aw[ks]), acc[0], 0, 0, 0);
+    }
   } else if constexpr (FF) {
     gemm16(p.w1p, wave, lane, a_global, acc);
     // hidden rows -> LDS (16-bit, as the two-launch path stores them), then they are the A operand of the second product
@@ -179,13 +230,7 @@ __global__ __launch_bounds__(NTH, 2) void decode_rowblock_kernel(const RbP p) {
       __hip_atomic_store(part + (sp * 2 + which) * TMR + r, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();                                    // (the stores above are issued; the release below orders them)
-    if (tid == 0) {
-      unsigned* const ctr = p.sync_ctr + rbk;
-      const unsigned old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned target = (old / NS + 1u) * NS;      // the multiple of NS that completes this launch's generation
-      while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(1);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
+    if (tid == 0) cluster_arrive_wait<NS>(p.sync_ctr + rbk);
     __syncthreads();
     if (tid < 2 * TMR) {
       const int which = tid >> 4, r = tid & 15;
@@ -245,7 +290,7 @@ int evk_decode_rb_pack(const void* w, void* packed, evk_stream_t stream) {
 
 int64_t evk_decode_rowblock_sync_bytes(int32_t R) {
   const int64_t rbs = (R + TMR - 1) / TMR;
-  return rbs * 256 + rbs * 4 * 2 * TMR * 4;          // counters (one per row block, on lines of their own up to 64 row blocks) + partial sums
+  return rbs * 256 + rbs * 4 * 2 * TMR * 4 + rbs * TMR * D * 2;      // two counters per row block (head of the buffer) + partial sums + hidden rows
 }
 
 int evk_decode_rowblock(const void* a, const void* w1_packed, const float* b1, const void* w2_packed, const float* b2, const void* x, void* y,
@@ -260,17 +305,19 @@ int evk_decode_rowblock(const void* a, const void* w1_packed, const float* b1, c
               (!gamma || (al16(gamma) && al16(beta))) && (!dgam || (al16(dgam) && al16(dbet) && ld_delta % 8 == 0 && ld_delta >= D)) &&
               (!sync_ws || al16(sync_ws)), "decode_rowblock: 16-byte aligned operands, delta pitch a multiple of 8");
   RbP p{(const bf16_t*)a, (const uint4*)w1_packed, b1, (const uint4*)w2_packed, b2, (const bf16_t*)x, (bf16_t*)y, gamma, beta, (const bf16_t*)dgam,
-        (const bf16_t*)dbet, (long)ld_delta, (bf16_t*)n, eps, R, nullptr, nullptr};
+        (const bf16_t*)dbet, (long)ld_delta, (bf16_t*)n, eps, R, nullptr, nullptr, nullptr, 0};
   ProfScope ps(EVK_FAM_GEMM, s, 2.0 * R * D * D * (w1_packed ? 2 : 1));
   const int rbs = (R + TMR - 1) / TMR;
   // the projection variant splits a row block over four workgroups when the caller provides the (zero-initialised, persistent) exchange
   // buffer and the whole grid is resident at once (one 512-thread workgroup per CU suffices: 4 x rbs <= 256); EVK_DECODE_RB_SPLIT=0 disables
   static const int split_on = [] { const char* e = getenv("EVK_DECODE_RB_SPLIT"); return e ? atoi(e) : 1; }();
-  if (!w1_packed && sync_ws && split_on && 4 * rbs <= 256) {
-    p.sync_ctr = reinterpret_cast<unsigned*>(sync_ws);
+  p.rbs = rbs;
+  if (sync_ws && split_on && 4 * rbs <= 256) {
+    p.sync_ctr = reinterpret_cast<unsigned*>(sync_ws);                                                        // [2][rbs]
     p.sync_part = reinterpret_cast<float*>(reinterpret_cast<char*>(sync_ws) + (size_t)rbs * 256);
-    // (counters 64 unsigned apart would need rbs * 256 bytes: the kernel indexes them densely, the head of the buffer is theirs)
-    hipLaunchKernelGGL((decode_rowblock_kernel<false, 4>), dim3((unsigned)(4 * rbs)), dim3(NTH), 0, s, p);
+    p.sync_hid = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(sync_ws) + (size_t)rbs * 256 + (size_t)rbs * 4 * 2 * TMR * 4);
+    if (w1_packed) hipLaunchKernelGGL((decode_rowblock_kernel<true, 4>), dim3((unsigned)(4 * rbs)), dim3(NTH), 0, s, p);
+    else hipLaunchKernelGGL((decode_rowblock_kernel<false, 4>), dim3((unsigned)(4 * rbs)), dim3(NTH), 0, s, p);
   } else if (w1_packed) {
     hipLaunchKernelGGL((decode_rowblock_kernel<true, 1>), dim3((unsigned)rbs), dim3(NTH), 0, s, p);
   } else {

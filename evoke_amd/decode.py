@@ -378,7 +378,7 @@ class _DecoderState:
                 q = layer.src_attn.linears[0](n)
                 c = _attend1(q.view(-1, 1, d), self.kc[i], self.vc[i], h, self.src_mask)
                 x, n = fw.rowblock(c.view(-1, d), x, w['co'], w['co_b'], 3 * i + 2, deltas, sync=self.rb_sync)
-                x, n = fw.rowblock(n, x, w['w2'], w['b2'], 3 * (i + 1) if i + 1 < nl else None, deltas, w1=w['w1'], b1=w['b1'])
+                x, n = fw.rowblock(n, x, w['w2'], w['b2'], 3 * (i + 1) if i + 1 < nl else None, deltas, w1=w['w1'], b1=w['b1'], sync=self.rb_sync)
             n_final = n
         for i, layer in enumerate(model.decoder.layers if rb is None else ()):
             sa = layer.self_attn

@@ -290,7 +290,8 @@ def test_embedding_ids_outside_the_table_never_touch_memory():
 
 
 @pytest.mark.parametrize('R,ff,cond,split', [(256, False, True, True), (256, False, True, False), (256, True, True, False), (40, True, False, False),
-                                             (7, False, True, True), (7, False, True, False), (256, False, None, True), (200, False, False, True)])
+                                             (7, False, True, True), (7, False, True, False), (256, False, None, True), (200, False, False, True),
+                                             (256, True, True, True), (40, True, False, True), (7, True, True, True)])
 def test_decode_rowblock_projection_residual_and_next_norm(R, ff, cond, split):
     """C ABI: evk_decode_rowblock (csrc/decode_rb.hip) against fp32 torch math on the same 16-bit operands -- output projection / whole
     feed-forward + residual + the next R2Gen (conditional) layer norm (unbiased std, eps on the std: encoder_decoder.py:93-103, 144-179) in

@@ -419,8 +419,16 @@ def test_step_graphs_follow_eager_through_lr_changes_mixed_step_kinds_and_decode
             with torch.no_grad():
                 m_g(b[0].cuda(), b[1].cuda(), b[2].cuda(), np.array(b[3]), b[4], b[5], mode='inference')
             rm = m_g.text_decoder.model.rm
-            want = torch.cat([ops.shadow(rm.attn.linears[k].weight).view(512, 512) for k in range(3)], 0)
-            assert rm._qkv_cache is not None and torch.equal(rm._qkv_cache[1], want), 'decode ran on stale relational-memory weights'
+            # the derived weights the decode step ran on: the f32 stack of the (default) f32 recurrence, or the 16-bit q | k | v cache of the
+            # 16-bit recurrence (EVK_DECODE_RM_F32=0)
+            from evoke_amd import decode as DEC
+            if DEC._RM_F32[0]:
+                fw = m_g.text_decoder.model._evk_fused_decode[1]
+                want = torch.cat([rm.attn.linears[k].weight.detach().float() for k in range(3)], 0)
+                assert torch.equal(fw.rm32_wqkv, want), 'decode ran on stale relational-memory weights'
+            else:
+                want = torch.cat([ops.shadow(rm.attn.linears[k].weight).view(512, 512) for k in range(3)], 0)
+                assert rm._qkv_cache is not None and torch.equal(rm._qkv_cache[1], want), 'decode ran on stale relational-memory weights'
             qkv.append(want.float().clone())
             m_g.train()
         else:
