@@ -133,9 +133,12 @@ class GradReducer:
 
     def __init__(self, flat_grads, params, bucket_bytes=128 << 20, overlap=True, mode=None):
         self.flat, self.overlap = flat_grads, overlap
-        # default: 'direct' from 4 ranks up (a ring all-reduce of the 1.39 GB of FineTune gradients is bound by ONE xGMI
-        # link, ~16 ms; reduce-scatter + all-gather written as all-to-all uses all seven links at once, ~2.3 ms), the plain all-reduce below
-        self.mode = mode or os.environ.get('EVK_GRAD_SYNC') or ('direct' if world_size() >= 4 else 'allreduce')
+        # default 'allreduce': RCCL's own all-reduce (it picks its algorithm for the xGMI mesh).  'direct' -- reduce-scatter + all-gather written
+        # as one all_to_all_single (every rank sends chunk j straight to rank j: one transfer per point-to-point link, all seven at once) + a
+        # local sum + all_gather_into_tensor, 2.3 ms against ~16 ms for a ring on the 1.39 GB of FineTune gradients by SURVEY.md section 5's
+        # arithmetic -- is verified with gloo (two ranks, three modes) but has never met RCCL with more than one rank (no multi-GPU node was
+        # available to the builder), so it stays opt-in: EVK_GRAD_SYNC=direct on a node is the first thing to measure there.
+        self.mode = mode or os.environ.get('EVK_GRAD_SYNC') or 'allreduce'
         if self.mode not in ('allreduce', 'direct', '16bit'):
             raise ValueError('EVK_GRAD_SYNC must be allreduce, direct or 16bit')
         self.buckets = []          # (flat_index, start, end)

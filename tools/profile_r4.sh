@@ -1,0 +1,19 @@
+# round-4 evidence set: rocprofv3 kernel statistics of the default train workload (+ the one-step timeline) and of the decode workload,
+# then (mode "all") the PMC passes the traffic / roofline tables are built from.   usage: bash tools/profile_r4.sh <outdir-name> [all]
+set -x
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/${1:-r4prof}
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o st -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-decode --no-prof > $O/stats.log 2>&1
+python3 $R/tools/step_timeline.py $O/stats/st_kernel_trace.csv > $O/timeline.txt 2>&1
+EVK_DECODE_DEPTH=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/dstats -o ds -- python3 $R/bench.py --workload decode --steps 2 --warmup 1 --no-cpu-baseline > $O/dstats.log 2>&1
+if [ "$2" = "all" ]; then
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o f -- python3 $R/bench.py --steps 1 --warmup 1 --no-prof --no-cpu-baseline --no-decode > $O/fetch.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o w -- python3 $R/bench.py --steps 1 --warmup 1 --no-prof --no-cpu-baseline --no-decode > $O/write.log 2>&1
+  rocprofv3 --kernel-trace --pmc MfmaUtil --output-format csv -d $O/mfma -o m -- python3 $R/bench.py --steps 1 --warmup 1 --no-prof --no-cpu-baseline --no-decode > $O/mfma.log 2>&1
+fi
+rm -f $O/stats/st_kernel_trace.csv.tmp
+ls -la $O $O/stats | head -30
+du -sh $O
+head -60 $O/timeline.txt
