@@ -627,6 +627,28 @@ int evk_bn_finalize(const float* sum, const float* sumsq, const float* gamma, co
   return evk_check_launch("bn_finalize");
 }
 
+// Inference: the batch norm behind a convolution is a fixed affine map per output channel -- scale[c] = gamma / sqrt(var + eps),
+// shift[c] = beta - mean * scale -- which the convolution kernels apply to their f32 accumulators (evk_conv2d_fwd_affine): conv + BN (+ identity)
+// (+ ReLU) in one launch with ONE rounding to the storage type, the arithmetic of bn_finalize_channel's eval branch.
+__global__ __launch_bounds__(256) void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                                                             const float* __restrict__ var, float eps, float* __restrict__ scale, float* __restrict__ shift, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float is = rsqrtf(var[c] + eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  scale[c] = g * is;
+  shift[c] = b - mean[c] * g * is;
+}
+
+int evk_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, float* scale, float* shift,
+                       int32_t C, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(running_mean && running_var && scale && shift && C > 0, "bn_eval_coeffs: bad args");
+  ProfScope ps(EVK_FAM_REDUCE, s);
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((int)cdiv(C, 256)), dim3(256), 0, s, gamma, beta, running_mean, running_var, eps, scale, shift, (int)C);
+  return evk_check_launch("bn_eval_coeffs");
+}
+
 int evk_bn_bwd_sums_from_gate_partials(const float* part, int32_t nblk, const float* gamma, const float* beta, float* sum_g, float* sum_gx,
                                        float* dbeta_acc, float* dgamma_acc, int32_t C, const void* dz, const void* y, const float* mean,
                                        const float* invstd, int64_t M, evk_stream_t stream) {

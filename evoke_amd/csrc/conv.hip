@@ -238,6 +238,30 @@ int evk_conv2d_fwd_stats_tile(const void* x, const void* w, void* y, const evk_c
   return evk_gemm_launch(&d, stream);
 }
 
+// Inference form of a convolution of the trunk: y = relu?(conv(x, w) * scale[co] + bias[co] (+ resid)), the eval-mode batch norm (evk_bn_eval_coeffs)
+// applied to the f32 accumulators.  Routes: the weight-stationary / strip / halo kernels with their inference epilogues; the few geometries the tile
+// GEMM takes (stride-2 convolutions, Co = 64) are refused (EVK_EUNSUPPORTED) -- evk_conv2d_fwd_affine_routes tells, the caller runs conv + bn there.
+int evk_conv2d_fwd_affine(const void* x, const void* w, void* y, const evk_conv_geom* g, const float* scale, const float* bias, const void* resid,
+                          int32_t relu, evk_stream_t stream) {
+  if (int e = check_geom(g)) return e;
+  EVK_REQUIRE(x && w && y && scale && bias, "conv fwd affine: null operand");
+  const int64_t M = (int64_t)g->N * g->Ho * g->Wo;
+  if (use_ws(g, M, g->Ci, g->Co)) return evk_conv1x1_ws_fwd_affine(x, w, y, M, g->Ci, g->Co, scale, bias, resid, relu, stream);
+  if (is_pointwise(g) && evk_gemm_strip_routes(M, g->Co, g->Ci, 0, 0))
+    return evk_gemm_strip_affine(x, g->Ci, w, g->Ci, y, g->Co, M, g->Co, g->Ci, scale, bias, resid, g->Co, relu, stream);
+  if (evk_conv3x3_halo_routes(g, g->Ci, g->Co, 0, 0))
+    return evk_conv3x3_halo_affine(x, w, y, g->N, g->Hi, g->Wi, g->Ci, g->Co, scale, bias, resid, g->Co, relu, stream);
+  evk_set_error("conv fwd affine: no kernel with the inference epilogue takes this geometry (evk_conv2d_fwd_affine_routes)");
+  return EVK_EUNSUPPORTED;
+}
+
+// 1 when evk_conv2d_fwd_affine takes this geometry (every route but the tile GEMM)
+int evk_conv2d_fwd_affine_routes(const evk_conv_geom* g) {
+  if (!g || check_geom(g)) return 0;
+  const int64_t M = (int64_t)g->N * g->Ho * g->Wo;
+  return use_ws(g, M, g->Ci, g->Co) || (is_pointwise(g) && evk_gemm_strip_routes(M, g->Co, g->Ci, 0, 0)) || evk_conv3x3_halo_routes(g, g->Ci, g->Co, 0, 0) ? 1 : 0;
+}
+
 int evk_conv2d_dgrad(const void* dy, const void* w, void* dx, const evk_conv_geom* g, evk_stream_t stream) {
   return evk_conv2d_dgrad_add(dy, w, nullptr, dx, g, stream);
 }

@@ -56,9 +56,10 @@ struct WsP {
   const bf16_t* sx;     // dgrad: optional [M][N] second statistic operand: third partial row = sum over pixels of dx * (sx - smean)
   const float* smean;   // [N] per-channel offset of sx (the batch mean of the batch norm whose input sx is), or null
   long M; int N, ntiles, slices, groups;
+  const float* scale; const float* bias; int relu;   // forward, inference (eval-mode batch norm in the epilogue): y = relu?((x . w) * scale[n] + bias[n] (+ skip)); no statistics
 };
 
-template <int K, int NW, int MT, bool DGRAD, int NWV>
+template <int K, int NW, int MT, bool DGRAD, int NWV, int AFF = 0>       // AFF: the inference forward (1: scale / bias / ReLU epilogue, 2: + identity)
 __global__ __launch_bounds__(64 * NWV, 1) void conv1x1_ws_kernel(const WsP p) {
   constexpr int KS = K / 32, NT = NW / 16, LDA = K + 8;
   constexpr int NTHR = 64 * NWV;
@@ -121,7 +122,12 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv1x1_ws_kernel(const WsP p) {
     for (int c = 0; c < CH; ++c) {
       const int ch = tid + NTHR * c, r = ch / (K / 8), kc = ch % (K / 8);
       const long row = (long)t * MT + r;
-      pf[c] = row < p.M ? *reinterpret_cast<const uint4*>(p.x + row * K + kc * 8) : make_uint4(0, 0, 0, 0);
+      if (AFF == 2) {     // every load is issued (clamped row: the pixels beyond M are never stored) -- see the identity rows below
+        const long rc = row < p.M ? row : p.M - 1;
+        pf[c] = *reinterpret_cast<const uint4*>(p.x + rc * K + kc * 8);
+      } else {
+        pf[c] = row < p.M ? *reinterpret_cast<const uint4*>(p.x + row * K + kc * 8) : make_uint4(0, 0, 0, 0);
+      }
     }
   };
   auto stash = [&](int buf) {                          // registers -> LDS
@@ -151,17 +157,50 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv1x1_ws_kernel(const WsP p) {
     for (int j = 0; j < 4; ++j) { s0[nt][j] = 0.f; s1[nt][j] = 0.f; }
 #pragma unroll
   for (int k = 0; k < 8; ++k) tx[k] = 0.f;
+  constexpr int CPR = NW / 8;                           // 16-byte chunks per pixel row of the wave's NW channels
+  constexpr int NCH = (16 * CPR + 63) / 64;             // chunks per lane for a 16-pixel group
+  // inference forward with an identity (AFF == 2): its rows (the lane's 16 bytes of every 16-pixel group, in the layout the output leaves in)
+  // are requested a whole pixel tile ahead, into one register set per pixel group of the (fully unrolled) tile loop.  Asked for at the point
+  // of use, a dependent ~1 us load per group made the kernel 2-5 x slower than the plain forward; a rotating register queue is no better (a
+  // register MOVE of a load's destination waits for the load); and a predicated or branch-guarded load anywhere in the loop makes the
+  // compiler's wait-count bookkeeping fall back to s_waitcnt vmcnt(0) once per tile (the latency exposed again), so in this variant every
+  // load of the loop is issued unconditionally with a clamped address and the weights' loads are drained before the loop.
+  constexpr int RD = AFF == 2 ? MT / 16 : 1;
+  constexpr int UNR = AFF == 2 ? MT / 16 : 1;
+  uint4 rq[RD][NCH];
+  auto res_req = [&](uint4 (&dst)[NCH], int tile, int mt) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i, pr = (c / CPR) & 15, cc = c % CPR;
+      long prow = (long)tile * MT + mt * 16 + pr;
+      prow = prow < p.M ? prow : p.M - 1;
+      dst[i] = *reinterpret_cast<const uint4*>(p.skip + prow * p.N + n0 + cc * 8);
+    }
+  };
+  if (AFF == 2) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the resident weights and the first tile: nothing older than the queue below
+    const int t0 = t < p.ntiles ? t : p.ntiles - 1;
+#pragma unroll
+    for (int d = 0; d < RD; ++d) res_req(rq[d], t0, d);
+  }
+  // the eval-mode batch norm of the wave's channels (AFF): scale / shift of the 4 channels the lane holds per 16-channel block
+  float4 bsc[NT], bsh[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    bsc[nt] = AFF ? *reinterpret_cast<const float4*>(p.scale + n0 + nt * 16 + g * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+    bsh[nt] = AFF ? *reinterpret_cast<const float4*>(p.bias + n0 + nt * 16 + g * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   for (; t < p.ntiles; t += p.groups) {
     const int tn = t + p.groups;
-    if (tn < p.ntiles) fetch(tn);                      // in flight while this tile multiplies
+    const int tr = tn < p.ntiles ? tn : t;              // (AFF == 2) the tile whose rows are requested as this one's are consumed
+    if (AFF == 2) fetch(tr);
+    else if (tn < p.ntiles) fetch(tn);                 // in flight while this tile multiplies
     const bf16_t* at = abuf + cur * MT * LDA;
-#pragma unroll 1
+#pragma unroll UNR
     for (int mt = 0; mt < MT / 16; ++mt) {
       f32x4 acc[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      constexpr int CPR = NW / 8;                       // 16-byte chunks per pixel row of the wave's NW channels
-      constexpr int NCH = (16 * CPR + 63) / 64;         // chunks per lane for a 16-pixel group
       // data gradient: the skip / gate rows of this pixel group, whole rows, in flight while the group multiplies
       uint4 skv[NCH], gtv[NCH], sxv[NCH];
       if (DGRAD) {
@@ -197,6 +236,17 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv1x1_ws_kernel(const WsP p) {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
+      if (AFF == 2) {          // the identity rows of this pixel group (requested a tile ago) through the wave's transpose buffer, like the skip rows above
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          const int c = lane + 64 * i, pr = c / CPR, cc = c % CPR;
+          if (c < 16 * CPR) *reinterpret_cast<uint4*>(sw + pr * OST + cc * 8) = rq[AFF == 2 ? mt : 0][i];
+        }
+        res_req(rq[AFF == 2 ? mt : 0], tr, mt);          // this group's rows of the NEXT tile, into the registers just consumed
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
       // lane holds D[channel n0 + nt*16 + 4g + j][pixel t*MT + mt*16 + li]
       const long pix = (long)t * MT + mt * 16 + li;
 #pragma unroll
@@ -214,6 +264,21 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv1x1_ws_kernel(const WsP p) {
           } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = 0.f;
+          }
+        } else if (AFF) {
+          // bit for bit the arithmetic of the unfused eval forward (this kernel's rounded output -> bn_apply_kernel: fma(x, scale, shift) +
+          // identity, ReLU, one more rounding): a batch whose size sends a layer down another route then decodes to the same tokens
+          const float4 bb = bsh[nt], sc = bsc[nt];
+          const uint32_t r01 = pack2bf(v[0], v[1]), r23 = pack2bf(v[2], v[3]);
+          v[0] = __builtin_fmaf(lo_bf(r01), sc.x, bb.x); v[1] = __builtin_fmaf(hi_bf(r01), sc.y, bb.y);
+          v[2] = __builtin_fmaf(lo_bf(r23), sc.z, bb.z); v[3] = __builtin_fmaf(hi_bf(r23), sc.w, bb.w);
+          if (AFF == 2) {
+            const uint2 sk = *reinterpret_cast<const uint2*>(sw + li * OST + nt * 16 + g * 4);
+            v[0] += lo_bf(sk.x); v[1] += hi_bf(sk.x); v[2] += lo_bf(sk.y); v[3] += hi_bf(sk.y);
+          }
+          if (p.relu) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
           }
         } else {
 #pragma unroll
@@ -246,7 +311,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv1x1_ws_kernel(const WsP p) {
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    if (tn < p.ntiles) stash(cur ^ 1);
+    if (AFF == 2 || tn < p.ntiles) stash(cur ^ 1);
     __syncthreads();
     cur ^= 1;
   }
@@ -278,13 +343,13 @@ __global__ __launch_bounds__(64 * NWV, 1) void conv1x1_ws_kernel(const WsP p) {
   }
 }
 
-template <int K, int NW, int MT, bool DGRAD, int NWV>
+template <int K, int NW, int MT, bool DGRAD, int NWV, int AFF = 0>
 int launch_ws(WsP p, hipStream_t s) {
   const size_t abuf = std::max((size_t)2 * MT * (K + 8), DGRAD ? (size_t)ws_kc(K, MT, NWV * NW + 8) * (NWV * NW + 8) : (size_t)0);
   const size_t lds = abuf * 2 + (size_t)(DGRAD ? 2 : 1) * NWV * 16 * (NW + 8) * 2;
   static bool configured = false;
   if (!configured && lds > 65536) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_ws_kernel<K, NW, MT, DGRAD, NWV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_ws_kernel<K, NW, MT, DGRAD, NWV, AFF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       evk_set_error("conv1x1_ws: hipFuncSetAttribute failed");
       return EVK_ELAUNCH;
     }
@@ -299,27 +364,27 @@ int launch_ws(WsP p, hipStream_t s) {
   p.groups = groups;
   ProfScope ps(EVK_FAM_GEMM, s, 2.0 * (double)p.M * p.N * K);
   evk_prof_tag((int)p.M, p.N, K, 1, 0, DGRAD ? 1 : 0);
-  hipLaunchKernelGGL((conv1x1_ws_kernel<K, NW, MT, DGRAD, NWV>), dim3(p.slices * groups), dim3(64 * NWV), lds, s, p);
+  hipLaunchKernelGGL((conv1x1_ws_kernel<K, NW, MT, DGRAD, NWV, AFF>), dim3(p.slices * groups), dim3(64 * NWV), lds, s, p);
   return evk_check_launch("conv1x1_ws");
 }
 
-template <bool DGRAD>
+template <bool DGRAD, int AFF = 0>
 int dispatch(const WsP& p, int K, hipStream_t s) {
   static const int v8 = [] { const char* e = getenv("EVK_WS_WAVES8"); return e ? atoi(e) : 1; }();
   if (v8) switch (K) {          // 8 waves x 32 channels (2 waves per SIMD hide the LDS / store latency of the per-16-pixel epilogue)
-    case 64: return launch_ws<64, 32, 128, DGRAD, 8>(p, s);
-    case 128: return launch_ws<128, 32, 128, DGRAD, 8>(p, s);
-    case 256: return launch_ws<256, 32, 128, DGRAD, 8>(p, s);
-    case 512: return launch_ws<512, 16, 64, DGRAD, 8>(p, s);
-    case 1024: return launch_ws<1024, 16, 32, DGRAD, 8>(p, s);
+    case 64: return launch_ws<64, 32, 128, DGRAD, 8, AFF>(p, s);
+    case 128: return launch_ws<128, 32, 128, DGRAD, 8, AFF>(p, s);
+    case 256: return launch_ws<256, 32, 128, DGRAD, 8, AFF>(p, s);
+    case 512: return launch_ws<512, 16, 64, DGRAD, 8, AFF>(p, s);
+    case 1024: return launch_ws<1024, 16, 32, DGRAD, 8, AFF>(p, s);
     default: break;
   }
   switch (K) {
-    case 64: return launch_ws<64, 64, 128, DGRAD, 4>(p, s);
-    case 128: return launch_ws<128, 64, 128, DGRAD, 4>(p, s);
-    case 256: return launch_ws<256, 64, 128, DGRAD, 4>(p, s);
-    case 512: return launch_ws<512, 32, 64, DGRAD, 4>(p, s);
-    case 1024: return launch_ws<1024, 16, 32, DGRAD, 8>(p, s);
+    case 64: return launch_ws<64, 64, 128, DGRAD, 4, AFF>(p, s);
+    case 128: return launch_ws<128, 64, 128, DGRAD, 4, AFF>(p, s);
+    case 256: return launch_ws<256, 64, 128, DGRAD, 4, AFF>(p, s);
+    case 512: return launch_ws<512, 32, 64, DGRAD, 4, AFF>(p, s);
+    case 1024: return launch_ws<1024, 16, 32, DGRAD, 8, AFF>(p, s);
     default: evk_set_error("conv1x1_ws: unsupported K = %d", K); return EVK_EINVAL;
   }
 }
@@ -354,8 +419,18 @@ int evk_conv1x1_ws_fwd(const void* x, const void* w, void* y, int64_t M, int32_t
   EVK_REQUIRE(x && w && y && evk_conv1x1_ws_supported(M, K, N), "conv1x1_ws_fwd: unsupported problem M=%ld K=%d N=%d", (long)M, K, N);
   EVK_REQUIRE(!part || (nblk && part_bytes >= evk_conv1x1_ws_part_bytes(M, K, N)), "conv1x1_ws_fwd: statistics buffer too small");
   if (part) *nblk = ws_groups(M, K, N);
-  WsP p{(const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, nullptr, nullptr, part, nullptr, nullptr, M, N, 0, 0, 0};
+  WsP p{(const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, nullptr, nullptr, part, nullptr, nullptr, M, N, 0, 0, 0, nullptr, nullptr, 0};
   return dispatch<false>(p, K, reinterpret_cast<hipStream_t>(stream));
+}
+
+/* inference form of the forward (eval-mode batch norm as per-channel scale / shift): y = relu?((x . w^T) * scale[n] + bias[n] (+ resid[m][n])) */
+int evk_conv1x1_ws_fwd_affine(const void* x, const void* w, void* y, int64_t M, int32_t K, int32_t N, const float* scale, const float* bias,
+                              const void* resid, int32_t relu, evk_stream_t stream) {
+  EVK_REQUIRE(x && w && y && scale && bias && evk_conv1x1_ws_supported(M, K, N), "conv1x1_ws_fwd_affine: unsupported problem M=%ld K=%d N=%d", (long)M, K, N);
+  EVK_REQUIRE(((reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(scale)) & 15) == 0 && (!resid || (reinterpret_cast<uintptr_t>(resid) & 15) == 0),
+              "conv1x1_ws_fwd_affine: 16-byte aligned scale / bias / residual");
+  WsP p{(const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, (const bf16_t*)resid, nullptr, nullptr, nullptr, nullptr, M, N, 0, 0, 0, scale, bias, relu};
+  return resid ? dispatch<false, 2>(p, K, reinterpret_cast<hipStream_t>(stream)) : dispatch<false, 1>(p, K, reinterpret_cast<hipStream_t>(stream));
 }
 
 /* dx[M][N] = gate(dy[M][K] . W[K][N] + skip): W as the forward stores it, [K = Co][N = Ci] */
@@ -373,7 +448,7 @@ int evk_conv1x1_ws_dgrad_xstat(const void* dy, const void* wt, const void* skip,
   EVK_REQUIRE(!part || (gate && nblk && part_bytes >= need), "conv1x1_ws_dgrad: gate statistics need a gate and a large enough buffer");
   EVK_REQUIRE(!stat_x || part, "conv1x1_ws_dgrad: stat_x needs the partials buffer");
   if (part) *nblk = ws_groups(M, K, N);
-  WsP p{(const bf16_t*)dy, (const bf16_t*)wt, (bf16_t*)dx, (const bf16_t*)skip, (const bf16_t*)gate, part, (const bf16_t*)stat_x, stat_mean, M, N, 0, 0, 0};
+  WsP p{(const bf16_t*)dy, (const bf16_t*)wt, (bf16_t*)dx, (const bf16_t*)skip, (const bf16_t*)gate, part, (const bf16_t*)stat_x, stat_mean, M, N, 0, 0, 0, nullptr, nullptr, 0};
   return dispatch<true>(p, K, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -59,6 +59,7 @@ struct C3P {
   unsigned long long* stamps;      // diagnostic (evk_conv3x3_halo_debug_stamps): per workgroup {memtime x 4, memrealtime x 2} or null
   float inv_w, inv_w2, inv_h, inv_h1;
   int kmul;                        // 1; 0 = timing probe (EVK_C3_PROBE=1): every in-loop load reads the step-0 addresses (cache hits, wrong results)
+  const float* scale; const float* bias; int relu;     // inference (eval-mode batch norm): y = relu?(conv * scale[co] + bias[co] (+ resid)); no gate, no statistics
 };
 
 // a / b for 0 <= a < 2^22, b > 0, inv = 1 / b (integer division proper costs ~40 instructions per use on this ISA)
@@ -303,6 +304,33 @@ __global__ __launch_bounds__(NTH, 2) void conv3x3_halo_kernel(const C3P p) {
         *reinterpret_cast<float4*>(prow + Co + n0) = make_float4(sq[0], sq[1], sq[2], sq[3]);
       }
     }
+  }
+  if (p.bias) {
+    // inference: eval-mode batch norm as scale / shift (+ identity), ReLU
+#pragma unroll
+    for (int in = 0; in < NI; ++in) {
+      const int n0 = co0 + wn * (16 * NI) + in * 16 + fq * 4;
+      const float4 bb = *reinterpret_cast<const float4*>(p.bias + n0);
+      const float4 sc = *reinterpret_cast<const float4*>(p.scale + n0);
+#pragma unroll
+      for (int im = 0; im < MI; ++im) {
+        if (!rowok[im]) continue;
+        const long m = m0 + wm * (16 * MI) + im * 16 + frow;
+        // bit for bit the unfused eval forward: this kernel's ROUNDED output -> bn_apply_kernel's fma(x, scale, shift) + identity, ReLU
+        const uint32_t r01 = pack2bf(acc[in][im][0], acc[in][im][1]), r23 = pack2bf(acc[in][im][2], acc[in][im][3]);
+        float v[4] = {__builtin_fmaf(lo_bf(r01), sc.x, bb.x), __builtin_fmaf(hi_bf(r01), sc.y, bb.y), __builtin_fmaf(lo_bf(r23), sc.z, bb.z), __builtin_fmaf(hi_bf(r23), sc.w, bb.w)};
+        if (p.resid) {
+          const uint2 t = *reinterpret_cast<const uint2*>(p.resid + m * p.ldr + n0);
+          v[0] += lo_bf(t.x); v[1] += hi_bf(t.x); v[2] += lo_bf(t.y); v[3] += hi_bf(t.y);
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        *reinterpret_cast<uint2*>(p.y + m * Co + n0) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+      }
+    }
+    return;
   }
   if (!p.gate && !p.resid) {
     // forward convolution: nothing but the rounded result leaves -- one row pointer per MFMA tile row, no per-tile branches
@@ -712,6 +740,29 @@ int evk_conv3x3_halo(const void* x, const void* w, void* y, int32_t N, int32_t H
     EVK_REQUIRE(nblk && part_bytes >= evk_conv3x3_halo_part_bytes(N, H, W, Co), "conv3x3_halo: statistics buffer too small");
     *nblk = p.tilesM * WM;
   }
+  evk_prof_tag(N * H * W, Co, 9 * C, 1, EVK_A_CONV, EVK_B_PLAIN);
+  ProfScope ps(EVK_FAM_GEMM, s, 2.0 * N * H * W * (double)Co * 9 * C);
+  return wide ? launch_halo<Cfg128>(p, s) : launch_halo<Cfg64>(p, s);
+}
+
+/* inference form (eval-mode batch norm as per-channel scale / shift): y = relu?(conv3x3(x, w) * scale[co] + bias[co] (+ resid)) */
+int evk_conv3x3_halo_affine(const void* x, const void* w, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t Co, const float* scale,
+                            const float* bias, const void* resid, int64_t ldr, int32_t relu, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(x && w && y && scale && bias, "conv3x3_halo_affine: null operand");
+  EVK_REQUIRE(evk_conv3x3_halo_supported(N, H, W, C, Co), "conv3x3_halo_affine: unsupported shape N=%d H=%d W=%d C=%d Co=%d", N, H, W, C, Co);
+  EVK_REQUIRE(al16(x) && al16(w) && al16(y) && al16(scale) && al16(bias) && (!resid || (al16(resid) && ldr % 4 == 0 && ldr >= Co)), "conv3x3_halo_affine: alignment / leading dimension");
+  const bool wide = wide_tiles(Co);
+  C3P p{};
+  p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.y = (bf16_t*)y;
+  p.N = N; p.H = H; p.W = W; p.C = C; p.Co = Co;
+  p.R = choose_rows(N, H, W, halo_max_for(Co));
+  p.tilesM = (int)cdiv((int64_t)N * H, p.R);
+  p.tilesN = Co / (wide ? Cfg128::TN : Cfg64::TN);
+  p.resid = (const bf16_t*)resid; p.ldr = ldr;
+  p.kmul = 1;
+  p.inv_w = 1.f / W; p.inv_w2 = 1.f / (W + 2); p.inv_h = 1.f / H; p.inv_h1 = 1.f / (H + 1);
+  p.scale = scale; p.bias = bias; p.relu = relu;
   evk_prof_tag(N * H * W, Co, 9 * C, 1, EVK_A_CONV, EVK_B_PLAIN);
   ProfScope ps(EVK_FAM_GEMM, s, 2.0 * N * H * W * (double)Co * 9 * C);
   return wide ? launch_halo<Cfg128>(p, s) : launch_halo<Cfg64>(p, s);

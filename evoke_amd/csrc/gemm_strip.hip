@@ -40,6 +40,7 @@ struct StP {
   float* gatestats;                // [tilesM * WM][2][N] or null (needs gate)
   const void* zeros;
   unsigned kmul;                   // 128; 0 = timing probe (EVK_STRIP_PROBE=1): every load re-reads K step 0 (cache hits, wrong results)
+  const float* scale; const float* bias; int relu;     // inference (eval-mode batch norm): C = relu?((A . B^T) * scale[n] + bias[n] (+ resid)); no gate, no statistics
 };
 
 template <int CTRL>
@@ -202,6 +203,32 @@ __global__ __launch_bounds__(NTH, 2) void gemm_strip_kernel(const StP p) {
       }
     }
   }
+  if (p.bias) {
+#pragma unroll
+    for (int in = 0; in < NI; ++in) {
+      const int n0 = col0 + wn * (16 * NI) + in * 16 + fq * 4;
+      const float4 bb = *reinterpret_cast<const float4*>(p.bias + n0);
+      const float4 sc = *reinterpret_cast<const float4*>(p.scale + n0);
+#pragma unroll
+      for (int im = 0; im < MI; ++im) {
+        if (!rowok[im]) continue;
+        const long m = (long)row0 + wm * (16 * MI) + im * 16 + frow;
+        // bit for bit the unfused eval forward: this kernel's ROUNDED output -> bn_apply_kernel's fma(x, scale, shift) + identity, ReLU
+        const uint32_t r01 = pack2bf(acc[in][im][0], acc[in][im][1]), r23 = pack2bf(acc[in][im][2], acc[in][im][3]);
+        float v[4] = {__builtin_fmaf(lo_bf(r01), sc.x, bb.x), __builtin_fmaf(hi_bf(r01), sc.y, bb.y), __builtin_fmaf(lo_bf(r23), sc.z, bb.z), __builtin_fmaf(hi_bf(r23), sc.w, bb.w)};
+        if (p.resid) {
+          const uint2 t = *reinterpret_cast<const uint2*>(p.resid + m * p.ldr + n0);
+          v[0] += lo_bf(t.x); v[1] += hi_bf(t.x); v[2] += lo_bf(t.y); v[3] += hi_bf(t.y);
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        *reinterpret_cast<uint2*>(p.C + m * p.ldc + n0) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+      }
+    }
+    return;
+  }
   if (!p.gate && !p.resid) {
     // forward convolution: nothing but the rounded product leaves -- one row pointer per MFMA tile row, no per-tile branches
     char* const cb = reinterpret_cast<char*>(p.C) + (((long)row0 + wm * (16 * MI) + frow) * p.ldc + col0 + wn * (16 * NI) + fq * 4) * 2;
@@ -311,6 +338,36 @@ int evk_gemm_strip(const void* A, int64_t lda, const void* B, int64_t ldb, void*
   p.zeros = zeros;
   static const int probe = [] { const char* e = getenv("EVK_STRIP_PROBE"); return e ? atoi(e) : 0; }();
   p.kmul = probe ? 0u : 128u;
+  evk_prof_tag((int)M, N, K, 1, EVK_A_PLAIN, EVK_B_PLAIN);
+  ProfScope ps(EVK_FAM_GEMM, s, 2.0 * M * (double)N * K);
+  hipLaunchKernelGGL(gemm_strip_kernel, dim3(tilesM * p.tilesN), dim3(NTH), LDS_BYTES, s, p);
+  return evk_check_launch("gemm_strip_kernel");
+}
+
+/* inference form (eval-mode batch norm as per-column scale / shift): C = relu?((A . B^T) * scale[n] + bias[n] (+ resid)) */
+int evk_gemm_strip_affine(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int32_t N, int32_t K,
+                          const float* scale, const float* bias, const void* resid, int64_t ldr, int32_t relu, evk_stream_t stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  EVK_REQUIRE(A && B && C && scale && bias, "gemm_strip_affine: null operand");
+  EVK_REQUIRE(evk_gemm_strip_supported(M, N, K), "gemm_strip_affine: unsupported shape M=%ld N=%d K=%d (N %% 128, K %% 64)", (long)M, N, K);
+  EVK_REQUIRE(al16(A) && al16(B) && al16(C) && al16(scale) && al16(bias) && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && lda >= K && ldb >= K && ldc >= N &&
+              (!resid || (al16(resid) && ldr % 4 == 0 && ldr >= N)), "gemm_strip_affine: alignment / leading dimensions");
+  StP p{};
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = (bf16_t*)C;
+  p.M = (int)M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.tilesN = N / TN;
+  const int tilesM = (int)cdiv(M, TM);
+  p.resid = (const bf16_t*)resid; p.ldr = ldr;
+  p.scale = scale; p.bias = bias; p.relu = relu;
+  static void* zeros = nullptr;
+  static bool attr_done = false;
+  if (!attr_done) {
+    EVK_REQUIRE(hipGetSymbolAddress(&zeros, HIP_SYMBOL(g_zero16)) == hipSuccess && zeros, "gemm_strip: no address for the zero block");
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_strip_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    attr_done = true;
+  }
+  p.zeros = zeros;
+  p.kmul = 128u;
   evk_prof_tag((int)M, N, K, 1, EVK_A_PLAIN, EVK_B_PLAIN);
   ProfScope ps(EVK_FAM_GEMM, s, 2.0 * M * (double)N * K);
   hipLaunchKernelGGL(gemm_strip_kernel, dim3(tilesM * p.tilesN), dim3(NTH), LDS_BYTES, s, p);

@@ -327,6 +327,17 @@ int evk_replay_run(void* plan, evk_stream_t stream) {
   return evk_check_launch("replay_run");
 }
 
+/* `n` consecutive replays of the step from ONE call: the decode's token loop needs no host decision between steps (the beam bookkeeping
+ * is a kernel of the step), so a host thread hands the whole remaining search to the launch queue here and the interpreter is not part
+ * of the per-token path.  Blocks at the pace of the GPU once the launch queue is full -- call it from a thread that may wait. */
+int evk_replay_run_n(void* plan, evk_stream_t stream, int32_t n) {
+  for (int32_t i = 0; i < n; ++i) {
+    const int rc = evk_replay_run(plan, stream);
+    if (rc != EVK_OK) return rc;
+  }
+  return EVK_OK;
+}
+
 int evk_replay_destroy(void* plan) {
   Plan* p = reinterpret_cast<Plan*>(plan);
   if (!p) return EVK_OK;

@@ -67,6 +67,32 @@ int evk_set_seed_epoch(const uint64_t* epoch_dev) {
 }
 
 int evk_version(void) { return 101; }
+
+/* A HIP stream whose kernels may only run on the compute units whose bit is set in `mask` (bit i of word i / 32; `words` x 32 bits, at
+ * least the device's CU count).  The serving loop gives the ENCODER stream such a mask: a convolution grid otherwise occupies every CU, and
+ * the ~10 us kernels of the searches in flight then wait for a workgroup slot behind 50-100 us tiles (measured: 4-5 x their lone
+ * duration).  The stream lives until evk_stream_destroy.  *stream_out is a hipStream_t. */
+int evk_stream_create_cu_mask(const uint32_t* mask, int32_t words, void** stream_out) {
+  EVK_REQUIRE(mask && stream_out && words > 0, "stream_create_cu_mask: bad args");
+  hipStream_t s = nullptr;
+  const hipError_t err = hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask);
+  if (err != hipSuccess) { evk_set_error("stream_create_cu_mask: %s", hipGetErrorString(err)); return EVK_ELAUNCH; }
+  *stream_out = s;
+  return EVK_OK;
+}
+
+int evk_stream_destroy(void* stream) {
+  if (stream && hipStreamDestroy(reinterpret_cast<hipStream_t>(stream)) != hipSuccess) { evk_set_error("stream_destroy failed"); return EVK_ELAUNCH; }
+  return EVK_OK;
+}
+
+int evk_device_cu_count(int32_t device, int32_t* cus) {
+  EVK_REQUIRE(cus, "device_cu_count: bad args");
+  hipDeviceProp_t pr;
+  if (hipGetDeviceProperties(&pr, device) != hipSuccess) { evk_set_error("device_cu_count: hipGetDeviceProperties failed"); return EVK_ELAUNCH; }
+  *cus = pr.multiProcessorCount;
+  return EVK_OK;
+}
 int evk_storage_format(void) {
 #ifdef EVK_STORE_F16
   return 16;

@@ -10,6 +10,7 @@ as state, the per-position conditional-LayerNorm inputs taken from the current m
 """
 import ctypes as C
 import os
+import threading
 import math
 
 import torch
@@ -65,16 +66,22 @@ def _graph_pool(dev, slot=0):
     return _pools[key]
 
 
+_plans_lock = threading.Lock()    # (searches driven by host threads end at the same time)
+
+
 def _reap_plans(force=False):
+    with _plans_lock:
+        retired, _PLANS[:] = list(_PLANS), []
     keep = []
-    for plan, graph, ev in _PLANS:
+    for plan, graph, ev in retired:
         if force or ev.query():
             if force:
                 ev.synchronize()
             H.lib.evk_replay_destroy(plan)
         else:
             keep.append((plan, graph, ev))
-    _PLANS[:] = keep
+    with _plans_lock:
+        _PLANS.extend(keep)
 
 
 def _topk(x, k):
@@ -522,10 +529,11 @@ class _BeamSession:
         except StopIteration as e:
             return e.value
 
-    def run_iter(self, enc, src_mask, return_scores=False, step_hook=None):
+    def run_iter(self, enc, src_mask, return_scores=False, step_hook=None, burst=0):
         """_run_iter under eval mode and no_grad for as long as the generator RUNS (a generator's body executes at next(), long after
-        beam_search's own eval / no_grad scope has been left)"""
-        it = self._run_iter(enc, src_mask, return_scores, step_hook)
+        beam_search's own eval / no_grad scope has been left; no_grad is per THREAD: the scope is opened around every next(), whichever
+        thread calls it)"""
+        it = self._run_iter(enc, src_mask, return_scores, step_hook, burst)
         dec = self.dec
         while True:
             # (nn.Module.eval / train walk the whole module tree: only when the decoder really is in training mode -- the serving loop
@@ -543,10 +551,13 @@ class _BeamSession:
                     dec.train(True)
             yield v
 
-    def _run_iter(self, enc, src_mask, return_scores=False, step_hook=None):
+    def _run_iter(self, enc, src_mask, return_scores=False, step_hook=None, burst=0):
         """run() as a generator that yields after every issued token step: a scheduler that drives several sessions (one per HIP stream)
-        round-robin keeps all their launch queues fed (FineTune.generate_pipelined) -- issuing one session's ~6k launches in one go
-        blocks the host at the GPU's pace, because a launch queue is finite."""
+        round-robin keeps all their launch queues fed (FineTune.generate_pipelined) -- issuing one session's ~3k launches in one go
+        blocks the host at the GPU's pace, because a launch queue is finite.
+        burst > 0 (and a replay plan, no step hook): yields -1 once everything in front of the token loop has been issued, then issues the
+        loop `burst` steps per native call (evk_replay_run_n: no interpreter between the steps) -- the form a per-search host THREAD drives:
+        ctypes drops the GIL for the call, so the thread may block on a full launch queue while the others keep issuing."""
         dec, B, beam, max_len, R = self.dec, self.B, self.beam, self.max_len, self.R
         dev, V1 = enc.device, dec.vocab_size + 1
         hook = step_hook if step_hook is not None else (lambda *a: None)
@@ -642,7 +653,8 @@ class _BeamSession:
                         # (a pool of the session's own: searches in flight at the same time replay concurrently, and a handle must not
                         # outlive the last graph that used it)
                         self.pool = torch.cuda.graph_pool_handle()
-                        graph.capture_begin(pool=self.pool)
+                        # (thread_local: the worker threads of generate_pipelined download results / record events on OTHER streams meanwhile)
+                        graph.capture_begin(pool=self.pool, capture_error_mode='thread_local')
                         try:
                             self._body()
                         finally:
@@ -667,9 +679,18 @@ class _BeamSession:
                         H.check(H.lib.evk_replay_info(self.plan, info), 'replay_info')
                         self.step_launches = int(info[1])                 # kernel nodes of ONE captured token step
             stats['step_launches'] = getattr(self, 'step_launches', None)
+            bursts = burst > 0 and self.plan is not None and step_hook is None
+            if bursts:
+                yield -1
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-            for it_ in range(done, n_body):
+            it_ = done
+            while bursts and it_ < n_body:
+                n = min(int(burst), n_body - it_)
+                H.check(H.lib.evk_replay_run_n(self.plan, H.stream(), n), 'replay_run_n')
+                it_ += n
+                yield it_ - 1
+            for it_ in range(it_, n_body):
                 if self.plan is not None:
                     H.check(H.lib.evk_replay_run(self.plan, H.stream()), 'replay_run')
                 elif self.graph is not None:
@@ -705,12 +726,13 @@ def _session_ok(dec, args, enc):
 
 
 @torch.no_grad()
-def beam_search(dec, enc_states, enc_mask, args, return_scores=False, step_hook=None, slot=0, as_iterator=False):
+def beam_search(dec, enc_states, enc_mask, args, return_scores=False, step_hook=None, slot=0, as_iterator=False, burst=0):
     """-> (B, max_seq_len) int64 token ids padded with [PAD] (= AttModel._sample_beam with sample_n = 1).
     step_hook(t, logp, beam_sum): test instrument, called on the launching stream right before the bookkeeping of position t consumes
     `logp` (f32, one row of >= V+1 log-probabilities per live hypothesis; may be edited in place) with the running sums (B, beam).
     slot: which of the decoder's persistent sessions to use (searches that are in flight at the same time need different slots);
-    as_iterator: return a generator that yields after every issued token step and returns the result (see _BeamSession.run_iter)."""
+    as_iterator: return a generator that yields after every issued token step and returns the result (see _BeamSession.run_iter);
+    burst: with as_iterator, token steps per native call (see _BeamSession._run_iter)."""
     if not _session_ok(dec, args, enc_states):
         if as_iterator:
             raise NotImplementedError('stepwise beam search needs the session path')
@@ -734,7 +756,7 @@ def beam_search(dec, enc_states, enc_mask, args, return_scores=False, step_hook=
                 sessions.pop(next(iter(sessions)))
         sessions[key] = ses
         if as_iterator:
-            return ses.run_iter(enc, src_mask, return_scores, step_hook)
+            return ses.run_iter(enc, src_mask, return_scores, step_hook, burst)
         return ses.run(enc, src_mask, return_scores, step_hook)
     finally:
         dec.train(was_training)

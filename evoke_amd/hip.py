@@ -112,6 +112,35 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_masked_streams = {}
+
+
+def masked_stream(device, reserve):
+    """torch stream (process lifetime, cached) whose kernels stay off `reserve` of every 32 compute units: the stream for full-GPU grids
+    that must leave room for another stream's small latency-bound kernels (evk_stream_create_cu_mask).  The cleared bits are the top
+    `reserve` / 8 of every 4 consecutive groups of 8 CU indices: the same share of every XCD whether the runtime enumerates the CUs
+    XCD-major or round-robin over the 8 XCDs.  reserve: 0 (no mask), 8, 16 or 24."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if reserve not in (8, 16, 24):
+        raise ValueError('masked_stream: reserve must be 8, 16 or 24 of every 32 CUs')
+    key = (idx, reserve)
+    if key not in _masked_streams:
+        n = C.c_int32(0)
+        check(lib.evk_device_cu_count(idx, C.byref(n)), 'device_cu_count')
+        words = (n.value + 31) // 32
+        mask = (C.c_uint32 * words)()
+        keep_groups = 4 - reserve // 8
+        for i in range(n.value):
+            if (i // 8) % 4 < keep_groups:
+                mask[i // 32] |= 1 << (i % 32)
+        out = C.c_void_p()
+        with torch.cuda.device(idx):
+            check(lib.evk_stream_create_cu_mask(mask, words, C.byref(out)), 'stream_create_cu_mask')
+        _masked_streams[key] = torch.cuda.ExternalStream(out.value, device=idx)
+    return _masked_streams[key]
+
+
 def ptr(t):
     return t.data_ptr() if t is not None else None
 

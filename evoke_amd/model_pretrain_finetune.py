@@ -168,8 +168,9 @@ class FineTune(_Base):
         """forward(..., mode=mode) over a sequence of batches, as a generator of its return values, with the device kept busy across
         batches.  The decode of a batch is a chain of ~100 x ~56 small dependent kernels: latency bound, most of the GPU idles while it
         runs, and the host can only issue it at the GPU's pace (a launch queue is finite).  So `depth` batches are decoded at the same time,
-        each on its own high-priority HIP stream with its own persistent beam session, the host issuing their token steps round-robin;
-        the visual extractor / fusion / text encoders of the following batch are queued on a further stream in between.  Per batch the
+        each on its own high-priority HIP stream with its own persistent beam session and its own host thread, which hands the whole token
+        loop to the launch queue from native code (evk_replay_run_n: the interpreter is not on the per-token path, the GIL is free);
+        this thread meanwhile queues the visual extractor / fusion / text encoders of the following batch on a further stream.  Per batch the
         kernels, their order and therefore the results are exactly those of forward() (tests/test_model_gpu.py).  batches: iterable of
         (images, report_ids, report_masks, patient_ids, inc_ids, inc_masks); r2gen decoder only.  depth: EVK_DECODE_DEPTH or 2."""
         import os
@@ -180,10 +181,26 @@ class FineTune(_Base):
             raise NotImplementedError('generate_pipelined: the r2gen decoder backend')
         from .decode import beam_search
         depth = max(1, int(depth if depth is not None else os.environ.get('EVK_DECODE_DEPTH', '2')))
+        # EVK_DECODE_THREADS=1 (default): one host thread per search in flight issues its token loop (evk_replay_run_n, GIL released);
+        # 0: this thread issues the token steps of all searches round-robin
+        threaded = os.environ.get('EVK_DECODE_THREADS', '1') != '0'
+        burst = max(1, int(os.environ.get('EVK_DECODE_BURST', '8')))          # token steps per native call ...
+        ahead = max(1, int(os.environ.get('EVK_DECODE_AHEAD', '2')))          # ... and bursts a search may be ahead of the GPU
+        pool = None
+        if threaded:
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(max_workers=depth, thread_name_prefix='evk-decode')
+        dev = torch.cuda.current_device()
         was_training = self.training
         self.eval()
         cur = torch.cuda.current_stream()
-        enc_s = torch.cuda.Stream()
+        # EVK_ENC_RESERVE_CUS = 8 / 16 / 24: the encoder stream keeps off that many of every 32 compute units (hip.masked_stream).  A
+        # convolution grid fills every CU and the searches' ~10 us kernels then queue behind its tiles for a workgroup slot (4-5 x their lone
+        # duration); measured on the decode workload, though, the encoders lose more than the searches gain -- 117 k tokens/s without a
+        # mask, 103 / 91 / 67 k with 8 / 16 / 24 reserved: the pipeline is bound by the sum of the GPU work, not by the chains' latency -- so
+        # the default is 0 (no mask)
+        reserve = int(os.environ.get('EVK_ENC_RESERVE_CUS', '0'))
+        enc_s = H.masked_stream(cur.device, reserve) if reserve > 0 else torch.cuda.Stream()
         # the decode chains are latency bound: their small kernels go first.  (EVK_DECODE_PRIO: comma list of stream priorities)
         prios = [int(v) for v in os.environ.get('EVK_DECODE_PRIO', '').split(',') if v.strip() != '']
         dec_s = [torch.cuda.Stream(priority=(prios[i] if i < len(prios) else -1)) for i in range(depth)]
@@ -206,17 +223,23 @@ class FineTune(_Base):
             return x, enc_mask, ev, report_ids
 
         def start(enc, slot):
-            """-> [slot, generator of the stepwise search, report ids, result or None]"""
+            """-> [slot, generator of the stepwise search, report ids, result or None, host copy of the result, future]"""
             x, enc_mask, ev, report_ids = enc
             with torch.cuda.stream(dec_s[slot]):
                 dec_s[slot].wait_event(ev)
                 x.record_stream(dec_s[slot])
                 enc_mask.record_stream(dec_s[slot])
                 try:
-                    gen = beam_search(self.text_decoder, x, enc_mask, self.args, slot=slot, as_iterator=True)
-                    return [slot, gen, report_ids, None]
+                    gen = beam_search(self.text_decoder, x, enc_mask, self.args, slot=slot, as_iterator=True, burst=burst if threaded else 0)
+                    job = [slot, gen, report_ids, None, None, None]
                 except NotImplementedError:              # no session path for this geometry: the whole search in one go
-                    return [slot, None, report_ids, beam_search(self.text_decoder, x, enc_mask, self.args)]
+                    return [slot, None, report_ids, beam_search(self.text_decoder, x, enc_mask, self.args), None, None]
+                if threaded:
+                    # everything in front of the token loop (cross-attention K / V, position 0, on first use the graph capture, which
+                    # must not meet another thread's allocations) from THIS thread; the loop itself from a worker
+                    if not advance(job):
+                        job[5] = pool.submit(drive, job)
+                return job
 
         def advance(job):
             """issue the next token step of a job; True when the search has been issued completely"""
@@ -231,12 +254,28 @@ class FineTune(_Base):
                     job[1] = None
                     return True
 
+        def drive(job):
+            """(worker thread) the rest of one search: the token loop as native bursts (the GIL is released inside), then the download"""
+            torch.cuda.set_device(dev)               # the current device, stream and grad mode are per thread
+            marks = deque()
+            with torch.no_grad():
+                while not advance(job):
+                    # at most `ahead` bursts queued: a thread that fills the launch queue to the brim blocks inside the runtime, and
+                    # with it every other thread's launches (measured: the next batch's encoders then wait for the search to drain)
+                    marks.append(torch.cuda.Event())
+                    marks[-1].record(dec_s[job[0]])
+                    if len(marks) > ahead:
+                        marks.popleft().synchronize()
+                with torch.cuda.stream(dec_s[job[0]]):
+                    job[4] = job[3].cpu()
+
         def finish(job):
             seq, report_ids = job[3], job[2]
-            with torch.cuda.stream(dec_s[job[0]]):
-                ids = seq.cpu()                      # waits for that decode stream only
+            if job[4] is None:
+                with torch.cuda.stream(dec_s[job[0]]):
+                    job[4] = seq.cpu()               # waits for that decode stream only
             ops.check_forward_guard(seq.device)      # verdicts of the encoder passes that have finished
-            gen_texts = self.tokenizer.decode_batch(ids.tolist())
+            gen_texts = self.tokenizer.decode_batch(job[4].tolist())
             gen_texts = [t if len(t) > 0 else NO_FINDING for t in gen_texts]
             if mode == 'sample':
                 return [gen_texts, self.tokenizer.decode_batch(report_ids.cpu().tolist())]
@@ -246,23 +285,40 @@ class FineTune(_Base):
             it = iter(batches)
             jobs = deque()                           # in flight, oldest first
             free = list(range(depth))
+            staged = None                            # (threaded) the encoders of the batch after the ones in flight, already queued
             exhausted = False
             while True:
-                while not exhausted and free:        # fill the free slots: encoders of the next batch, then its search joins the rotation
-                    batch = next(it, None)
-                    if batch is None:
-                        exhausted = True
-                        break
-                    jobs.append(start(encode(batch), free.pop(0)))
+                while free and (staged is not None or not exhausted):     # fill the free slots: encoders, then the search joins the rotation
+                    enc, staged = staged, None
+                    if enc is None:
+                        batch = next(it, None)
+                        if batch is None:
+                            exhausted = True
+                            break
+                        enc = encode(batch)
+                    jobs.append(start(enc, free.pop(0)))
                 if not jobs:
                     break
-                for job in list(jobs):               # one token step of every search in flight
-                    advance(job)
+                if threaded:
+                    if staged is None and not exhausted:                   # the workers issue the searches; this thread gets one batch ahead
+                        batch = next(it, None)
+                        if batch is None:
+                            exhausted = True
+                        else:
+                            staged = encode(batch)
+                    if jobs[0][5] is not None:
+                        jobs[0][5].result()                                 # (re-raises what the worker raised)
+                        jobs[0][1] = None
+                else:
+                    for job in list(jobs):           # one token step of every search in flight
+                        advance(job)
                 while jobs and jobs[0][1] is None:   # results leave in batch order
                     job = jobs.popleft()
                     yield finish(job)
                     free.append(job[0])
         finally:
+            if pool is not None:
+                pool.shutdown(wait=True)
             for st in [enc_s] + dec_s:
                 cur.wait_stream(st)
             self.train(was_training)

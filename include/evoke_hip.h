@@ -97,6 +97,14 @@ int evk_prof_enable(int on);                     /* records a hipEvent pair arou
 int evk_prof_collect(double* ms_per_family, int64_t* launches_per_family, double* flops_gemm); /* syncs+resets */
 int evk_prof_dump_to(const char* path);          /* next evk_prof_collect also writes one CSV row per launch (shape-tagged GEMMs) */
 
+/* ---- compute-unit partitioned streams (runtime.hip) ------------------------------------------------------------------------
+ * The reference serves one batch at a time (modules/tester.py test loop: forward(mode='inference') per batch).  The serving loop here
+ * (FineTune.generate_pipelined) overlaps the encoders of the next batch with the searches in flight; evk_stream_create_cu_mask makes
+ * the encoder stream leave a share of the CUs to the searches' small dependent kernels.  mask: bit i = CU i may be used. */
+int evk_stream_create_cu_mask(const uint32_t* mask, int32_t words, void** stream_out);
+int evk_stream_destroy(void* stream);
+int evk_device_cu_count(int32_t device, int32_t* cus);
+
 /* ---- step replayer (replay.hip): the launch sequence of a stream-captured training step re-issued from C++ ------------
  * The reference's step is eager PyTorch (modules/trainer_v0401.py:426-435: zero_grad, forward, backward, clip, step).  Here the
  * step is captured ONCE per batch structure with hipStreamBeginCapture (through torch.cuda.graph), and the resulting hipGraph_t
@@ -108,6 +116,8 @@ int evk_prof_dump_to(const char* path);          /* next evk_prof_collect also w
 void* evk_replay_build(void* hip_graph, int32_t max_lanes);
 int evk_replay_info(void* plan, int64_t* out6);
 int evk_replay_run(void* plan, evk_stream_t stream);
+int evk_replay_run_n(void* plan, evk_stream_t stream, int32_t n);   /* n replays back to back (the ~100 token steps of a beam search,
+                                                                       modules/beam_search.py / att_model.py:139-192's loop, from one call) */
 int evk_replay_destroy(void* plan);
 
 /* ---- GEMM / implicit-GEMM family (MFMA) -------------------------------------------------------------
@@ -301,6 +311,29 @@ int64_t evk_trunk_ws_bytes(const evk_trunk_cfg* cfg, int32_t N, int32_t H, int32
 /* images f32 NCHW [N][3][H][W] -> out bf16 NHWC [N][H/32][W/32][4*planes[3]]; ws keeps what the backward needs */
 int evk_trunk_forward(const evk_trunk_cfg* cfg, const evk_trunk_layer* layers, int32_t n_layers, const float* images, int32_t N,
                       int32_t H, int32_t W, void* ws, int64_t ws_bytes, void* out, int32_t training, evk_stream_t stream);
+/* Inference forward of the trunk (nn.Module.eval() + torch.no_grad() around modules/visual_extractor.py:30-43 -- the test / sample /
+ * validation loops of modules/trainer_v0401.py:470-494, 592-658): the eval-mode batch norms as per-channel scale / shift applied to the
+ * convolutions' f32 accumulators, identity / ReLU in the same epilogue.  fold_ws = evk_trunk_fold_bytes(cfg) bytes kept by the caller between
+ * calls (the scale / shift vectors); refold != 0 recomputes them (affine parameters or running statistics changed). */
+int64_t evk_trunk_fold_bytes(const evk_trunk_cfg* cfg);
+int evk_trunk_forward_inference(const evk_trunk_cfg* cfg, const evk_trunk_layer* layers, int32_t n_layers, const float* images, int32_t N,
+                                int32_t H, int32_t W, void* ws, int64_t ws_bytes, void* out, void* fold_ws, int64_t fold_bytes, int32_t refold,
+                                evk_stream_t stream);
+/* pieces of it, callable directly (nn.BatchNorm2d in eval mode behind nn.Conv2d, modules/visual_extractor.py:30-43): the coefficients, and a
+ * convolution with the scale / bias + optional residual + optional ReLU epilogue on the routes that have it (weight-stationary / strip / halo
+ * kernels: evk_conv2d_fwd_affine_routes = 1; the tile GEMM's geometries return EVK_EUNSUPPORTED). */
+int evk_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, float* scale, float* shift,
+                       int32_t C, evk_stream_t stream);
+int evk_conv2d_fwd_affine(const void* x, const void* w, void* y, const evk_conv_geom* g, const float* scale, const float* bias, const void* resid,
+                          int32_t relu, evk_stream_t stream);
+int evk_conv2d_fwd_affine_routes(const evk_conv_geom* g);
+int evk_conv1x1_ws_fwd_affine(const void* x, const void* w, void* y, int64_t M, int32_t K, int32_t N, const float* scale, const float* bias,
+                              const void* resid, int32_t relu, evk_stream_t stream);
+int evk_conv3x3_halo_affine(const void* x, const void* w, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t Co, const float* scale,
+                            const float* bias, const void* resid, int64_t ldr, int32_t relu, evk_stream_t stream);
+int evk_gemm_strip_affine(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int32_t N, int32_t K,
+                          const float* scale, const float* bias, const void* resid, int64_t ldr, int32_t relu, evk_stream_t stream);
+
 /* dout bf16 (shape of out); parameter gradients are accumulated in place; weight-gradient GEMMs run on wgrad_stream
  * (ordered after their inputs by events; pass NULL or `stream` to keep everything on one stream)                 */
 int evk_trunk_backward(const evk_trunk_cfg* cfg, const evk_trunk_layer* layers, int32_t n_layers, int32_t N, int32_t H, int32_t W,

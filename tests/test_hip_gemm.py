@@ -208,6 +208,70 @@ def test_conv_fwd_dgrad_wgrad(H, cfg):
     close(dw, wr.grad.permute(0, 2, 3, 1), 2e-4, 3e-3 * (N * g.Ho * g.Wo) ** 0.5)
 
 
+AFFINE = [  # N, Hi, Wi, Ci, Co, KH, stride, pad, resid, relu -- the routes of evk_conv2d_fwd_affine (and two geometries it refuses)
+    (4, 24, 24, 256, 1024, 1, 1, 0, True, True),      # conv3 of a layer3 bottleneck + identity + ReLU: weight-stationary kernel
+    (3, 48, 48, 128, 512, 1, 1, 0, True, True),       # conv3 of layer2 (K = 128), a pixel count that is no multiple of the tile
+    (2, 96, 96, 64, 256, 1, 1, 0, True, False),       # conv3 of layer1 (K = 64), identity without ReLU
+    (64, 24, 24, 1024, 256, 1, 1, 0, False, True),    # conv1 of layer3 at the bench's batch (256 strips): strip GEMM
+    (64, 24, 24, 1024, 256, 1, 1, 0, True, True),     # strip GEMM with an identity
+    (2, 24, 24, 256, 256, 3, 1, 1, False, True),      # conv2: halo kernel
+    (2, 24, 24, 256, 256, 3, 1, 1, True, False),      # halo kernel with a residual, no ReLU
+    (2, 48, 48, 128, 128, 3, 2, 1, False, True),      # the stride-2 conv2 of a layer's first block: tile GEMM's geometry, refused
+    (2, 24, 24, 512, 1024, 1, 2, 0, False, False),    # shortcut convolution (1x1 stride 2): refused
+]
+
+
+@pytest.mark.parametrize('cfg', AFFINE)
+def test_conv_with_batchnorm_epilogue(H, cfg):
+    """evk_bn_eval_coeffs + evk_conv2d_fwd_affine (the inference form of conv -> eval-mode BatchNorm2d (-> + identity) -> ReLU,
+    modules/visual_extractor.py:30-43 under model.eval()) on every route that has the epilogue -- weight-stationary, strip, halo -- against
+    fp32 torch (F.conv2d -> F.batch_norm(training=False) -> + residual -> relu) on the same 16-bit operands, and BIT FOR BIT against the
+    library's unfused eval forward of the same layer (evk_conv2d_fwd_stats -> evk_bn_apply): the epilogue reproduces its arithmetic, so a
+    batch whose size sends a layer down another route decodes to the same tokens.  Geometries of the tile GEMM are refused (the trunk runs
+    conv + bn there)."""
+    N, Hi, Wi, Ci, Co, KH, stride, pad, with_resid, relu = cfg
+    g = H.conv_geom(N, Hi, Wi, Ci, Co, KH, KH, stride, pad)
+    gen = torch.Generator().manual_seed(77)
+    x = rnd(N, Hi, Wi, Ci, seed=51)
+    w = rnd(Co, KH, KH, Ci, seed=52, scale=(2.0 / (KH * KH * Ci)) ** 0.5)
+    gamma = 0.5 + torch.rand(Co, generator=gen)
+    beta = torch.randn(Co, generator=gen) * 0.2
+    mean = torch.randn(Co, generator=gen) * 0.3
+    var = 0.3 + torch.rand(Co, generator=gen)
+    resid = rnd(N, g.Ho, g.Wo, Co, seed=53) if with_resid else None
+    xd, wd = x.cuda(), w.cuda()
+    gd, bd, md, vd = gamma.cuda(), beta.cuda(), mean.cuda(), var.cuda()          # (kept alive: a temporary's block would be handed to the next one)
+    scale = torch.empty(Co, dtype=torch.float32, device='cuda')
+    shift = torch.empty(Co, dtype=torch.float32, device='cuda')
+    H.check(H.lib.evk_bn_eval_coeffs(H.ptr(gd), H.ptr(bd), H.ptr(md), H.ptr(vd), C.c_float(1e-5), H.ptr(scale), H.ptr(shift), Co, H.stream()), 'bn_eval_coeffs')
+    sc = gamma / torch.sqrt(var + 1e-5)
+    close(scale, sc, 1e-5, 1e-6)
+    close(shift, beta - mean * sc, 1e-5, 2e-6)
+    y = torch.full((N, g.Ho, g.Wo, Co), 7.0, dtype=STORE_DTYPE, device='cuda')
+    rd = resid.cuda() if with_resid else None
+    rc = H.lib.evk_conv2d_fwd_affine(H.ptr(xd), H.ptr(wd), H.ptr(y), C.byref(g), H.ptr(scale), H.ptr(shift), H.ptr(rd) if rd is not None else None,
+                                     int(relu), H.stream())
+    if not H.lib.evk_conv2d_fwd_affine_routes(C.byref(g)):
+        assert rc == -3 and float(y.float().min()) == 7.0          # EVK_EUNSUPPORTED, nothing written
+        return
+    H.check(rc, 'conv2d_fwd_affine')
+    yr = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), None, stride, pad)
+    yr = F.batch_norm(yr, mean, var, gamma, beta, training=False, eps=1e-5)
+    if with_resid:
+        yr = yr + resid.float().permute(0, 3, 1, 2)
+    if relu:
+        yr = torch.relu(yr)
+    rt = 2.0 ** -7 if STORE_DTYPE == torch.bfloat16 else 2.0 ** -9        # (two roundings, as in the unfused forward)
+    close(y, yr.permute(0, 2, 3, 1), rt, 4e-3)
+    y0 = torch.empty_like(y)
+    y1 = torch.empty_like(y)
+    nblk = C.c_int32(0)
+    H.check(H.lib.evk_conv2d_fwd_stats(H.ptr(xd), H.ptr(wd), H.ptr(y0), C.byref(g), None, 0, C.byref(nblk), H.stream()), 'conv2d_fwd_stats')
+    H.check(H.lib.evk_bn_apply(H.ptr(y0), H.ptr(scale), H.ptr(shift), H.ptr(rd) if rd is not None else None, H.ptr(y1), N * g.Ho * g.Wo, Co, int(relu),
+                               H.stream()), 'bn_apply')
+    assert torch.equal(y, y1), 'the fused epilogue differs from conv -> bn_apply (max %.3e)' % float((y.float() - y1.float()).abs().max())
+
+
 @pytest.mark.parametrize('N,Hh,W', [(2, 32, 32), (1, 64, 48), (2, 64, 128), (3, 40, 256)])       # the last two: the halo kernel of stem.hip
 def test_stem(H, N, Hh, W):
     g = torch.Generator().manual_seed(11)

@@ -240,6 +240,50 @@ def test_trunk_follows_bf16_emulation(train):
 LOGP_TOL = 8e-3 if F16 else 6e-2          # flat, at every position: |engine log-probability - reference| in the default decode mode (f32 relational memory)
 
 
+@pytest.mark.parametrize('res', [224, 384])
+def test_inference_trunk_with_batchnorm_epilogues_follows_the_eval_forward(res):
+    """The inference forward of the visual extractor (eval mode under no_grad: the eval-mode batch norms as scale / shift in the convolution
+    epilogues together with identity and ReLU, evk_trunk_forward_inference) against the unfused eval forward of the same module
+    (EVK_FOLD_BN=0: conv, bn_finalize, bn_apply per layer), whose arithmetic the epilogues reproduce bit for bit, and against the fp32
+    oracle; and the scale / shift vectors must follow the parameters: after a change of a running statistic the next call recomputes them."""
+    from evoke_amd import trunk as T
+    from evoke_amd.trunk import ResNet
+    from oracle import functional as O, spec as S
+    from tests.helpers import rel_err
+    inp = make_inputs(CASES['ft224_inc' if res == 224 else 'ft384_inc'], V)
+    spec = {}
+    S.resnet_spec(spec)
+    m = ResNet({})
+    m.load_state_dict({k[len('visual_extractor.'):]: v for k, v in S.procedural_state(spec).items()})
+    m = m.cuda().eval()
+    img = inp['images'].cuda()
+    saved = T.FOLD_BN[0]
+
+    def run(fold):
+        T.FOLD_BN[0] = fold
+        try:
+            with torch.no_grad():
+                return m(img)[0]
+        finally:
+            T.FOLD_BN[0] = saved
+
+    att_f = run(True)
+    assert getattr(m.model, '_evk_fold', None) is not None, 'the inference path did not run'
+    att_u = run(False)
+    ref = O.resnet101_trunk(S.procedural_state(spec), inp['images'], O.Ctx(train=False))
+    n, c = ref.shape[:2]
+    ref_p = ref.reshape(n, c, -1).permute(0, 2, 1)
+    e_fu, e_f, e_u = rel_err(att_f.float(), att_u.float().cpu()), rel_err(att_f.float(), ref_p), rel_err(att_u.float(), ref_p)
+    print('\n[inference trunk %d^2] fused vs unfused %.3e | fused vs fp32 oracle %.3e | unfused vs fp32 oracle %.3e' % (res, e_fu, e_f, e_u))
+    assert torch.equal(att_f, att_u) and e_f <= 2e-3, (e_fu, e_f, e_u)
+    # the vectors follow the parameters
+    with torch.no_grad():
+        m.model.pairs()[5][1].running_var.mul_(4.0)
+    att_2, att_2u = run(True), run(False)
+    assert torch.equal(att_2, att_2u)
+    assert rel_err(att_2.float(), att_f.float().cpu()) > 1e-3, 'the running statistic changed but the scale / shift vectors did not'
+
+
 @pytest.mark.parametrize('name', [n for n, c in CASES.items() if c['kind'] == 'beam' and c['max_seq_len'] <= 40])
 def test_beam_search_matches_reference(name):
     """FineTune.forward(mode='inference') end to end (incremental device-side beam search vs the reference's full re-decode) on the

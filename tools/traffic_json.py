@@ -13,7 +13,7 @@ wr, _ = load(sys.argv[2], 1.0)
 steps = float(sys.argv[3])
 # the GEMM / convolution family: the tile kernels of gemm.hip, the strip GEMM, the halo-tile 3x3 and stem kernels (forward / data gradient and
 # weight gradient: they took over launches of gemm_kernel in round 3) and the split-K reductions
-FAMILY = ('void gemm_', 'gemm_strip_kernel', 'void conv3x3_halo_kernel', 'conv3x3_halo_kernel', 'wgk::conv3x3_wgrad_halo_kernel', 'stem_fwd_kernel', 'stem_wgrad_kernel', 'splitk_reduce')
+FAMILY = ('void gemm_', 'gemm_strip_kernel', 'gemm_tn_kernel', 'gemm_f32_kernel', 'void conv3x3_halo_kernel', 'conv3x3_halo_kernel', 'wgk::conv3x3_wgrad_halo_kernel', 'stem_fwd_kernel', 'stem_wgrad_kernel', 'splitk_reduce')
 fam = lambda n: n.startswith(FAMILY)
 names = sorted(set(fe) | set(wr), key=lambda n: -(fe.get(n, 0) + wr.get(n, 0)))
 out = {
