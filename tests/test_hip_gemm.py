@@ -262,7 +262,7 @@ def test_conv_with_batchnorm_epilogue(H, cfg):
     if relu:
         yr = torch.relu(yr)
     rt = 2.0 ** -7 if STORE_DTYPE == torch.bfloat16 else 2.0 ** -9        # (two roundings, as in the unfused forward)
-    close(y, yr.permute(0, 2, 3, 1), rt, 4e-3)
+    close(y, yr.permute(0, 2, 3, 1), rt, 4e-3 if STORE_DTYPE == torch.float16 else 3e-2)       # (the conv output's rounding, scaled by gamma / sigma, where the shift cancels it)
     y0 = torch.empty_like(y)
     y1 = torch.empty_like(y)
     nblk = C.c_int32(0)

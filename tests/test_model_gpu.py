@@ -275,7 +275,7 @@ def test_inference_trunk_with_batchnorm_epilogues_follows_the_eval_forward(res):
     ref_p = ref.reshape(n, c, -1).permute(0, 2, 1)
     e_fu, e_f, e_u = rel_err(att_f.float(), att_u.float().cpu()), rel_err(att_f.float(), ref_p), rel_err(att_u.float(), ref_p)
     print('\n[inference trunk %d^2] fused vs unfused %.3e | fused vs fp32 oracle %.3e | unfused vs fp32 oracle %.3e' % (res, e_fu, e_f, e_u))
-    assert torch.equal(att_f, att_u) and e_f <= 2e-3, (e_fu, e_f, e_u)
+    assert torch.equal(att_f, att_u) and e_f <= (2e-3 if F16 else 2e-2), (e_fu, e_f, e_u)
     # the vectors follow the parameters
     with torch.no_grad():
         m.model.pairs()[5][1].running_var.mul_(4.0)
