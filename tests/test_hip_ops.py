@@ -1097,3 +1097,30 @@ def test_decode_attention_fed_by_the_fused_projection_equals_append_then_attend(
     sc = (q.float().view(R, heads, 1, 64) @ kk.transpose(-1, -2)) * 0.125
     ref = (torch.softmax(sc, -1) @ vv).permute(0, 2, 1, 3).reshape(R, 1, HD)
     close(got.float(), ref.cpu(), 1e-2, 1e-2, 'decode attention qkv R=%d S=%d pos=%d' % (R, S, pos))
+
+
+def test_cu_masked_stream_runs_kernels_on_its_share_of_the_compute_units():
+    """evk_stream_create_cu_mask / hip.masked_stream: a stream whose kernels keep off 8, 16 or 24 of every 32 CUs: a kernel
+    launched on the stream produces the same bytes as on the default stream, and a bad request is refused."""
+    import ctypes as C
+    from evoke_amd import hip as H
+    n = C.c_int32(0)
+    H.check(H.lib.evk_device_cu_count(0, C.byref(n)), 'device_cu_count')
+    assert n.value >= 64
+    x = rnd(4096, 512).to(BF).cuda()
+    want = torch.empty(4096, 512, dtype=torch.float32, device='cuda')
+    H.check(H.lib.evk_cast(H.ptr(x), H.BF16, H.ptr(want), H.F32, x.numel(), H.stream()), 'cast')
+    torch.cuda.synchronize()
+    for reserve in (8, 16, 24):
+        st = H.masked_stream('cuda:0', reserve)
+        assert H.masked_stream('cuda:0', reserve) is st                      # cached: one stream per (device, share)
+        got = torch.empty_like(want)
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            H.check(H.lib.evk_cast(H.ptr(x), H.BF16, H.ptr(got), H.F32, x.numel(), H.stream()), 'cast on the masked stream')
+        st.synchronize()
+        assert torch.equal(got, want)
+    with pytest.raises(ValueError):
+        H.masked_stream('cuda:0', 5)
+    out = C.c_void_p()
+    assert H.lib.evk_stream_create_cu_mask(None, 0, C.byref(out)) == -1       # EVK_EINVAL

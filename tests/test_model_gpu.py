@@ -874,6 +874,42 @@ def test_pipelined_generation_equals_per_batch_inference():
         assert isinstance(sg, list) and len(sg) == len(gt)
 
 
+@pytest.mark.parametrize('env', [
+    {'EVK_DECODE_THREADS': '0'},                                                   # the calling thread issues every token step round-robin
+    {'EVK_DECODE_THREADS': '1', 'EVK_DECODE_BURST': '1', 'EVK_DECODE_AHEAD': '1'},     # host threads, one step per native call
+    {'EVK_DECODE_THREADS': '1', 'EVK_DECODE_DEPTH': '3', 'EVK_DECODE_BURST': '5'},     # three searches in flight, bursts that do not divide the loop
+    {'EVK_DECODE_THREADS': '1', 'EVK_ENC_RESERVE_CUS': '8'},                       # encoders on a CU-masked stream (hip.masked_stream)
+    {'EVK_DECODE_THREADS': '1', 'EVK_FOLD_BN': '1'},                               # batch norms in the convolution epilogues (bit-identical forward)
+], ids=['one_thread', 'threads_burst1', 'depth3_burst5', 'cu_mask', 'fused_bn'])
+def test_pipelined_generation_modes_return_the_same_ids(env, monkeypatch):
+    """Every way generate_pipelined can drive the searches (host threads issuing native bursts of token steps / one thread round-robin,
+    2 or 3 searches in flight, encoders on a CU-masked stream, the fused inference trunk) returns the ids of forward(mode='inference'),
+    five batches of three different structures, in batch order."""
+    from evoke_amd import trunk as T
+    from evoke_amd.model_pretrain_finetune import FineTune
+    from oracle import spec as S
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setattr(T, 'FOLD_BN', [env.get('EVK_FOLD_BN', '0') != '0'])
+    args = dict(ARGS, max_seq_len=20, beam_size=3)
+    model = FineTune(args, load_tokenizer(), 'iu_xray')
+    load_procedural(model, S.finetune_spec(V))
+    model.eval()
+    batches = []
+    for k, name in enumerate(('beam224', 'ft224_inc', 'beam224_b4', 'beam224', 'ft224_inc')):
+        inp = make_inputs(CASES[name], V)
+        batches.append((inp['images'].cuda() * (1.0 + 0.05 * k), inp['ids'].cuda(), inp['masks'].cuda(), np.array(inp['patient_ids']), inp['inc_ids'],
+                        inp['inc_masks']))
+    with torch.no_grad():
+        monkeypatch.setattr(T, 'FOLD_BN', [False])
+        want = [model(*b, mode='inference')[1].cpu() for b in batches]
+        monkeypatch.setattr(T, 'FOLD_BN', [env.get('EVK_FOLD_BN', '0') != '0'])
+        got = [seq.cpu() for _, seq in model.generate_pipelined(batches, mode='inference')]
+    assert len(got) == len(want)
+    for k, (w, g) in enumerate(zip(want, got)):
+        assert torch.equal(w, g), 'batch %d: %s changed the token ids' % (k, env)
+
+
 def test_pipelined_generation_with_asynchronously_uploaded_batches():
     """The serving loop as a loader drives it: every batch is uploaded with `.to(device, non_blocking=True)` from pinned memory on the
     CALLER's stream when the generator asks for it -- behind a long-running kernel, so that the copy lands late -- and dropped by the
