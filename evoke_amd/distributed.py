@@ -131,6 +131,8 @@ class GradReducer:
     the bytes on the links) and cast back -- an overflow of the scaled fp16 gradients becomes inf, which the optimizer's overflow
     scan turns into a skipped step on every rank."""
 
+    active = False          # set by begin(): more than one rank takes part in this step's gradient sum
+
     def __init__(self, flat_grads, params, bucket_bytes=128 << 20, overlap=True, mode=None):
         self.flat, self.overlap = flat_grads, overlap
         # default 'allreduce': RCCL's own all-reduce (it picks its algorithm for the xGMI mesh).  'direct' -- reduce-scatter + all-gather written
@@ -180,6 +182,7 @@ class GradReducer:
         self.counts = {}
         n = len(self.buckets)
         self.launched = [False] * n
+        self.active = self._active()                  # (constant over a step: asked once, not per gradient)
         self.streams = [set() for _ in range(n)]      # HIP streams that produced gradients of the bucket
         self.next = n - 1                             # the only bucket that may go out now
         self.issued = []
@@ -229,7 +232,7 @@ class GradReducer:
             # dedicated stream that waits for the streams THIS bucket's gradients came from (not for every side stream: the
             # weight-gradient stream of an early bucket has nothing to do with the relational memory's), so the main stream is
             # not held back at a bucket boundary (RCCL orders itself after the stream that is current at the call).
-            cur = torch.cuda.current_stream()
+            cur = ops.H.current_stream()
             comm = ops.side_stream('comm')
             comm.wait_stream(cur)
             for st in self.streams[b]:
@@ -250,12 +253,12 @@ class GradReducer:
         b = self.bucket_of.get(id(p))
         if b is None:
             return
-        if self.launched[b] and self._active():
+        if self.launched[b] and self.active:
             raise RuntimeError('GradReducer: a gradient arrived for bucket %d after its collective was issued (structure key %r: '
                                'the learned gradient counts do not describe this batch)' % (b, self.key))
         self.counts[id(p)] = self.counts.get(id(p), 0) + 1
-        if self.flat[self.buckets[b][0]].is_cuda:
-            self.streams[b].add(torch.cuda.current_stream())
+        if self.active and self.flat[self.buckets[b][0]].is_cuda:          # (one rank: no collective will wait for anything)
+            self.streams[b].add(ops.H.current_stream())
             # Weight gradients are launched on the 'wgrad' side stream (ops.wgrad_stream, the trunk runner's second stream) while the
             # callback runs on the stream that issued the backward op: the collective of this bucket must wait for that stream too.
             # (Without it the all-reduce could start before the last weight-gradient kernel had added its part, which then landed on
@@ -298,7 +301,7 @@ class GradReducer:
             h.wait()
         self.handles = []
         if self.flat and self.flat[0].is_cuda and self._active():
-            torch.cuda.current_stream().wait_stream(ops.side_stream('comm'))
+            ops.H.current_stream().wait_stream(ops.side_stream('comm'))
         self._share_touched()
         if self.learning:
             self.learned[self.key] = dict(self.counts)

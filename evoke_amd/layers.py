@@ -753,7 +753,7 @@ class EncoderDecoder(nn.Module):
         if not (ops.SIDE_STREAMS_ENABLED[0] and input_ids.is_cuda):
             emb = self.model.embed(input_ids)
             return emb, self.model.rm(emb), None
-        main = torch.cuda.current_stream()
+        main = H.current_stream()
         side = ops.side_stream('rm')
         side.wait_stream(main)
         input_ids.record_stream(side)          # read by this stream's kernels, forward and backward (see _Base._side_branch)
@@ -769,7 +769,7 @@ class EncoderDecoder(nn.Module):
         emb, memory, side = pending
         enc, src_mask = self.encode(enc_states, enc_mask)
         if side is not None:
-            main = torch.cuda.current_stream()
+            main = H.current_stream()
             main.wait_stream(side)
             emb.record_stream(main)
             memory.record_stream(main)

@@ -361,19 +361,23 @@ def grad_done(p):
 # own HIP stream concurrently with the fat ResNet kernels; autograd replays each op's backward on its forward stream.
 # ----------------------------------------------------------------------------------------------------
 _side_streams = {}
+_side_raw = set()            # (device, raw handle) of every side stream
+_main_raw = {}              # device -> raw handle of the stream remembered in _main_stream
 SIDE_STREAMS_ENABLED = [True]
 
 
 def side_stream(name, device=None):
     """The named side stream of `device`; the stream current at the call is remembered as that device's main stream."""
-    dev = torch.cuda.current_device() if device is None else device
+    dev = H._cur_device() if device is None else device
     key = (name, dev)
     st = _side_streams.get(key)
     if st is None:
         st = _side_streams[key] = torch.cuda.Stream(device=dev)
-    cur = torch.cuda.current_stream(dev)
-    if all(cur != s for (n, d), s in _side_streams.items() if d == dev):
-        _main_stream[dev] = cur
+        _side_raw.add((dev, st.cuda_stream))
+    raw = H._raw_stream(dev)
+    if (dev, raw) not in _side_raw and _main_raw.get(dev) != raw:        # (raw handles: no Stream objects built or compared per call)
+        _main_raw[dev] = raw
+        _main_stream[dev] = torch.cuda.current_stream(dev)
     return st
 
 
@@ -382,7 +386,7 @@ _main_stream = {}
 
 def existing_side_stream(name, device=None):
     """the named side stream of `device` if it has been created, else None (never creates one)"""
-    dev = torch.cuda.current_device() if device is None else device
+    dev = H._cur_device() if device is None else device
     return _side_streams.get((name, dev))
 
 
@@ -396,7 +400,7 @@ def join_side_streams(into=None, skip=None):
     (called before the optimizer / gradient all-reduce, because parameter gradients are accumulated in place from those
     streams).  `skip` names a side stream to leave out.  While a step is being captured in a HIP graph only the streams that
     have joined the capture are waited for (an idle side stream has nothing queued and is not part of the graph)."""
-    cur = torch.cuda.current_stream() if into is None else into
+    cur = H.current_stream() if into is None else into
     cap = _capturing(cur)
     for (name, dev), st in _side_streams.items():
         if dev == cur.device.index and st != cur and name != skip and (not cap or _capturing(st)):
@@ -491,7 +495,7 @@ _wgrad_join_queued = [False]
 
 def _wgrad_join_callback():
     _wgrad_join_queued[0] = False
-    cur = torch.cuda.current_stream()
+    cur = H.current_stream()
     cap = _capturing(cur)
     for (name, dev), st in _side_streams.items():
         if name == 'wgrad' and dev == cur.device.index and (not cap or _capturing(st)):
@@ -515,22 +519,25 @@ class wgrad_stream:
 
     def __init__(self, *tensors):
         self.tensors = tensors
-        self.ctx = None
+        self.prev = None
 
     def __enter__(self):
         if SIDE_STREAMS_ENABLED[0] and WGRAD_SIDE_STREAM[0]:
             side = side_stream('wgrad')
             join_wgrad_at_backward_end()
-            side.wait_stream(torch.cuda.current_stream())
+            cur = H.current_stream()
+            side.wait_stream(cur)
             for t in self.tensors:
                 t.record_stream(side)
-            self.ctx = torch.cuda.stream(side)
-            self.ctx.__enter__()
+            # (set_stream directly: torch.cuda.stream()'s context manager costs ~10 us per entry, 60 entries per backward)
+            self.prev = cur
+            torch.cuda.set_stream(side)
         return self
 
     def __exit__(self, *exc):
-        if self.ctx is not None:
-            self.ctx.__exit__(*exc)
+        if self.prev is not None:
+            torch.cuda.set_stream(self.prev)
+            self.prev = None
         return False
 
 

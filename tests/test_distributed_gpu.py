@@ -244,6 +244,7 @@ def test_reducer_collectives_wait_for_the_weight_gradient_stream():
     try:
         x = torch.randn(16, 32, device='cuda').to(ops.BF16).requires_grad_(True)
         red.begin('one-linear')
+        red.active = True             # the bookkeeping of a multi-rank step (one rank alone skips it: no collective will wait for anything)
         ops.linear(x, W).float().sum().backward()
         wg = ops.existing_side_stream('wgrad')
         assert wg is not None, 'the linear backward did not use the weight-gradient stream'

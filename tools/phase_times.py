@@ -4,11 +4,11 @@ import time
 
 import torch
 
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import bench  # noqa: E402
 from evoke_amd import distributed as D, ops, optim  # noqa: E402
 from evoke_amd.model_pretrain_finetune import FineTune  # noqa: E402
-from tests.helpers import load_tokenizer  # noqa: E402
+from evoke_amd.config import load_default_tokenizer as load_tokenizer  # noqa: E402
 
 dev = torch.device('cuda', 0)
 torch.manual_seed(9233)
@@ -45,7 +45,12 @@ def step():
     mark('fwd_end')
     ret['all_loss'].backward()
     mark('bwd_end')
+    for (name, d), st in list(ops._side_streams.items()):            # when each side stream runs dry (everything the backward queued on it)
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(st)
+        ev.setdefault('side:' + name, []).append(e)
     red.finish()
+    mark('joined')
     opt.step()
     mark('opt_end')
 
@@ -60,8 +65,13 @@ for _ in range(N):
     step()
 torch.cuda.synchronize()
 print('wall %.2f ms/step' % (1e3 * (time.perf_counter() - t0) / N))
-order = ['start', 'trunk_fwd_end', 'fwd_end', 'trunk_bwd_start', 'bwd_end', 'opt_end']
+order = ['start', 'trunk_fwd_end', 'fwd_end', 'trunk_bwd_start', 'bwd_end', 'joined', 'opt_end']
 for a, c in zip(order[:-1], order[1:]):
     ms = sum(x.elapsed_time(y) for x, y in zip(ev[a], ev[c])) / N
     print('%-16s -> %-16s %7.2f ms' % (a, c, ms))
 print('opt_end -> next start %.2f ms' % (sum(x.elapsed_time(y) for x, y in zip(ev['opt_end'][:-1], ev['start'][1:])) / (N - 1)))
+for k in sorted(ev):
+    if k.startswith('side:'):
+        print('start -> %-12s dry %7.2f ms   (main stream: bwd_end at %.2f, joined at %.2f)' % (
+            k[5:], sum(x.elapsed_time(y) for x, y in zip(ev['start'], ev[k])) / N, sum(x.elapsed_time(y) for x, y in zip(ev['start'], ev['bwd_end'])) / N,
+            sum(x.elapsed_time(y) for x, y in zip(ev['start'], ev['joined'])) / N))
