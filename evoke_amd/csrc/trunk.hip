@@ -278,8 +278,8 @@ int evk_trunk_forward(const evk_trunk_cfg* cfg, const evk_trunk_layer* layers, i
  * accumulators as a per-channel scale / shift (evk_bn_eval_coeffs: gamma / sqrt(var + eps), beta - mean * gamma / sqrt(var + eps)), together
  * with the identity and the ReLU -- the 2 x 100 bn_finalize / bn_apply launches of the eval-mode forward (6.3 ms of a 15.4 ms pass over 128
  * images at 384^2: one more read and write of every activation) are gone, and the activations are rounded to 16 bits once instead of twice.
- *   fold_ws: evk_trunk_fold_bytes(cfg) bytes the CALLER keeps between calls (the scale / shift vectors); refold != 0: (re)compute them (the
- *   affine parameters or the running statistics changed since the last call), 0: reuse them.  The stem and the 9 convolutions the tile GEMM
+ *   fold_ws: evk_trunk_fold_bytes(cfg) bytes the CALLER keeps between calls (the scale / shift vectors); refold bit 0: (re)compute them (the
+ *   affine parameters or the running statistics changed since the last call), else reuse them; bit 1: see conv_affine below.  The stem and the 9 convolutions the tile GEMM
  *   takes (stride 2, Co = 64) keep the unfused path. */
 int64_t evk_trunk_fold_bytes(const evk_trunk_cfg* cfg) {
   Plan P;
@@ -309,18 +309,21 @@ int evk_trunk_forward_inference(const evk_trunk_cfg* cfg, const evk_trunk_layer*
       const evk_conv_geom& g = P.pairs[i].g;
       sc[i] = reinterpret_cast<float*>(f); f += align256((long)g.Co * 4);
       sh[i] = reinterpret_cast<float*>(f); f += align256((long)g.Co * 4);
-      if (refold)
+      if (refold & 1)
         TRY(evk_bn_eval_coeffs(layers[i].gamma, layers[i].beta, layers[i].running_mean, layers[i].running_var, cfg->eps, sc[i], sh[i], g.Co, stream));
     }
   }
   int nblk = 0;
   // z = relu?(conv(x, w) * scale + shift (+ resid)) in one launch where a route has the epilogue; conv, then the eval-mode bn pass, otherwise
+  // refold == 2 / the caller's mode bit 1: the convolutions with an identity keep conv + bn_apply (with the cached vectors: no bn_finalize
+  // launch) -- their fused form holds one 8-wave workgroup per CU for ~130 us, which a serving loop's small decode kernels then queue behind
+  const bool fuse_identity = !(refold & 2);
   auto conv_affine = [&](int i, const void* xin, const void* resid, int relu) -> int {
     const evk_conv_geom& g = P.pairs[i].g;
-    if (evk_conv2d_fwd_affine_routes(&g))
+    if (evk_conv2d_fwd_affine_routes(&g) && (!resid || fuse_identity))
       return evk_conv2d_fwd_affine(xin, layers[i].w, c.at(P.pairs[i].z), &g, sc[i], sh[i], resid, relu, stream);
     TRY(evk_conv2d_fwd_stats(xin, layers[i].w, c.at(P.pairs[i].y), &g, nullptr, 0, &nblk, stream));
-    return bn_forward(c, i, resid, relu, nblk);
+    return evk_bn_apply(c.at(P.pairs[i].y), sc[i], sh[i], resid, c.at(P.pairs[i].z), P.pairs[i].M, P.pairs[i].C, relu, stream);
   };
   TRY(evk_stem_pack_image(images, c.at(P.xpad), N, H, W, stream));
   TRY(evk_stem_pack_weight(reinterpret_cast<const float*>(layers[0].w), c.at(P.wp), stream));

@@ -98,7 +98,9 @@ class _Stem(torch.autograd.Function):
 # forward (conv, bn_finalize, bn_apply per layer) BIT FOR BIT (tests/test_model_gpu.py, tests/test_hip_gemm.py).  Measured on MI355X, 128 images
 # at 384^2: 15.3 -> 13.5 ms per forward alone, but 117 -> 112 k tokens/s on the pipelined decode workload (the conv3 + identity kernels hold one
 # 8-wave, 220-VGPR workgroup per CU for the whole launch and the searches' small kernels wait for the slots) -- so it is OPT-IN.
-FOLD_BN = [os.environ.get('EVK_FOLD_BN', '0') != '0']
+# EVK_FOLD_BN=2: the same, but convolutions that add an identity keep conv + bn_apply (14.2 ms alone, 120 k tokens/s in the pipeline -- on one
+# box; on another, 37 k: DESIGN.md section 9).
+FOLD_BN = [int(os.environ.get('EVK_FOLD_BN', '0') or 0)]          # 0 off, 1 every route that has the epilogue, 2 all but the convolutions with an identity
 
 
 class _WsLease:
@@ -431,7 +433,7 @@ class ResNetTrunk(nn.Sequential):
         lease = _WsLease(nb, dev, tag=torch.cuda.current_stream().cuda_stream)
         out = _e(N, Hh // 32, Ww // 32, 4 * RESNET_LAYERS[-1][0], device=dev)
         H.check(H.lib.evk_trunk_forward_inference(C.byref(cfg), arr, len(pairs), H.ptr(images), N, Hh, Ww, H.ptr(lease.ws), nb, H.ptr(out), H.ptr(fold),
-                                                  fold.numel(), int(refold), H.stream()), 'trunk_forward_inference')
+                                                  fold.numel(), int(refold) | (2 if FOLD_BN[0] == 2 else 0), H.stream()), 'trunk_forward_inference')
         if refold:
             ev = torch.cuda.Event()
             ev.record()

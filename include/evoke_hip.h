@@ -314,7 +314,8 @@ int evk_trunk_forward(const evk_trunk_cfg* cfg, const evk_trunk_layer* layers, i
 /* Inference forward of the trunk (nn.Module.eval() + torch.no_grad() around modules/visual_extractor.py:30-43 -- the test / sample /
  * validation loops of modules/trainer_v0401.py:470-494, 592-658): the eval-mode batch norms as per-channel scale / shift applied to the
  * convolutions' f32 accumulators, identity / ReLU in the same epilogue.  fold_ws = evk_trunk_fold_bytes(cfg) bytes kept by the caller between
- * calls (the scale / shift vectors); refold != 0 recomputes them (affine parameters or running statistics changed). */
+ * calls (the scale / shift vectors); refold bit 0 recomputes them (affine parameters or running statistics changed), bit 1 keeps the
+ * convolutions that add an identity unfused (conv + evk_bn_apply with the cached vectors). */
 int64_t evk_trunk_fold_bytes(const evk_trunk_cfg* cfg);
 int evk_trunk_forward_inference(const evk_trunk_cfg* cfg, const evk_trunk_layer* layers, int32_t n_layers, const float* images, int32_t N,
                                 int32_t H, int32_t W, void* ws, int64_t ws_bytes, void* out, void* fold_ws, int64_t fold_bytes, int32_t refold,
