@@ -108,14 +108,26 @@ class _WsLease:
     done with it, instead of a malloc/free per step: a freed block that a second stream has touched cannot be re-used by
     the caching allocator until that stream's event completes, so a host that runs ahead would keep hipMalloc-ing new
     20 GB blocks.  Re-use is safe in stream order: the next forward is enqueued on the main stream after the optimizer /
-    gradient reducer has joined the weight-gradient stream."""
+    gradient reducer has joined the weight-gradient stream; a forward without a backward (eval under no_grad) hands the buffer back with
+    its kernels still queued and leaves an event for a later lease taken on ANOTHER stream (release_queued)."""
     _pool = {}
 
-    def __init__(self, nbytes, device, tag=None):
-        # tag: leases that are handed back while their kernels are still queued (the inference forward) are only re-used by the SAME stream
-        self.key = (device.index if device.index is not None else torch.cuda.current_device(), int(nbytes)) + ((tag,) if tag is not None else ())
+    _last_use = {}            # data_ptr -> (raw stream, event): the last QUEUED use of a buffer that was handed back before its kernels ran
+
+    def __init__(self, nbytes, device):
+        self.key = (device.index if device.index is not None else torch.cuda.current_device(), int(nbytes))
         free = _WsLease._pool.setdefault(self.key, [])
         self.ws = free.pop() if free else torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        last = _WsLease._last_use.pop(self.ws.data_ptr(), None)
+        if last is not None and last[0] != H.stream():
+            H.current_stream().wait_event(last[1])       # the inference forward of another stream may still be reading / writing it
+
+    def release_queued(self):
+        """hand the buffer back although the kernels that use it are only QUEUED (the inference forward keeps nothing for a backward):
+        a later lease on the same stream is ordered by the stream, one on another stream waits for the event recorded here"""
+        ev = torch.cuda.Event()
+        ev.record()
+        _WsLease._last_use[self.ws.data_ptr()] = (H.stream(), ev)
 
     LIMIT = 64 << 30          # bytes kept idle in the pool per process (other shapes are evicted first)
 
@@ -170,6 +182,8 @@ class _TrunkFn(torch.autograd.Function):
         H.check(H.lib.evk_trunk_forward(C.byref(cfg), arr, len(pairs), H.ptr(images), N, Hh, Ww, H.ptr(ws), nb, H.ptr(out),
                                         int(trunk.training), H.stream()), 'trunk_forward')
         ctx.lease, ctx.trunk, ctx.dims, ctx.training, ctx.keep = lease, trunk, (N, Hh, Ww), trunk.training, keep
+        if not torch.is_grad_enabled():
+            lease.release_queued()         # (no backward will come: the buffer goes back as soon as ctx dies, with its kernels still queued)
         return out
 
     @staticmethod
@@ -430,7 +444,7 @@ class ResNetTrunk(nn.Sequential):
         nb = H.lib.evk_trunk_ws_bytes(C.byref(cfg), N, Hh, Ww)
         if nb < 0:
             raise RuntimeError('evk_trunk_ws_bytes: ' + H.lib.evk_last_error().decode())
-        lease = _WsLease(nb, dev, tag=torch.cuda.current_stream().cuda_stream)
+        lease = _WsLease(nb, dev)
         out = _e(N, Hh // 32, Ww // 32, 4 * RESNET_LAYERS[-1][0], device=dev)
         H.check(H.lib.evk_trunk_forward_inference(C.byref(cfg), arr, len(pairs), H.ptr(images), N, Hh, Ww, H.ptr(lease.ws), nb, H.ptr(out), H.ptr(fold),
                                                   fold.numel(), int(refold) | (2 if FOLD_BN[0] == 2 else 0), H.stream()), 'trunk_forward_inference')
@@ -438,6 +452,7 @@ class ResNetTrunk(nn.Sequential):
             ev = torch.cuda.Event()
             ev.record()
             self._evk_fold = (key, fold, ev)
+        lease.release_queued()
         del keep
         return out
 
