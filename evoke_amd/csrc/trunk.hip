@@ -40,30 +40,57 @@ evk_conv_geom geom(int N, int Hi, int Wi, int Ci, int Co, int k, int stride, int
   return g;
 }
 
-int make_plan(const evk_trunk_cfg* cfg, int N, int H, int W, Plan& P) {
+// infer: the plan of a forward that no backward follows.  Nothing but a block's input has to outlive the block, so the activations
+// live in TWO arenas the blocks alternate between (block k writes arena k & 1 and reads its input -- block k-1's output, or the pooled
+// stem output -- from the other one): 6 GB instead of 40 for 128 images at 384^2.  No gradient / slab / flipped-weight regions.
+int make_plan(const evk_trunk_cfg* cfg, int N, int H, int W, Plan& P, bool infer = false) {
   EVK_REQUIRE(cfg && N > 0 && H >= 32 && W >= 32 && H % 32 == 0 && W % 32 == 0, "trunk: image size must be a multiple of 32 (got %dx%d)", H, W);
   P.N = N; P.H = H; P.W = W;
   long off = 0;
   auto take = [&](long bytes) { long o = off; off = align256(off + bytes); return o; };
-  P.xpad = take((long)N * (H + 6) * (W + 8) * 4 * 2);
+  long arena[2] = {0, 0}, acur = 0, asize = 0;
+  auto atake = [&](long bytes) { long o = acur; acur = align256(acur + bytes); return o; };   // (inference: from the current arena)
+  if (infer) {
+    // the largest arena any block (or the stem) needs
+    long need = align256((long)N * (H + 6) * (W + 8) * 4 * 2) + 2 * align256((long)N * (H / 2) * (W / 2) * 64 * 2) + align256((long)N * (H / 4) * (W / 4) * 64 * 2);
+    int h0 = H / 4, w0 = W / 4;
+    for (int L = 0; L < 4; ++L)
+      for (int b = 0; b < cfg->blocks[L]; ++b) {
+        const int stride = b == 0 ? cfg->stride[L] : 1, pl = cfg->planes[L];
+        const int ho = (h0 - 1) / stride + 1, wo = (w0 - 1) / stride + 1;
+        long nb = 2 * align256((long)N * h0 * w0 * pl * 2) + 2 * align256((long)N * ho * wo * pl * 2) + 2 * align256((long)N * ho * wo * pl * 4 * 2);
+        if (b == 0) nb += 2 * align256((long)N * ho * wo * pl * 4 * 2);
+        if (nb > need) need = nb;
+        h0 = ho; w0 = wo;
+      }
+    asize = need;
+    arena[0] = take(need); arena[1] = take(need);
+    acur = arena[1];                                    // the stem plays block "-1"
+  }
+  P.xpad = infer ? atake((long)N * (H + 6) * (W + 8) * 4 * 2) : take((long)N * (H + 6) * (W + 8) * 4 * 2);
   P.wp = take(64 * 224 * 2);
-  P.dwp = take(64 * 224 * 4);
-  long gcap = 0, slab = evk_stem_wgrad_ws_bytes(N, H, W), part = 0;
+  P.dwp = infer ? -1 : take(64 * 224 * 4);
+  long gcap = 0, slab = infer ? 0 : evk_stem_wgrad_ws_bytes(N, H, W), part = 0;
   auto add_pair = [&](const evk_conv_geom& g, int C, long M) {
     Pair pr{};
     pr.g = g; pr.C = C; pr.M = M;
-    pr.y = take(M * C * 2); pr.z = take(M * C * 2); pr.stats = take(6L * C * 4);
-    pr.dy = take(M * C * 2); pr.sums = take(2L * C * 4);
-    if (M * C * 2 > gcap) gcap = M * C * 2;
-    if (evk_conv_stats_bytes(M, C) > part) part = evk_conv_stats_bytes(M, C);
+    if (infer) {
+      pr.y = atake(M * C * 2); pr.z = atake(M * C * 2); pr.stats = take(6L * C * 4);
+      pr.dy = pr.sums = -1;
+    } else {
+      pr.y = take(M * C * 2); pr.z = take(M * C * 2); pr.stats = take(6L * C * 4);
+      pr.dy = take(M * C * 2); pr.sums = take(2L * C * 4);
+      if (M * C * 2 > gcap) gcap = M * C * 2;
+      if (evk_conv_stats_bytes(M, C) > part) part = evk_conv_stats_bytes(M, C);
+    }
     P.pairs.push_back(pr);
   };
   int h = H / 2, w = W / 2;
   add_pair(evk_conv_geom{}, 64, (long)N * h * w);                 // stem
   h = (h - 1) / 2 + 1; w = (w - 1) / 2 + 1;
-  P.pooled = take((long)N * h * w * 64 * 2);
-  P.pool_idx = take((long)N * h * w * 64);
-  int inpl = 64;
+  P.pooled = infer ? atake((long)N * h * w * 64 * 2) : take((long)N * h * w * 64 * 2);
+  P.pool_idx = infer ? -1 : take((long)N * h * w * 64);
+  int inpl = 64, blk = 0;
   for (int L = 0; L < 4; ++L) {
     const int planes = cfg->planes[L];
     EVK_REQUIRE(cfg->blocks[L] >= 1 && planes >= 8 && (planes & (planes - 1)) == 0, "trunk: bad layer %d config", L);
@@ -71,11 +98,16 @@ int make_plan(const evk_trunk_cfg* cfg, int N, int H, int W, Plan& P) {
       const int stride = b == 0 ? cfg->stride[L] : 1;
       const bool down = b == 0;
       const int ho = (h - 1) / stride + 1, wo = (w - 1) / stride + 1;
+      if (infer) {
+        EVK_REQUIRE(acur <= arena[(blk + 1) & 1] + asize, "trunk: inference arena overflow before block %d", blk);
+        acur = arena[blk & 1];
+      }
+      ++blk;
       evk_conv_geom g1 = geom(N, h, w, inpl, planes, 1, 1, 0);
       evk_conv_geom g2 = geom(N, h, w, planes, planes, 3, stride, 1);
       evk_conv_geom g3 = geom(N, ho, wo, planes, planes * 4, 1, 1, 0);
       add_pair(g1, planes, (long)N * h * w);
-      if (evk_conv_xstat_bytes(&g1) > part) part = evk_conv_xstat_bytes(&g1);
+      if (!infer && evk_conv_xstat_bytes(&g1) > part) part = evk_conv_xstat_bytes(&g1);
       add_pair(g2, planes, (long)N * ho * wo);
       add_pair(g3, planes * 4, (long)N * ho * wo);
       if (down) {
@@ -83,6 +115,11 @@ int make_plan(const evk_trunk_cfg* cfg, int N, int H, int W, Plan& P) {
         add_pair(gd, planes * 4, (long)N * ho * wo);
       }
       P.has_down.push_back(down ? 1 : 0);
+      if (infer) {
+        EVK_REQUIRE(acur <= arena[(blk - 1) & 1] + asize, "trunk: inference arena overflow (block %d)", blk - 1);
+        inpl = planes * 4; h = ho; w = wo;
+        continue;
+      }
       for (size_t i = P.pairs.size() - (down ? 4 : 3); i < P.pairs.size(); ++i) {
         const long nb = evk_conv2d_wgrad_ws_bytes(&P.pairs[i].g);
         if (nb > slab) slab = nb;
@@ -90,6 +127,16 @@ int make_plan(const evk_trunk_cfg* cfg, int N, int H, int W, Plan& P) {
       if ((long)N * h * w * inpl * 2 > gcap) gcap = (long)N * h * w * inpl * 2;
       inpl = planes * 4; h = ho; w = wo;
     }
+  }
+  P.wflip.assign(P.pairs.size(), -1);
+  P.wcls.assign(P.pairs.size(), -1);
+  if (infer) {
+    P.gcap = 0; P.red_bytes = P.slab_bytes = P.part_bytes = 0;
+    P.red = P.slab = P.part = -1;
+    for (int i = 0; i < 6; ++i) P.gbuf[i] = -1;
+    P.zeros = take(2 * 2048 * 4);
+    P.total = off;
+    return EVK_OK;
   }
   P.gcap = gcap;
   for (int i = 0; i < 6; ++i) P.gbuf[i] = take(gcap);
@@ -100,8 +147,6 @@ int make_plan(const evk_trunk_cfg* cfg, int N, int H, int W, Plan& P) {
   P.zeros = take(2 * 2048 * 4);
   P.part_bytes = part;
   P.part = take(part);
-  P.wflip.assign(P.pairs.size(), -1);
-  P.wcls.assign(P.pairs.size(), -1);
   for (size_t i = 1; i < P.pairs.size(); ++i) {
     const evk_conv_geom& g = P.pairs[i].g;
     if (evk_conv3x3s2_dgrad_parity_supported(&g) && evk_conv3x3s2_dgrad_parity_ws_bytes(&g) <= gcap) P.wcls[i] = take((long)g.Co * 9 * g.Ci * 2);
@@ -219,6 +264,14 @@ int64_t evk_trunk_ws_bytes(const evk_trunk_cfg* cfg, int32_t N, int32_t H, int32
   return P.total;
 }
 
+/* workspace of evk_trunk_forward_inference: two arenas the blocks alternate between (6 GB for 128 images at 384^2; the training layout
+ * of evk_trunk_ws_bytes keeps every activation for the backward: 40 GB) */
+int64_t evk_trunk_infer_ws_bytes(const evk_trunk_cfg* cfg, int32_t N, int32_t H, int32_t W) {
+  Plan P;
+  if (make_plan(cfg, N, H, W, P, true) != EVK_OK) return -1;
+  return P.total;
+}
+
 int evk_trunk_num_pairs(const evk_trunk_cfg* cfg) {
   if (!cfg) return -1;
   int n = 1;
@@ -296,7 +349,7 @@ int evk_trunk_forward_inference(const evk_trunk_cfg* cfg, const evk_trunk_layer*
                                 int32_t H, int32_t W, void* ws, int64_t ws_bytes, void* out, void* fold_ws, int64_t fold_bytes, int32_t refold,
                                 evk_stream_t stream) {
   Plan P;
-  TRY(make_plan(cfg, N, H, W, P));
+  TRY(make_plan(cfg, N, H, W, P, true));
   EVK_REQUIRE(layers && images && ws && out && fold_ws, "trunk_forward_inference: null argument");
   EVK_REQUIRE(n_layers == (int)P.pairs.size(), "trunk_forward_inference: expected %d conv+bn pairs, got %d", (int)P.pairs.size(), n_layers);
   EVK_REQUIRE(ws_bytes >= P.total && fold_bytes >= evk_trunk_fold_bytes(cfg), "trunk_forward_inference: workspace too small");
@@ -317,10 +370,11 @@ int evk_trunk_forward_inference(const evk_trunk_cfg* cfg, const evk_trunk_layer*
   // z = relu?(conv(x, w) * scale + shift (+ resid)) in one launch where a route has the epilogue; conv, then the eval-mode bn pass, otherwise
   // refold == 2 / the caller's mode bit 1: the convolutions with an identity keep conv + bn_apply (with the cached vectors: no bn_finalize
   // launch) -- their fused form holds one 8-wave workgroup per CU for ~130 us, which a serving loop's small decode kernels then queue behind
-  const bool fuse_identity = !(refold & 2);
+  // bit 2: nothing fused at all -- conv + bn_apply per layer, i.e. the eval forward of evk_trunk_forward minus its bn_finalize launches
+  const bool fuse_identity = !(refold & 2), fuse = !(refold & 4);
   auto conv_affine = [&](int i, const void* xin, const void* resid, int relu) -> int {
     const evk_conv_geom& g = P.pairs[i].g;
-    if (evk_conv2d_fwd_affine_routes(&g) && (!resid || fuse_identity))
+    if (fuse && evk_conv2d_fwd_affine_routes(&g) && (!resid || fuse_identity))
       return evk_conv2d_fwd_affine(xin, layers[i].w, c.at(P.pairs[i].z), &g, sc[i], sh[i], resid, relu, stream);
     TRY(evk_conv2d_fwd_stats(xin, layers[i].w, c.at(P.pairs[i].y), &g, nullptr, 0, &nblk, stream));
     return evk_bn_apply(c.at(P.pairs[i].y), sc[i], sh[i], resid, c.at(P.pairs[i].z), P.pairs[i].M, P.pairs[i].C, relu, stream);
@@ -329,7 +383,7 @@ int evk_trunk_forward_inference(const evk_trunk_cfg* cfg, const evk_trunk_layer*
   TRY(evk_stem_pack_weight(reinterpret_cast<const float*>(layers[0].w), c.at(P.wp), stream));
   TRY(evk_stem_fwd_stats(c.at(P.xpad), c.at(P.wp), c.at(P.pairs[0].y), N, H, W, nullptr, 0, &nblk, stream));
   TRY(bn_forward(c, 0, nullptr, 1, nblk));
-  TRY(evk_maxpool3x3s2_fwd_idx(c.at(P.pairs[0].z), c.at(P.pooled), c.at(P.pool_idx), N, H / 2, W / 2, 64, stream));
+  TRY(evk_maxpool3x3s2_fwd(c.at(P.pairs[0].z), c.at(P.pooled), N, H / 2, W / 2, 64, stream));
   const void* x = c.at(P.pooled);
   int i = 1;
   for (size_t b = 0; b < P.has_down.size(); ++b) {

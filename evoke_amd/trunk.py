@@ -93,14 +93,17 @@ class _Stem(torch.autograd.Function):
         return None, None
 
 
-# EVK_FOLD_BN=1: eval mode under no_grad runs evk_trunk_forward_inference (csrc/trunk.hip): the eval-mode batch norms as per-channel scale /
-# shift in the convolutions' epilogues together with identity and ReLU -- no bn_finalize / bn_apply passes -- reproducing the unfused eval
-# forward (conv, bn_finalize, bn_apply per layer) BIT FOR BIT (tests/test_model_gpu.py, tests/test_hip_gemm.py).  Measured on MI355X, 128 images
-# at 384^2: 15.3 -> 13.5 ms per forward alone, but 117 -> 112 k tokens/s on the pipelined decode workload (the conv3 + identity kernels hold one
-# 8-wave, 220-VGPR workgroup per CU for the whole launch and the searches' small kernels wait for the slots) -- so it is OPT-IN.
-# EVK_FOLD_BN=2: the same, but convolutions that add an identity keep conv + bn_apply (14.2 ms alone, 120 k tokens/s in the pipeline -- on one
-# box; on another, 37 k: DESIGN.md section 9).
-FOLD_BN = [int(os.environ.get('EVK_FOLD_BN', '0') or 0)]          # 0 off, 1 every route that has the epilogue, 2 all but the convolutions with an identity
+# Eval mode under no_grad (report generation, validation) runs evk_trunk_forward_inference (csrc/trunk.hip): a forward that keeps nothing for
+# a backward -- two activation arenas the blocks alternate between (6 GB for 128 images at 384^2 instead of the training layout's 40), the
+# eval-mode batch-norm coefficients cached between calls.  EVK_FOLD_BN selects how much of the batch norm goes into the convolution epilogues;
+# every setting reproduces conv -> bn_finalize -> bn_apply of evk_trunk_forward BIT FOR BIT (tests/test_model_gpu.py, tests/test_hip_gemm.py):
+#   0  nothing fused: conv + bn_apply per layer (the same launches minus bn_finalize)
+#   1  scale / shift / identity / ReLU in the epilogue of every route that has one: slower -- 17.7 ms per forward of 128 images at 384^2
+#      against 15.3 (the conv3 + identity launches stream three 4P-wide tensors through the weight-stationary kernel's 64-byte row pieces
+#      and stage the identity through LDS to reproduce the unfused rounding), 112 k tokens/s in the serving loop against 117
+#   2  (default) the same except for the convolutions that add an identity: 14.2 ms, 120 k tokens/s
+#  -1  the training runner (evk_trunk_forward, training = 0) as before round 4
+FOLD_BN = [int(os.environ.get('EVK_FOLD_BN', '2') or 0)]
 
 
 class _WsLease:
@@ -413,7 +416,7 @@ class ResNetTrunk(nn.Sequential):
         assert images.dtype == F32 and images.is_cuda and images.dim() == 4 and images.shape[1] == 3
         if self.training:
             torch._foreach_add_([bn.num_batches_tracked for _, bn in self.pairs()], 1)
-        if not self.training and not torch.is_grad_enabled() and FOLD_BN[0]:
+        if not self.training and not torch.is_grad_enabled() and int(FOLD_BN[0]) >= 0:
             return self._forward_inference(images.contiguous())
         anchor = next((p for p in self.parameters() if p.requires_grad), self[0].weight)   # ties the node into the autograd graph
         return _TrunkFn.apply(images.contiguous(), anchor, self)
@@ -441,13 +444,14 @@ class ResNetTrunk(nn.Sequential):
         if not refold and st[2] is not None:
             torch.cuda.current_stream().wait_event(st[2])          # (the vectors may have been written on another stream)
         arr, keep = _TrunkFn._layers(pairs, False)
-        nb = H.lib.evk_trunk_ws_bytes(C.byref(cfg), N, Hh, Ww)
+        nb = H.lib.evk_trunk_infer_ws_bytes(C.byref(cfg), N, Hh, Ww)
         if nb < 0:
-            raise RuntimeError('evk_trunk_ws_bytes: ' + H.lib.evk_last_error().decode())
+            raise RuntimeError('evk_trunk_infer_ws_bytes: ' + H.lib.evk_last_error().decode())
         lease = _WsLease(nb, dev)
         out = _e(N, Hh // 32, Ww // 32, 4 * RESNET_LAYERS[-1][0], device=dev)
+        mode = {0: 4, 1: 0, 2: 2}[int(FOLD_BN[0])]
         H.check(H.lib.evk_trunk_forward_inference(C.byref(cfg), arr, len(pairs), H.ptr(images), N, Hh, Ww, H.ptr(lease.ws), nb, H.ptr(out), H.ptr(fold),
-                                                  fold.numel(), int(refold) | (2 if FOLD_BN[0] == 2 else 0), H.stream()), 'trunk_forward_inference')
+                                                  fold.numel(), int(refold) | mode, H.stream()), 'trunk_forward_inference')
         if refold:
             ev = torch.cuda.Event()
             ev.record()

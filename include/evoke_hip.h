@@ -315,8 +315,11 @@ int evk_trunk_forward(const evk_trunk_cfg* cfg, const evk_trunk_layer* layers, i
  * validation loops of modules/trainer_v0401.py:470-494, 592-658): the eval-mode batch norms as per-channel scale / shift applied to the
  * convolutions' f32 accumulators, identity / ReLU in the same epilogue.  fold_ws = evk_trunk_fold_bytes(cfg) bytes kept by the caller between
  * calls (the scale / shift vectors); refold bit 0 recomputes them (affine parameters or running statistics changed), bit 1 keeps the
- * convolutions that add an identity unfused (conv + evk_bn_apply with the cached vectors). */
+ * convolutions that add an identity unfused (conv + evk_bn_apply with the cached vectors), bit 2 keeps every layer unfused (the eval forward
+ * of evk_trunk_forward bit for bit, without its bn_finalize launches and on evk_trunk_infer_ws_bytes of workspace). */
 int64_t evk_trunk_fold_bytes(const evk_trunk_cfg* cfg);
+int64_t evk_trunk_infer_ws_bytes(const evk_trunk_cfg* cfg, int32_t N, int32_t H, int32_t W);   /* `ws` of the inference forward: two arenas the blocks
+                                                                                                   alternate between, no per-layer activations */
 int evk_trunk_forward_inference(const evk_trunk_cfg* cfg, const evk_trunk_layer* layers, int32_t n_layers, const float* images, int32_t N,
                                 int32_t H, int32_t W, void* ws, int64_t ws_bytes, void* out, void* fold_ws, int64_t fold_bytes, int32_t refold,
                                 evk_stream_t stream);

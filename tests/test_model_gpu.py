@@ -244,7 +244,7 @@ LOGP_TOL = 8e-3 if F16 else 6e-2          # flat, at every position: |engine log
 def test_inference_trunk_with_batchnorm_epilogues_follows_the_eval_forward(res):
     """The inference forward of the visual extractor (eval mode under no_grad: the eval-mode batch norms as scale / shift in the convolution
     epilogues together with identity and ReLU, evk_trunk_forward_inference) against the unfused eval forward of the same module
-    (EVK_FOLD_BN=0: conv, bn_finalize, bn_apply per layer), whose arithmetic the epilogues reproduce bit for bit, and against the fp32
+    (EVK_FOLD_BN=-1: the training runner's conv, bn_finalize, bn_apply per layer), whose arithmetic every mode reproduces bit for bit, and against the fp32
     oracle; and the scale / shift vectors must follow the parameters: after a change of a running statistic the next call recomputes them."""
     from evoke_amd import trunk as T
     from evoke_amd.trunk import ResNet
@@ -267,9 +267,11 @@ def test_inference_trunk_with_batchnorm_epilogues_follows_the_eval_forward(res):
         finally:
             T.FOLD_BN[0] = saved
 
-    att_f = run(True)
+    att_f = run(1)
     assert getattr(m.model, '_evk_fold', None) is not None, 'the inference path did not run'
-    att_u = run(False)
+    att_u = run(-1)                                            # the training runner (evk_trunk_forward, training = 0)
+    for mode in (2, 0):                                        # identity convolutions unfused / nothing fused: the same bits again
+        assert torch.equal(run(mode), att_u), 'inference trunk mode %d differs from the training runner' % mode
     ref = O.resnet101_trunk(S.procedural_state(spec), inp['images'], O.Ctx(train=False))
     n, c = ref.shape[:2]
     ref_p = ref.reshape(n, c, -1).permute(0, 2, 1)
@@ -279,7 +281,8 @@ def test_inference_trunk_with_batchnorm_epilogues_follows_the_eval_forward(res):
     # the vectors follow the parameters
     with torch.no_grad():
         m.model.pairs()[5][1].running_var.mul_(4.0)
-    att_2, att_2u = run(True), run(False)
+    att_2, att_2u = run(1), run(-1)
+    assert torch.equal(run(2), att_2u)
     assert torch.equal(att_2, att_2u)
     assert rel_err(att_2.float(), att_f.float().cpu()) > 1e-3, 'the running statistic changed but the scale / shift vectors did not'
 
@@ -879,18 +882,19 @@ def test_pipelined_generation_equals_per_batch_inference():
     {'EVK_DECODE_THREADS': '1', 'EVK_DECODE_BURST': '1', 'EVK_DECODE_AHEAD': '1'},     # host threads, one step per native call
     {'EVK_DECODE_THREADS': '1', 'EVK_DECODE_DEPTH': '3', 'EVK_DECODE_BURST': '5'},     # three searches in flight, bursts that do not divide the loop
     {'EVK_DECODE_THREADS': '1', 'EVK_ENC_RESERVE_CUS': '8'},                       # encoders on a CU-masked stream (hip.masked_stream)
-    {'EVK_DECODE_THREADS': '1', 'EVK_FOLD_BN': '1'},                               # batch norms in the convolution epilogues (bit-identical forward)
-], ids=['one_thread', 'threads_burst1', 'depth3_burst5', 'cu_mask', 'fused_bn'])
+    {'EVK_DECODE_THREADS': '1', 'EVK_FOLD_BN': '1'},                               # batch norms in every convolution epilogue that has one
+    {'EVK_DECODE_THREADS': '1', 'EVK_FOLD_BN': '0'},                               # inference runner, nothing fused
+    {'EVK_DECODE_THREADS': '1', 'EVK_FOLD_BN': '-1'},                              # the training runner in eval mode (before round 4)
+], ids=['one_thread', 'threads_burst1', 'depth3_burst5', 'cu_mask', 'fused_bn', 'unfused_runner', 'training_runner'])
 def test_pipelined_generation_modes_return_the_same_ids(env, monkeypatch):
     """Every way generate_pipelined can drive the searches (host threads issuing native bursts of token steps / one thread round-robin,
-    2 or 3 searches in flight, encoders on a CU-masked stream, the fused inference trunk) returns the ids of forward(mode='inference'),
-    five batches of three different structures, in batch order."""
+    2 or 3 searches in flight, encoders on a CU-masked stream, every setting of the inference trunk) returns the ids of
+    forward(mode='inference') over the training runner, five batches of three different structures, in batch order."""
     from evoke_amd import trunk as T
     from evoke_amd.model_pretrain_finetune import FineTune
     from oracle import spec as S
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    monkeypatch.setattr(T, 'FOLD_BN', [env.get('EVK_FOLD_BN', '0') != '0'])
     args = dict(ARGS, max_seq_len=20, beam_size=3)
     model = FineTune(args, load_tokenizer(), 'iu_xray')
     load_procedural(model, S.finetune_spec(V))
@@ -901,9 +905,9 @@ def test_pipelined_generation_modes_return_the_same_ids(env, monkeypatch):
         batches.append((inp['images'].cuda() * (1.0 + 0.05 * k), inp['ids'].cuda(), inp['masks'].cuda(), np.array(inp['patient_ids']), inp['inc_ids'],
                         inp['inc_masks']))
     with torch.no_grad():
-        monkeypatch.setattr(T, 'FOLD_BN', [False])
+        monkeypatch.setattr(T, 'FOLD_BN', [-1])
         want = [model(*b, mode='inference')[1].cpu() for b in batches]
-        monkeypatch.setattr(T, 'FOLD_BN', [env.get('EVK_FOLD_BN', '0') != '0'])
+        monkeypatch.setattr(T, 'FOLD_BN', [int(env.get('EVK_FOLD_BN', '2'))])
         got = [seq.cpu() for _, seq in model.generate_pipelined(batches, mode='inference')]
     assert len(got) == len(want)
     for k, (w, g) in enumerate(zip(want, got)):

@@ -15,7 +15,7 @@ with torch.no_grad():
     for _ in range(30):                           # running statistics of a network that has seen data (fresh ones overflow fp16 in eval mode)
         m(img[:16])
 m.eval()
-for fold in {'both': (1, 0, 2, 1, 0, 2), '0': (0,), '1': (1,), '2': (2,)}[which]:
+for fold in {'both': (-1, 0, 1, 2, -1, 0, 1, 2), '-1': (-1,), '0': (0,), '1': (1,), '2': (2,)}[which]:
     T.FOLD_BN[0] = fold
     with torch.no_grad():
         for _ in range(3):
