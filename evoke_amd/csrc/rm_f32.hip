@@ -39,6 +39,46 @@ struct GemmF3 { GemmF g[3]; int nprob; int b1, b2; GateE gate; int has_gate; }; 
 constexpr int FTM = 32, FTN = 64, FKC = 64, FLD = FKC + 4;          // LDS row pitch 68 floats: 16 lanes x 16 B land in 16 different bank groups
 constexpr int FSTAGE = (FTM + FTN) * FLD;                            // floats per stage (6528)
 
+// SPLIT (fp16-storage build): every f32 operand element x goes into LDS as TWO fp16 values, hi = fp16(x) and lo = fp16(x - hi) (x = hi + lo to
+// 2^-22 |x|), and the product is accumulated in f32 from three 16-bit MFMAs per 32-deep step -- hi.hi + hi.lo + lo.hi; the lo.lo term is below
+// f32's own rounding -- on v_mfma_f32_16x16x32_f16 (16 x the f32 MFMA's rate: 6 instructions of 16 cycles replace 16 of 32).  Same bytes from
+// memory (the f32 masters), same LDS footprint (2 + 2 bytes per element), the split done once per element on its way into LDS.  The error of
+// MEASURED: the products get 2.5 x cheaper but the launches are latency bound -- decode 119.9 -> 121.5 k tokens/s, train step 48.85 -> 48.65 ms
+// (two A/B pairs on one box) -- while the 60-token recurrence of tests/test_hip_ops.py ends 4.9 x the f32 oracle's distance from float64
+// (f32 MFMA: 0.5 x; operands to 2^-22 instead of 2^-24).  Model-level parity is unchanged (log-probabilities 2-3e-3 from the reference in
+// both modes: 16-bit noise elsewhere dominates), but a 1 % gain does not buy a 9 x coarser recurrence: OPT-IN (EVK_RM_SPLIT16=1).
+constexpr int HLD = FKC + 8;                                         // fp16 row pitch (144 bytes: 16-byte reads of 16 rows hit 16 bank groups)
+constexpr int HIMG = (FTM + FTN) * HLD;                              // halfs per image (hi or lo) of one stage
+__device__ __forceinline__ void split4(const float4 x, uint2& h, uint2& l) {
+#ifdef EVK_STORE_F16
+  const float v[4] = {x.x, x.y, x.z, x.w};
+  unsigned short hh[4], ll[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const _Float16 a = (_Float16)v[i];
+    const _Float16 b = (_Float16)(v[i] - (float)a);
+    hh[i] = __builtin_bit_cast(unsigned short, a);
+    ll[i] = __builtin_bit_cast(unsigned short, b);
+  }
+  h = make_uint2((uint32_t)hh[0] | ((uint32_t)hh[1] << 16), (uint32_t)hh[2] | ((uint32_t)hh[3] << 16));
+  l = make_uint2((uint32_t)ll[0] | ((uint32_t)ll[1] << 16), (uint32_t)ll[2] | ((uint32_t)ll[3] << 16));
+#else
+  h = l = make_uint2(0, 0);
+#endif
+}
+
+// 1: split products (opt-in, fp16-storage build only), 0: f32 MFMA (default).  EVK_RM_SPLIT16 sets the initial value, evk_rm_f32_split16() changes it.
+int g_split16 = -1;
+inline int rm_split16() {
+#ifdef EVK_STORE_F16
+  if (g_split16 < 0) { const char* e = getenv("EVK_RM_SPLIT16"); g_split16 = e ? (atoi(e) != 0) : 0; }
+  return g_split16;
+#else
+  return 0;                                   // (bf16 has 8 significand bits: three terms would not reach f32)
+#endif
+}
+
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmF3 pp) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -77,12 +117,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmF3 pp) {
       x0_ = make_float4(tanhf(x0_.x), tanhf(x0_.y), tanhf(x0_.z), tanhf(x0_.w));     \
       x1_ = make_float4(tanhf(x1_.x), tanhf(x1_.y), tanhf(x1_.z), tanhf(x1_.w));     \
     }                                                                                \
-    *reinterpret_cast<float4*>(As_ + pr * FLD + pc * 4) = x0_;                       \
-    *reinterpret_cast<float4*>(As_ + (pr + 16) * FLD + pc * 4) = x1_;                \
-    *reinterpret_cast<float4*>(Bs_ + pr * FLD + pc * 4) = B0;                        \
-    *reinterpret_cast<float4*>(Bs_ + (pr + 16) * FLD + pc * 4) = B1;                 \
-    *reinterpret_cast<float4*>(Bs_ + (pr + 32) * FLD + pc * 4) = B2;                 \
-    *reinterpret_cast<float4*>(Bs_ + (pr + 48) * FLD + pc * 4) = B3;                 \
+    if (SPLIT) {                                                                     \
+      unsigned short* const H_ = reinterpret_cast<unsigned short*>(sm) + (stage) * 2 * HIMG;   \
+      unsigned short* const L_ = H_ + HIMG;                                          \
+      const float4 xs_[6] = {x0_, x1_, B0, B1, B2, B3};                              \
+      _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) {                             \
+        const int row_ = (i_ < 2 ? pr + 16 * i_ : FTM + pr + 16 * (i_ - 2));         \
+        uint2 h_, l_;                                                                \
+        split4(xs_[i_], h_, l_);                                                     \
+        *reinterpret_cast<uint2*>(H_ + row_ * HLD + pc * 4) = h_;                    \
+        *reinterpret_cast<uint2*>(L_ + row_ * HLD + pc * 4) = l_;                    \
+      }                                                                              \
+    } else {                                                                         \
+      *reinterpret_cast<float4*>(As_ + pr * FLD + pc * 4) = x0_;                     \
+      *reinterpret_cast<float4*>(As_ + (pr + 16) * FLD + pc * 4) = x1_;              \
+      *reinterpret_cast<float4*>(Bs_ + pr * FLD + pc * 4) = B0;                      \
+      *reinterpret_cast<float4*>(Bs_ + (pr + 16) * FLD + pc * 4) = B1;               \
+      *reinterpret_cast<float4*>(Bs_ + (pr + 32) * FLD + pc * 4) = B2;               \
+      *reinterpret_cast<float4*>(Bs_ + (pr + 48) * FLD + pc * 4) = B3;               \
+    }                                                                                \
   }
 #define EVK_F32_SET0 r00, r01, r02, r03, r04, r05
 #define EVK_F32_SET1 r10, r11, r12, r13, r14, r15
@@ -94,6 +147,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmF3 pp) {
   const int wm = wave >> 1, wn = wave & 1;
   const int aoff = (wm * 16 + (lane & 15)) * FLD + 4 * (lane >> 4);
   const int boff = FTM * FLD + (wn * 32 + (lane & 15)) * FLD + 4 * (lane >> 4);
+  const int haoff = (wm * 16 + (lane & 15)) * HLD + 8 * (lane >> 4);                       // (SPLIT) 8 consecutive k of the lane's row
+  const int hboff = (FTM + wn * 32 + (lane & 15)) * HLD + 8 * (lane >> 4);
   f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   constexpr int NCH = KP / FKC;
   static_assert(NCH == 8, "the chunk loop below is written out for eight chunks");
@@ -103,7 +158,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmF3 pp) {
   EVK_F32_SS(EVK_F32_SET0, 0)
   __syncthreads();
 #define EVK_F32_MAC(c)                                                                              \
-  {                                                                                                 \
+  if (SPLIT) {                                                                                      \
+    const unsigned short* const H_ = reinterpret_cast<const unsigned short*>(sm) + ((c) & 1) * 2 * HIMG;   \
+    const unsigned short* const L_ = H_ + HIMG;                                                     \
+    _Pragma("unroll") for (int q = 0; q < FKC / 32; ++q) {                                          \
+      const bf16x8 ah = *reinterpret_cast<const bf16x8*>(H_ + haoff + 32 * q), al = *reinterpret_cast<const bf16x8*>(L_ + haoff + 32 * q);        \
+      const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(H_ + hboff + 32 * q), bl0 = *reinterpret_cast<const bf16x8*>(L_ + hboff + 32 * q);      \
+      const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(H_ + hboff + 16 * HLD + 32 * q), bl1 = *reinterpret_cast<const bf16x8*>(L_ + hboff + 16 * HLD + 32 * q);  \
+      acc[0] = EVK_MFMA_16x16x32(ah, bh0, acc[0], 0, 0, 0);                                         \
+      acc[1] = EVK_MFMA_16x16x32(ah, bh1, acc[1], 0, 0, 0);                                         \
+      acc[0] = EVK_MFMA_16x16x32(ah, bl0, acc[0], 0, 0, 0);                                         \
+      acc[1] = EVK_MFMA_16x16x32(ah, bl1, acc[1], 0, 0, 0);                                         \
+      acc[0] = EVK_MFMA_16x16x32(al, bh0, acc[0], 0, 0, 0);                                         \
+      acc[1] = EVK_MFMA_16x16x32(al, bh1, acc[1], 0, 0, 0);                                         \
+    }                                                                                               \
+    __syncthreads();                                                                                \
+  } else {                                                                                          \
     const float* const S = sm + ((c) & 1) * FSTAGE;                                                 \
     _Pragma("unroll") for (int q = 0; q < FKC / 16; ++q) {                                          \
       const float4 a4 = *reinterpret_cast<const float4*>(S + aoff + 16 * q);                        \
@@ -179,9 +249,11 @@ inline GemmF mkf(const float* A, long lda, const float* W, const float* bias, co
 int gemm_f32_multi(const GemmF* g, int nprob, const GateE* gate, hipStream_t s) {
   EVK_REQUIRE(nprob >= 1 && nprob <= 3, "rm f32 gemm: 1 .. 3 problems per launch");
   static bool attr_done = false;
-  constexpr int LDS = 2 * FSTAGE * 4;
+  constexpr int LDS = (2 * FSTAGE * 4 > 2 * 2 * HIMG * 2) ? 2 * FSTAGE * 4 : 2 * 2 * HIMG * 2;
+  const bool split = rm_split16() != 0;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr_done = true;
   }
   GemmF3 pp{};
@@ -195,7 +267,8 @@ int gemm_f32_multi(const GemmF* g, int nprob, const GateE* gate, hipStream_t s) 
   pp.b1 = blocks[0]; pp.b2 = blocks[0] + blocks[1];
   pp.has_gate = gate ? 1 : 0;
   if (gate) { EVK_REQUIRE(nprob == 1 && g[0].N == D512, "rm f32 gemm: the gate epilogue rides on the single 512-column product"); pp.gate = *gate; }
-  hipLaunchKernelGGL(gemm_f32_kernel, dim3(blocks[0] + blocks[1] + blocks[2]), dim3(256), LDS, s, pp);
+  if (split) hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3(blocks[0] + blocks[1] + blocks[2]), dim3(256), LDS, s, pp);
+  else hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3(blocks[0] + blocks[1] + blocks[2]), dim3(256), LDS, s, pp);
   return evk_check_launch("rm f32 gemm");
 }
 
@@ -363,6 +436,17 @@ int rmf32_gate_train(const float* xp, long x_bstride, const float* gu, const flo
 }
 
 extern "C" {
+
+/* how the f32 relational-memory products are formed: 1 = three fp16 MFMAs over hi / lo halves of the f32 operands (fp16-storage build only),
+ * 0 = v_mfma_f32_16x16x4_f32; mode < 0 only queries.  Returns the mode in force. */
+int evk_rm_f32_split16(int32_t mode) {
+  (void)rm_split16();
+#ifdef EVK_STORE_F16
+  if (mode >= 0) g_split16 = mode != 0;
+#endif
+  return rm_split16();
+}
+
 
 int64_t evk_rm_decode_f32_ws_bytes(int32_t B) {
   const long R = (long)B * S3;

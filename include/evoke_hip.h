@@ -619,6 +619,11 @@ int evk_rm_decode_step(const void* x, const void* Wx, const float* bx, void* mem
  * (v_mfma_f32_16x16x4_f32: a k-ordered fmaf chain).  out16 [B][1536] = the new memory in the 16-bit storage format for the decoder's
  * conditional layer norms (that path does not feed back).  8 launches, like the 16-bit step. */
 int64_t evk_rm_decode_f32_ws_bytes(int32_t B);
+/* Arithmetic of the f32 relational-memory products (evk_rm_decode_step_f32, evk_rm_forward_f32; RelationalMemory.forward_step,
+ * modules/encoder_decoder.py:274-291): mode 0 (default) uses v_mfma_f32_16x16x4_f32; mode 1 (fp16-storage build only, opt-in) splits every
+ * f32 operand element into hi + lo fp16 halves and accumulates hi.hi + hi.lo + lo.hi in f32 on the 16-bit MFMA -- operands to 2^-22, +1 %
+ * throughput, 9 x the rounding of mode 0 in a long recurrence --; mode < 0 queries.  Returns the mode in force.  Env EVK_RM_SPLIT16 = initial value. */
+int evk_rm_f32_split16(int32_t mode);
 int evk_rm_decode_step_f32(const float* x, const float* Wx, const float* bx, float* mem, const float* Wqkv, const float* bqkv, const float* Wo,
                            const float* bo, const float* W0, const float* b0, const float* W2, const float* b2, const float* U, const float* bU,
                            void* out16, void* ws, int64_t ws_bytes, int32_t B, evk_stream_t stream);

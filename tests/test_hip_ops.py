@@ -657,15 +657,29 @@ def test_rm_decode_step_is_bit_identical_to_the_recurrence_runner():
             assert torch.equal(tmem.float(), torch.tanh(mem_b.float()).to(BF).float()) or (tmem.float() - torch.tanh(mem_b.float())).abs().max() < 2e-3
 
 
-def test_rm_decode_step_f32_follows_the_fp32_oracle_through_a_long_recurrence():
-    """evk_rm_decode_step_f32 (the decode step's relational memory on the f32-input MFMA, f32 masters, f32 state) against the oracle's
-    rm_step (CPU restatement of modules/encoder_decoder.py:274-291) over 60 consecutive tokens from the same inputs.  The recurrence
-    amplifies rounding (that is why it runs in f32), so the yardstick is the oracle itself: run in float64 it is the truth, run in float32
-    it shows what f32 arithmetic can do; the engine must stay within 4 x the f32 oracle's own distance from the truth (+ 1e-5).  The
-    16-bit row handed to the decoder must be the memory rounded."""
+@pytest.mark.parametrize('split', [0, 1])
+def test_rm_decode_step_f32_follows_the_fp32_oracle_through_a_long_recurrence(split):
+    """evk_rm_decode_step_f32 (the decode step's relational memory: f32 masters, f32 state, products on the f32-input MFMA -- split 0 -- or
+    as three fp16 MFMAs over hi / lo halves of the f32 operands -- split 1, opt-in in the fp16 build, evk_rm_f32_split16) against the
+    oracle's rm_step (CPU restatement of modules/encoder_decoder.py:274-291) over 60 consecutive tokens from the same inputs.  The
+    recurrence amplifies rounding (that is why it runs in f32), so the yardstick is the oracle itself: run in float64 it is the truth,
+    run in float32 it shows what f32 arithmetic can do; the engine must stay within 4 x the f32 oracle's own distance from the truth
+    (+ 1e-5) on the f32 MFMA and within 8 x with split operands (2^-22 per operand against 2^-24; measured 4.9 x; the 16-bit recurrence
+    this path replaced: > 1000 x).  The 16-bit row handed to the decoder must be the memory rounded."""
     from evoke_amd import hip as H
     from evoke_amd.layers import RelationalMemory
     from oracle import functional as O
+    before = H.lib.evk_rm_f32_split16(-1)
+    if H.lib.evk_rm_f32_split16(split) != split:
+        H.lib.evk_rm_f32_split16(before)
+        pytest.skip('this build forms the products on the f32 MFMA only')
+    try:
+        _rm_recurrence_against_the_oracles(H, RelationalMemory, O, 8 if split else 4)
+    finally:
+        H.lib.evk_rm_f32_split16(before)
+
+
+def _rm_recurrence_against_the_oracles(H, RelationalMemory, O, factor):
     torch.manual_seed(6)
     rm = RelationalMemory(3, 512, 8).cuda().eval()
     with torch.no_grad():
@@ -708,7 +722,7 @@ def test_rm_decode_step_f32_follows_the_fp32_oracle_through_a_long_recurrence():
             worst = max(worst, err)
             assert torch.equal(out16.float().cpu(), mem.reshape(B, -1).to(BF).float().cpu())
     print('\n[f32 relational memory] max |memory - float64 oracle| over 60 tokens: engine %.2e, float32 oracle %.2e' % (worst, worst32))
-    assert worst <= 4 * worst32 + 1e-5, (worst, worst32)
+    assert worst <= factor * worst32 + 1e-5, (worst, worst32)
 
 
 def test_conv_fwd_stats_and_dgrad_add():
