@@ -172,13 +172,15 @@ class FineTune(_Base):
         loop to the launch queue from native code (evk_replay_run_n: the interpreter is not on the per-token path, the GIL is free);
         this thread meanwhile queues the visual extractor / fusion / text encoders of the following batch on a further stream.  Per batch the
         kernels, their order and therefore the results are exactly those of forward() (tests/test_model_gpu.py).  batches: iterable of
-        (images, report_ids, report_masks, patient_ids, inc_ids, inc_masks); r2gen decoder only.  depth: EVK_DECODE_DEPTH or 2."""
+        (images, report_ids, report_masks, patient_ids, inc_ids, inc_masks).  depth: EVK_DECODE_DEPTH or 2.  (The distilgpt2 backend has no
+        stepwise sessions: for it only the encoders run ahead, _generate_encoders_ahead.)"""
         import os
         from collections import deque
         if mode not in ('sample', 'inference'):
             raise ValueError
         if self.decoder_kind != 'r2gen':
-            raise NotImplementedError('generate_pipelined: the r2gen decoder backend')
+            yield from self._generate_encoders_ahead(batches, mode)
+            return
         from .decode import beam_search
         depth = max(1, int(depth if depth is not None else os.environ.get('EVK_DECODE_DEPTH', '2')))
         # EVK_DECODE_THREADS=1 (default): one host thread per search in flight issues its token loop (evk_replay_run_n, GIL released);
@@ -321,6 +323,50 @@ class FineTune(_Base):
                 pool.shutdown(wait=True)
             for st in [enc_s] + dec_s:
                 cur.wait_stream(st)
+            self.train(was_training)
+
+    def _generate_encoders_ahead(self, batches, mode):
+        """generate_pipelined for a decoder backend without stepwise sessions (distilgpt2: its generate() drives the search from the host,
+        language_model.py:271-280): the encoders of batch k + 1 are queued on a second stream BEFORE batch k is generated, so the GPU
+        runs them in the gaps of that host-driven search.  Results are those of forward(mode=mode), batch for batch."""
+        was_training = self.training
+        self.eval()
+        cur = torch.cuda.current_stream()
+        enc_s = torch.cuda.Stream()
+        enc_s.wait_stream(cur)
+
+        def encode(batch):
+            images, report_ids, report_masks, patient_ids, inc_ids, inc_masks = batch
+            enc_s.wait_stream(torch.cuda.current_stream())           # (the batch may have been uploaded on the caller's stream just now)
+            for t in (images, report_ids, report_masks, inc_ids, inc_masks):
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(enc_s)
+            with torch.cuda.stream(enc_s):
+                x, enc_mask = self.encoder_states(images, patient_ids, report_ids.shape[0], inc_ids, inc_masks)
+                ev = torch.cuda.Event()
+                ev.record(enc_s)
+            return x, enc_mask, ev, report_ids, report_masks
+
+        def generate(enc):
+            x, enc_mask, ev, report_ids, report_masks = enc
+            here = torch.cuda.current_stream()
+            here.wait_event(ev)
+            x.record_stream(here)
+            enc_mask.record_stream(here)
+            ret = self.text_decoder_forward(report_ids.to(x.device), report_masks.to(x.device), x, enc_mask, mode=mode)
+            return [ret[0], ret[1]]
+
+        try:
+            prev = None
+            for batch in batches:
+                enc = encode(batch)
+                if prev is not None:
+                    yield generate(prev)
+                prev = enc
+            if prev is not None:
+                yield generate(prev)
+        finally:
+            cur.wait_stream(enc_s)
             self.train(was_training)
 
     def forward(self, images, report_ids, report_masks, patient_ids, inc_ids=None, inc_masks=None, mode='train'):

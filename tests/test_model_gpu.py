@@ -585,6 +585,15 @@ def test_finetune_with_distilgpt2_decoder_matches_reference_composition():
     assert len(texts) == case['B'] and seq.dtype == torch.long
     if F16:
         assert seq.shape == wseq.shape and torch.equal(seq, wseq), 'generated token ids differ from the HF fixture'
+    # the serving loop over this backend (encoders of the next batch queued ahead of the host-driven generate): forward()'s results
+    with torch.no_grad():
+        b = (inp['images'].cuda(), inp['ids'].cuda(), inp['masks'].cuda(), np.array(inp['patient_ids']), inp['inc_ids'], inp['inc_masks'])
+        b2 = (b[0] * 1.05,) + b[1:]
+        want2 = [model(*bb, mode='inference') for bb in (b, b2, b)]
+        got2 = list(model.generate_pipelined([b, b2, b], mode='inference'))
+    assert len(got2) == 3
+    for (wt, ws), (gt, gs) in zip(want2, got2):
+        assert wt == gt and torch.equal(ws.cpu(), gs.cpu()), 'generate_pipelined (distilgpt2) differs from forward(mode=inference)'
     ops.set_dropout_enabled(True)
     assert not bad, bad
 
