@@ -192,6 +192,8 @@ def decode_record(model, a, rank, world, dev, with_cpu):
                                % (a.res, beam, B, a.views, L, V), 'parallelism': 'replicas x%d' % world,
                    'mean_generated_len': float((seq != 0).sum(1).float().mean().item()), 'hip_graph_step': DEC.stats.get('graph'),
                    'pipelined_encoders': pipelined, 'searches_in_flight': depth,
+                   'host_thread_per_search': pipelined and os.environ.get('EVK_DECODE_THREADS', '1') != '0',
+                   'inference_trunk_mode': int(__import__('evoke_amd.trunk', fromlist=['FOLD_BN']).FOLD_BN[0]),
                    'relational_memory': 'f32 (default)' if DEC._RM_F32[0] else '16-bit (EVK_DECODE_RM_F32=0)',
                    'fused_beam_bookkeeping': DEC.stats.get('fused_bookkeeping'), 'launches_per_token_step': n_launch},
         'roofline': {'bound': 'hbm', 'kernel': 'per-token decode step (captured once, re-issued by csrc/replay.hip: relational-memory step, 3 decoder layers, '
