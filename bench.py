@@ -184,13 +184,17 @@ def decode_record(model, a, rank, world, dev, with_cpu):
     eff_step_ms = ms_per_batch / L
     ach = L * alg_bytes / (ms_per_batch * 1e-3) / 1e9
     n_launch = DEC.stats.get('step_launches')
+    mean_len = float((seq != 0).sum(1).float().mean().item())
     rec = {
         'metric': 'decode tokens/sec (beam search, %d^2)' % a.res, 'value': B * L * n * world / dt, 'unit': 'tokens/s', 'steps': n,
+        # `value` counts token POSITIONS run (every hypothesis is extended for all max_seq_len positions, as the reference does);
+        # emitted_tokens_per_s counts only the tokens of the returned reports (up to and excluding the padding after [EOS])
+        'positions_per_s': B * L * n * world / dt, 'emitted_tokens_per_s': B * mean_len * n * world / dt,
         'ms_per_batch': ms_per_batch, 'higher_is_better': True, 'dtype': H.STORE,
         'config': {'workload': 'EVOKE-%d inference: beam=%d, batch %d studies x %d views, max_seq_len %d (all steps run, as the reference), '
                                'incremental decoder state, visual extractor + fusion included, V=%d, random-init weights'
                                % (a.res, beam, B, a.views, L, V), 'parallelism': 'replicas x%d' % world,
-                   'mean_generated_len': float((seq != 0).sum(1).float().mean().item()), 'hip_graph_step': DEC.stats.get('graph'),
+                   'mean_generated_len': mean_len, 'hip_graph_step': DEC.stats.get('graph'),
                    'pipelined_encoders': pipelined, 'searches_in_flight': depth,
                    'host_thread_per_search': pipelined and os.environ.get('EVK_DECODE_THREADS', '1') != '0',
                    'inference_trunk_mode': int(__import__('evoke_amd.trunk', fromlist=['FOLD_BN']).FOLD_BN[0]),
@@ -394,7 +398,7 @@ def main():
     L, Li = (100, 30) if kind == 'finetune' else (40, 0)
     model = (FineTune if kind == 'finetune' else Pretrain)(args, load_tokenizer(), 'mimic_cxr').to(dev)
     model.train()
-    if kind == 'pretrain' and world > 1:
+    if kind == 'pretrain' and (world > 1 or D.forced()):
         model.gather = D.gather_rows
     opt = optim.build_two_stage_optimizer(args, model, clip_value=0.1)
     red = D.GradReducer.for_optimizer(opt)
@@ -438,6 +442,8 @@ def main():
     for _ in range(n_warm):
         step()
     barrier()
+    skipped0 = ops.overflow_steps(dev)
+    red.timing = bool(red.active)          # events around the collectives (a process group exists: N > 1, or the EVK_FORCE_DIST=1 rehearsal)
     t0 = time.perf_counter()
     losses = []
     for i in range(a.steps):
@@ -445,6 +451,11 @@ def main():
     host_dt = time.perf_counter() - t0
     barrier()
     dt = time.perf_counter() - t0
+    comm = red.comm_stats(a.steps) if red.timing else None
+    if comm is not None:
+        comm['backend'] = torch.distributed.get_backend()
+    red.timing = False
+    skipped = ops.overflow_steps(dev) - skipped0
     # host cost of ISSUING one step, measured from an idle GPU (inside the timed loop the launch queue is full whenever the GPU is
     # the bottleneck, so the loop's host time mostly measures the GPU): two more steps, each issued after a full synchronisation
     issue = []
@@ -503,8 +514,13 @@ def main():
         'vs_baseline': None, 'dtype': H.STORE, 'data': 'synthetic',
         'config': {'workload': 'EVOKE-%d %s-view %s train step (fwd+bwd+allreduce+clip+RAdam), %d studies (%d images) per GPU, '
                                'L=%d, Li=%d, V=%d, random-init weights' % (a.res, a.views, kind, a.batch, int(batch['images'].shape[0]), L, Li, V),
-                   'parallelism': 'dp%d' % world, 'rccl_ranks': D.world_size(), 'grad_sync': red.mode if world > 1 else 'none (1 rank)',
-                   'loss_last': float(losses[-1].item()),
+                   'parallelism': 'dp%d' % world, 'rccl_ranks': D.world_size(),
+                   'grad_sync': (red.mode + (' (EVK_FORCE_DIST=1: 1-rank process group, every collective issued)' if D.forced() and world == 1 else ''))
+                   if red.active else 'none (1 rank, no process group)',
+                   'comm': comm, 'loss_last': float(losses[-1].item()),
+                   # a dynamic-loss-scale overflow skips the optimizer update of that step (fp16 storage): steps of the timed region it skipped
+                   'overflow_skipped_steps': skipped, 'loss_scale': ops.loss_scale_value(dev),
+                   'batches': 'one synthetic batch per rank, fed every step',
                    'host_launch_ms_per_step': host_issue_ms, 'host_loop_ms_per_step': 1e3 * host_dt / a.steps,
                    'step_graph': bool(use_graph and getattr(step, 'graph', None) is not None),
                    'step_replay_plan': getattr(step, 'info', None)},

@@ -342,7 +342,7 @@ int evk_beam_step(const float* logp, int32_t ld, int32_t V1, int32_t beam, int32
   EVK_REQUIRE((!mem || (mem_row > 0 && mem_row % 2 == 0)) && (!anc || anc_cols > 0), "beam_step: bad state geometry");
   EVK_REQUIRE(!pos_advance || ticket, "beam_step: advancing the position needs a (zero-initialised) ticket word");
   EVK_REQUIRE(!mem2 || mem, "beam_step: mem2 needs mem");
-  static const int fast_on = [] { const char* e = getenv("EVK_BEAM_STEP_FAST"); return e ? atoi(e) : 1; }();
+  static const int fast_on = evk_tunable("EVK_BEAM_STEP_FAST", 1);
   const bool fast = fast_on && V1 <= CMAX * 64;
   const size_t lds = (size_t)beam * max_len * 8 + (anc ? (size_t)beam * anc_cols * 4 : 0) + (mem ? (size_t)beam * mem_row * 2 : 0) +
                      (fast && mem2 ? (size_t)beam * mem_row * 2 : 0);

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void part_fold_kernel(float* __restrict__ part
 constexpr int FOLD_MIN_ROWS = 1024, FOLD_FACTOR = 16;
 // folds `part` (nblk rows of ld floats) when it pays; returns the row count the next stage has to walk
 static int maybe_fold(float* part, int nblk, int ld, hipStream_t s) {
-  static const int on = [] { const char* e = getenv("EVK_BN_FOLD"); return e ? atoi(e) : 1; }();
+  static const int on = evk_tunable("EVK_BN_FOLD", 1);
   if (!on || nblk < FOLD_MIN_ROWS || (ld & 3) || (reinterpret_cast<uintptr_t>(part) & 15)) return nblk;
   const int h = (nblk + FOLD_FACTOR - 1) / FOLD_FACTOR;
   const long total = (long)h * (ld / 4);

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <mutex>
 #include "../../include/evoke_hip.h"
 
 // 16-bit storage format of activations, weight shadows and gradients.  The DEFAULT build stores IEEE fp16 (libevoke_hip.so:
@@ -74,6 +75,35 @@ void evk_set_error(const char* fmt, ...);
       evk_set_error(__VA_ARGS__);             \
       return EVK_EINVAL;                      \
     }                                         \
+  } while (0)
+
+// Experiment switches.  Every kernel route has ONE measured default; the EVK_* environment variables read through evk_tunable() select the
+// alternatives that were measured against it (DESIGN.md names each).  They are inert unless EVK_EXPERIMENTAL=1 is set as well, so a stray
+// variable in a production environment cannot move a launch onto a route the test-suite does not cover (runtime.hip).
+int evk_tunable(const char* name, int dflt);
+
+// First-use initialisation that belongs to ONE device (hipFuncSetAttribute of a kernel's dynamic-LDS limit, hipGetSymbolAddress of a
+// __device__ block), safe when several host threads enter the library at once (autograd's backward threads, one thread per search in flight,
+// the encoder thread): one std::once_flag per device ordinal; init() returns the pointer to cache (any non-null value when there is none).
+constexpr int EVK_MAX_DEVICES = 16;
+struct EvkDeviceOnce {
+  std::once_flag flag[EVK_MAX_DEVICES];
+  void* value[EVK_MAX_DEVICES] = {};
+  template <class F>
+  void* get(F&& init) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= EVK_MAX_DEVICES) dev = 0;
+    std::call_once(flag[dev], [&] { value[dev] = init(); });
+    return value[dev];
+  }
+};
+#define EVK_DYN_LDS_ONCE(kern, bytes)                                                                                              \
+  do {                                                                                                                             \
+    static EvkDeviceOnce once_;                                                                                                    \
+    once_.get([&]() -> void* {                                                                                                     \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes));    \
+      return reinterpret_cast<void*>(1);                                                                                           \
+    });                                                                                                                            \
   } while (0)
 
 // profiling: an event pair around each launch when enabled (bench.py roofline leg)

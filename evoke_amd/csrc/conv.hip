@@ -200,7 +200,7 @@ int64_t evk_conv_stats_bytes(int64_t M, int32_t C) { return (int64_t)stats_rows(
 
 // short-K, wide-N pointwise products (Bottleneck conv3 forward, conv1 data gradient) go to the weight-stationary kernel
 static bool use_ws(const evk_conv_geom* g, int64_t M, int K, int N) {
-  static const int on = [] { const char* e = getenv("EVK_CONV1X1_WS"); return e ? atoi(e) : 1; }();
+  static const int on = evk_tunable("EVK_CONV1X1_WS", 1);
   return on && is_pointwise(g) && N >= 2 * K && evk_conv1x1_ws_supported(M, K, N);
 }
 
@@ -326,7 +326,7 @@ static bool s2_parity_geom(const evk_conv_geom* g) {
 }
 
 int evk_conv3x3s2_dgrad_parity_supported(const evk_conv_geom* g) {
-  static const int on = [] { const char* e = getenv("EVK_S2_PARITY"); return e ? atoi(e) : 1; }();
+  static const int on = evk_tunable("EVK_S2_PARITY", 1);
   return on && s2_parity_geom(g) ? 1 : 0;
 }
 

@@ -347,14 +347,7 @@ template <int K, int NW, int MT, bool DGRAD, int NWV, int AFF = 0>
 int launch_ws(WsP p, hipStream_t s) {
   const size_t abuf = std::max((size_t)2 * MT * (K + 8), DGRAD ? (size_t)ws_kc(K, MT, NWV * NW + 8) * (NWV * NW + 8) : (size_t)0);
   const size_t lds = abuf * 2 + (size_t)(DGRAD ? 2 : 1) * NWV * 16 * (NW + 8) * 2;
-  static bool configured = false;
-  if (!configured && lds > 65536) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_ws_kernel<K, NW, MT, DGRAD, NWV, AFF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      evk_set_error("conv1x1_ws: hipFuncSetAttribute failed");
-      return EVK_ELAUNCH;
-    }
-    configured = true;
-  }
+  if (lds > 65536) EVK_DYN_LDS_ONCE((&conv1x1_ws_kernel<K, NW, MT, DGRAD, NWV, AFF>), lds);
   p.ntiles = (int)cdiv(p.M, MT);
   p.slices = p.N / (NWV * NW);
   int groups = 256 / p.slices;
@@ -370,7 +363,7 @@ int launch_ws(WsP p, hipStream_t s) {
 
 template <bool DGRAD, int AFF = 0>
 int dispatch(const WsP& p, int K, hipStream_t s) {
-  static const int v8 = [] { const char* e = getenv("EVK_WS_WAVES8"); return e ? atoi(e) : 1; }();
+  static const int v8 = evk_tunable("EVK_WS_WAVES8", 1);
   if (v8) switch (K) {          // 8 waves x 32 channels (2 waves per SIMD hide the LDS / store latency of the per-16-pixel epilogue)
     case 64: return launch_ws<64, 32, 128, DGRAD, 8, AFF>(p, s);
     case 128: return launch_ws<128, 32, 128, DGRAD, 8, AFF>(p, s);

@@ -663,7 +663,7 @@ bool make_plan(int N, int H, int W, int Ci, int Co, Plan& pl) {
   pl.tpxp = (R * W + 31) / 32 * 32;
   pl.pairs_ci = Ci / 64;
   pl.npairs = (Ci / 64) * (Co / 64);
-  static const int target = [] { const char* e = getenv("EVK_C3W_BLOCKS"); return e ? atoi(e) : 256; }();
+  static const int target = evk_tunable("EVK_C3W_BLOCKS", 256);
   int ns = (target + pl.npairs / 2) / pl.npairs;
   const int tiles = (int)cdiv(TR, R);
   if (ns > tiles) ns = tiles;
@@ -676,17 +676,13 @@ bool make_plan(int N, int H, int W, int Ci, int Co, Plan& pl) {
 }  // namespace wgk
 
 bool halo_enabled() {
-  static const int on = [] { const char* e = getenv("EVK_CONV3X3_HALO"); return e ? atoi(e) : 1; }();
+  static const int on = evk_tunable("EVK_CONV3X3_HALO", 1);
   return on != 0;
 }
 
 template <class CF>
 int launch_halo(const C3P& p, hipStream_t s) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel<CF>), hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS_BYTES);
-    attr_done = true;
-  }
+  EVK_DYN_LDS_ONCE(conv3x3_halo_kernel<CF>, CF::LDS_BYTES);
   hipLaunchKernelGGL(conv3x3_halo_kernel<CF>, dim3(p.tilesM * p.tilesN), dim3(NTH), CF::LDS_BYTES, s, p);
   return evk_check_launch("conv3x3_halo_kernel");
 }
@@ -732,7 +728,7 @@ int evk_conv3x3_halo(const void* x, const void* w, void* y, int32_t N, int32_t H
   p.tilesN = Co / (wide ? Cfg128::TN : Cfg64::TN);
   p.resid = (const bf16_t*)resid; p.ldr = ldr; p.gate = (const bf16_t*)gate; p.ldg = ldg;
   p.colstats = colstats; p.gatestats = gatestats;
-  static const int probe = [] { const char* e = getenv("EVK_C3_PROBE"); return e ? atoi(e) : 0; }();
+  static const int probe = evk_tunable("EVK_C3_PROBE", 0);
   p.kmul = probe ? 0 : 1;
   p.inv_w = 1.f / W; p.inv_w2 = 1.f / (W + 2); p.inv_h = 1.f / H; p.inv_h1 = 1.f / (H + 1);
   p.stamps = g_stamps;
@@ -792,17 +788,15 @@ int evk_conv3x3_wgrad_halo(const void* dy, const void* x, float* dw, int32_t N, 
   p.N = N; p.H = H; p.W = W; p.Co = Co; p.Ci = Ci;
   p.R = pl.R; p.tpxp = pl.tpxp; p.rps = pl.rps; p.nsplit = pl.nsplit; p.pairs_ci = pl.pairs_ci; p.npairs = pl.npairs;
   p.inv_w = 1.f / W; p.inv_w2 = 1.f / (W + 2); p.inv_h = 1.f / H; p.inv_h1 = 1.f / (H + 1);
-  static void* zeros = nullptr;
-  if (!zeros) {
-    EVK_REQUIRE(hipGetSymbolAddress(&zeros, HIP_SYMBOL(wgk::g_zero16)) == hipSuccess && zeros, "conv3x3_wgrad_halo: no address for the zero block");
-  }
-  p.zeros = zeros;
-  p.stamps = g_stamps;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static EvkDeviceOnce zeros_once;
+  p.zeros = zeros_once.get([]() -> void* {
+    void* z = nullptr;
+    if (hipGetSymbolAddress(&z, HIP_SYMBOL(wgk::g_zero16)) != hipSuccess) z = nullptr;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgk::conv3x3_wgrad_halo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, wgk::LDS_BYTES);
-    attr_done = true;
-  }
+    return z;
+  });
+  EVK_REQUIRE(p.zeros, "conv3x3_wgrad_halo: no address for the zero block");
+  p.stamps = g_stamps;
   evk_prof_tag(Co, Ci, N * H * W, 9, EVK_A_KSTR, EVK_B_WGATHER);
   ProfScope ps(EVK_FAM_GEMM, s, 2.0 * N * H * W * (double)Co * 9 * Ci);
   hipLaunchKernelGGL(wgk::conv3x3_wgrad_halo_kernel, dim3(pl.npairs * pl.nsplit), dim3(NTH), wgk::LDS_BYTES, s, p);
@@ -812,7 +806,7 @@ int evk_conv3x3_wgrad_halo(const void* dy, const void* x, float* dw, int32_t N, 
 }
 
 int evk_conv3x3_wgrad_halo_routes(const evk_conv_geom* g) {
-  static const int on = [] { const char* e = getenv("EVK_CONV3X3_WGRAD_HALO"); return e ? atoi(e) : 1; }();
+  static const int on = evk_tunable("EVK_CONV3X3_WGRAD_HALO", 1);
   if (!on || !g) return 0;
   if (g->KH != 3 || g->KW != 3 || g->stride_h != 1 || g->stride_w != 1 || g->pad_h != 1 || g->pad_w != 1) return 0;
   if (g->Hi != g->Ho || g->Wi != g->Wo) return 0;

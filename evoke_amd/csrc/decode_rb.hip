@@ -310,7 +310,7 @@ int evk_decode_rowblock(const void* a, const void* w1_packed, const float* b1, c
   const int rbs = (R + TMR - 1) / TMR;
   // the projection variant splits a row block over four workgroups when the caller provides the (zero-initialised, persistent) exchange
   // buffer and the whole grid is resident at once (one 512-thread workgroup per CU suffices: 4 x rbs <= 256); EVK_DECODE_RB_SPLIT=0 disables
-  static const int split_on = [] { const char* e = getenv("EVK_DECODE_RB_SPLIT"); return e ? atoi(e) : 1; }();
+  static const int split_on = evk_tunable("EVK_DECODE_RB_SPLIT", 1);
   p.rbs = rbs;
   if (sync_ws && split_on && 4 * rbs <= 256) {
     p.sync_ctr = reinterpret_cast<unsigned*>(sync_ws);                                                        // [2][rbs]

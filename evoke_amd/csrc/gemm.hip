@@ -807,12 +807,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmP p) {
 template <int KC, int TN, int TM>
 int launch_skinny_cfg(const GemmP& p, hipStream_t s) {
   constexpr int LDS = (TM + TN) * KC * 2;
-  static bool attr_done = false;
   auto kern = gemm_skinny_kernel<KC, TN, TM>;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_done = true;
-  }
+  EVK_DYN_LDS_ONCE(kern, LDS);
   dim3 grid((unsigned)cdiv(p.N, TN), (unsigned)cdiv(p.M, TM), 1);
   hipLaunchKernelGGL(kern, grid, dim3(NTHR), LDS, s, p);
   return evk_check_launch("gemm_skinny_kernel");
@@ -821,10 +817,10 @@ int launch_skinny_cfg(const GemmP& p, hipStream_t s) {
 int launch_skinny(const GemmP& p, hipStream_t s) {
   // <= 256 rows (relational memory, decode step): the whole K = 512 panel in flight at once and 16-column blocks (twice the
   // blocks) -- one memory round trip per 512 of K instead of two.  Larger M: 2x the LDS per block would halve the residency.
-  static const int deep = [] { const char* e = getenv("EVK_SKINNY_DEEP"); return e ? atoi(e) : 1; }();
-  static const int half = [] { const char* e = getenv("EVK_SKINNY_TM64"); return e ? atoi(e) : 1; }();
+  static const int deep = evk_tunable("EVK_SKINNY_DEEP", 1);
+  static const int half = evk_tunable("EVK_SKINNY_TM64", 1);
   // (<= 1024 rows: the decode step's 768-row relational-memory products, 0.439 -> 0.419 ms per token)
-  static const int deep_rows = [] { const char* e = getenv("EVK_SKINNY_DEEP_ROWS"); return e ? atoi(e) : 1024; }();
+  static const int deep_rows = evk_tunable("EVK_SKINNY_DEEP_ROWS", 1024);
   if (deep && p.K % 512 == 0 && p.M <= deep_rows) return half ? launch_skinny_cfg<512, 16, 64>(p, s) : launch_skinny_cfg<512, 16, 128>(p, s);
   return launch_skinny_cfg<256, 32, 128>(p, s);
 }
@@ -1003,7 +999,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(const SkrP p) {
 
 // one launch of the reduction: the wide kernel once the output gives every CU a few blocks of whole 4 KB runs (EVK_REDUCE_WIDE=0/1 forces)
 inline int launch_splitk_reduce(const SkrP& r, int batch, hipStream_t s) {
-  static const int mode = [] { const char* e = getenv("EVK_REDUCE_WIDE"); return e ? atoi(e) : -1; }();
+  static const int mode = evk_tunable("EVK_REDUCE_WIDE", -1);
   const long nq = r.mn >> 2;
   const bool wide = mode >= 0 ? mode == 1 : cdiv(nq, 256) * batch >= 192;
   if (wide) hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3((int)cdiv(nq, 256), batch), dim3(256), 0, s, r);
@@ -1019,7 +1015,7 @@ constexpr long SLAB_MAX_BYTES = 192L << 20;
 // EVK_GEMM_SB=0/1 forces one of them for experiments.
 inline int single_buf_override() {
   static int v = -2;
-  if (v == -2) { const char* e = getenv("EVK_GEMM_SB"); v = !e ? -1 : (e[0] == '0' ? 0 : 1); }
+  if (v == -2) { const int t = evk_tunable("EVK_GEMM_SB", -1); v = t < 0 ? -1 : (t ? 1 : 0); }
   return v;
 }
 
@@ -1028,12 +1024,8 @@ int launch_cfg_sb(const GemmP& p, dim3 grid, hipStream_t s) {
   constexpr int TILE_LDS = (SB ? 1 : 2) * (64 * WM + 64 * WN) * BK * 2;
   constexpr int STAGE_LDS = WM * WN * 8192;            // the epilogue's per-wave 64 x 64 bf16 staging tiles
   constexpr int LDS = TILE_LDS > STAGE_LDS ? TILE_LDS : STAGE_LDS;
-  static bool attr_done = false;
   auto kern = gemm_kernel<WM, WN, AMODE, BMODE, SB>;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_done = true;
-  }
+  EVK_DYN_LDS_ONCE(kern, LDS);
   hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), LDS, s, p);
   return evk_check_launch("gemm_kernel");
 }
@@ -1045,12 +1037,12 @@ int launch_cfg(const GemmP& p, dim3 grid, hipStream_t s) {
   return sb ? launch_cfg_sb<WM, WN, AMODE, BMODE, true>(p, grid, s) : launch_cfg_sb<WM, WN, AMODE, BMODE, false>(p, grid, s);
 }
 
-inline long skinny_tiles() { static long v = [] { const char* e = getenv("EVK_SKINNY_TILES"); return e ? atol(e) : 113L; }(); return v; }
-inline long skinny_rows() { static long v = [] { const char* e = getenv("EVK_SKINNY_ROWS"); return e ? atol(e) : 4096L; }(); return v; }
+inline long skinny_tiles() { static long v = evk_tunable("EVK_SKINNY_TILES", 113); return v; }
+inline long skinny_rows() { static long v = evk_tunable("EVK_SKINNY_ROWS", 4096); return v; }
 
 inline long split_target() {
   static long v = 0;
-  if (!v) { const char* e = getenv("EVK_SPLIT_TARGET"); v = e ? atol(e) : 256; if (v < 1) v = 256; }
+  if (!v) { v = evk_tunable("EVK_SPLIT_TARGET", 256); if (v < 1) v = 256; }
   return v;
 }
 
@@ -1062,7 +1054,7 @@ inline long split_target() {
 // per CU, which loses on problems of few tiles -> only when the big tiles alone give every CU four rounds of blocks, and not for
 // the convolutions with fused statistics (neutral within noise on the trunk's 1x1 shapes; their partial-row layout stays).
 inline bool use_big_tile(long M, long N, long nz) {
-  static const int mode = [] { const char* e = getenv("EVK_TILE256"); return e ? atoi(e) : -1; }();
+  static const int mode = evk_tunable("EVK_TILE256", -1);
   if (mode == 0 || M < 256 || N < 256) return false;
   if (mode == 1) return true;
   return cdiv(M, 256) * cdiv(N, 256) * nz >= 1024;
@@ -1126,11 +1118,11 @@ int launch_modes(GemmP& p, int batch, int splitk_req, void* ws, long ws_bytes, c
   }
   p.ksteps_per_split = (int)cdiv(ksteps, splitk);
   splitk = (int)cdiv(ksteps, p.ksteps_per_split);
-  static const int kslice = [] { const char* e = getenv("EVK_KSLICE_XCD"); return e ? atoi(e) : 1; }();
+  static const int kslice = evk_tunable("EVK_KSLICE_XCD", 1);
   p.kslice_xcd = kslice;
   // measured (tools/gemm_bench.py --cold, 4640 x 16384 x 2048): 256-wide tiles (32 resident per XCD) 745 -> 785 TFLOP/s with 4-row groups,
   // the NN data gradient on 128-wide tiles (64-96 resident) 780 -> 850 with 8; EVK_GROUP_M forces a value (0 = plain M-major order)
-  static const int group_m = [] { const char* e = getenv("EVK_GROUP_M"); return e ? atoi(e) : -1; }();
+  static const int group_m = evk_tunable("EVK_GROUP_M", -1);
   p.group_m = group_m >= 0 ? group_m : (big ? 4 : 8);
   dim3 grid(tilesM * p.tilesN, splitk, batch);
   int rc;
@@ -1219,11 +1211,11 @@ extern "C" int evk_gemm_launch(const evk_gemm* d, evk_stream_t stream) {
   {
     // measured (cold caches, tools/gemm_bench.py --cold): +20 % on the write-dominated K = 64 convolutions of layer1, neutral
     // elsewhere -> on for short-K problems; EVK_LDS_STORE=0/1 forces it off / on for every eligible launch
-    static const int lds_store = [] { const char* e = getenv("EVK_LDS_STORE"); return e ? atoi(e) : -1; }();
+    static const int lds_store = evk_tunable("EVK_LDS_STORE", -1);
     p.lds_store = (lds_store < 0 ? d->K <= 128 : lds_store != 0) && !p.c_f32 && !p.accumulate && (d->N % 8 == 0) && (d->ldc % 8 == 0) && al(d->C, 16) && (d->sCo % 8 == 0) && (d->sCi % 8 == 0);
   }
   {
-    static const int fast_loads = [] { const char* e = getenv("EVK_FAST_LOADS"); return e ? atoi(e) : 1; }();
+    static const int fast_loads = evk_tunable("EVK_FAST_LOADS", 1);
     p.fast_loads = fast_loads;
   }
   p.gate = reinterpret_cast<const bf16_t*>(d->relu_gate); p.ldg = d->ldg;

@@ -297,6 +297,17 @@ __global__ __launch_bounds__(NTH, 2) void gemm_strip_kernel(const StP p) {
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// the device's zero block + the kernel's dynamic-LDS limit, once per device (both belong to ONE GPU) and safe against concurrent first calls
+inline const void* strip_zero_block() {
+  static EvkDeviceOnce once;
+  return once.get([]() -> void* {
+    void* z = nullptr;
+    if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_zero16)) != hipSuccess) z = nullptr;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_strip_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    return z;
+  });
+}
+
 }  // namespace
 
 extern "C" {
@@ -328,15 +339,9 @@ int evk_gemm_strip(const void* A, int64_t lda, const void* B, int64_t ldb, void*
     EVK_REQUIRE(nblk && part_bytes >= evk_gemm_strip_part_bytes(M, N), "gemm_strip: statistics buffer too small");
     *nblk = tilesM * WM;
   }
-  static void* zeros = nullptr;
-  static bool attr_done = false;
-  if (!attr_done) {
-    EVK_REQUIRE(hipGetSymbolAddress(&zeros, HIP_SYMBOL(g_zero16)) == hipSuccess && zeros, "gemm_strip: no address for the zero block");
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_strip_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    attr_done = true;
-  }
-  p.zeros = zeros;
-  static const int probe = [] { const char* e = getenv("EVK_STRIP_PROBE"); return e ? atoi(e) : 0; }();
+  p.zeros = strip_zero_block();
+  EVK_REQUIRE(p.zeros, "gemm_strip: no address for the zero block");
+  static const int probe = evk_tunable("EVK_STRIP_PROBE", 0);
   p.kmul = probe ? 0u : 128u;
   evk_prof_tag((int)M, N, K, 1, EVK_A_PLAIN, EVK_B_PLAIN);
   ProfScope ps(EVK_FAM_GEMM, s, 2.0 * M * (double)N * K);
@@ -359,14 +364,8 @@ int evk_gemm_strip_affine(const void* A, int64_t lda, const void* B, int64_t ldb
   const int tilesM = (int)cdiv(M, TM);
   p.resid = (const bf16_t*)resid; p.ldr = ldr;
   p.scale = scale; p.bias = bias; p.relu = relu;
-  static void* zeros = nullptr;
-  static bool attr_done = false;
-  if (!attr_done) {
-    EVK_REQUIRE(hipGetSymbolAddress(&zeros, HIP_SYMBOL(g_zero16)) == hipSuccess && zeros, "gemm_strip: no address for the zero block");
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_strip_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    attr_done = true;
-  }
-  p.zeros = zeros;
+  p.zeros = strip_zero_block();
+  EVK_REQUIRE(p.zeros, "gemm_strip: no address for the zero block");
   p.kmul = 128u;
   evk_prof_tag((int)M, N, K, 1, EVK_A_PLAIN, EVK_B_PLAIN);
   ProfScope ps(EVK_FAM_GEMM, s, 2.0 * M * (double)N * K);
@@ -377,8 +376,8 @@ int evk_gemm_strip_affine(const void* A, int64_t lda, const void* B, int64_t ldb
 // routing used by conv.hip for pointwise convolutions: the strip kernel pays when its one-block-per-CU grid fills the chip and the
 // K loop is long enough to amortise its prologue (EVK_GEMM_STRIP=0 disables, EVK_GEMM_STRIP_MIN_BLOCKS moves the threshold)
 int evk_gemm_strip_routes(int64_t M, int32_t N, int32_t K, int64_t part_bytes, int32_t want_stats) {
-  static const int on = [] { const char* e = getenv("EVK_GEMM_STRIP"); return e ? atoi(e) : 1; }();
-  static const int min_blocks = [] { const char* e = getenv("EVK_GEMM_STRIP_MIN_BLOCKS"); return e ? atoi(e) : 200; }();
+  static const int on = evk_tunable("EVK_GEMM_STRIP", 1);
+  static const int min_blocks = evk_tunable("EVK_GEMM_STRIP_MIN_BLOCKS", 200);
   if (!on || !evk_gemm_strip_supported(M, N, K) || K < 256) return 0;
   if (cdiv(M, TM) * (N / TN) < min_blocks) return 0;
   if (want_stats && part_bytes < evk_gemm_strip_part_bytes(M, N)) return 0;

@@ -197,7 +197,7 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 // Shape / layout test shared with gemm.hip's router: whole 128 x 128 tiles, 16-byte aligned rows and batch strides.
 bool evk_gemm_tn_supported(int M, int N, int K, long lda, long ldb, long ldc, long sAo, long sAi, long sBo, long sBi, long sCo, long sCi) {
-  static const int on = [] { const char* e = getenv("EVK_GEMM_TN"); return e ? atoi(e) : 1; }();
+  static const int on = evk_tunable("EVK_GEMM_TN", 1);
   if (!on) return false;
   if (M < TM || N < TN || (M % TM) || (N % TN) || K < 1) return false;
   if ((lda % 8) || (ldb % 8) || (ldc % 4) || lda < M || ldb < N || ldc < N) return false;
@@ -218,19 +218,19 @@ int evk_gemm_tn_launch(const void* A, const void* B, float* C, float* slab, int 
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.tilesM = M / TM; p.tilesN = N / TN; p.ntiles = p.tilesM * p.tilesN;
   p.nsplit = nsplit; p.steps_per_split = steps_per_split; p.slab_mn = (long)M * N;
-  static const int group_m = [] { const char* e = getenv("EVK_TN_GROUP_M"); return e ? atoi(e) : 4; }();
+  static const int group_m = evk_tunable("EVK_TN_GROUP_M", 4);
   p.group_m = group_m < 1 ? 1 : group_m;
   p.bi = bi; p.sAo = sAo; p.sAi = sAi; p.sBo = sBo; p.sBi = sBi; p.sCo = sCo; p.sCi = sCi;
   const long nwg = (long)p.ntiles * nsplit * batch;
   EVK_REQUIRE(nwg < (1L << 31), "gemm_tn: grid too large");
-  static void* zeros = nullptr;
-  static bool attr_done = false;
-  if (!attr_done) {
-    EVK_REQUIRE(hipGetSymbolAddress(&zeros, HIP_SYMBOL(g_tn_zero16)) == hipSuccess && zeros, "gemm_tn: no address for the zero block");
+  static EvkDeviceOnce zeros_once;          // per device: the symbol's address and the kernel attribute belong to one GPU
+  p.zeros = zeros_once.get([]() -> void* {
+    void* z = nullptr;
+    if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_tn_zero16)) != hipSuccess) z = nullptr;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    attr_done = true;
-  }
-  p.zeros = zeros;
+    return z;
+  });
+  EVK_REQUIRE(p.zeros, "gemm_tn: no address for the zero block");
   hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)nwg), dim3(NTH), LDS_BYTES, s, p);
   return evk_check_launch("gemm_tn_kernel");
 }

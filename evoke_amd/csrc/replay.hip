@@ -40,6 +40,8 @@ struct Plan {
   size_t n_kernels = 0, n_copies = 0, n_sets = 0, n_cross = 0;
 };
 
+inline bool replay_debug() { static const int on = evk_tunable("EVK_REPLAY_DEBUG", 0); return on != 0; }
+
 int new_event(Plan* p) {
   hipEvent_t e;
   if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return -1;
@@ -111,7 +113,7 @@ void* evk_replay_build(void* graph_handle, int32_t max_lanes) {
         // their parameters faithfully on ROCm 7.2 and cloning + pruning the graph to isolate such a node corrupts the
         // original's kernel arguments -- the plan is refused and the caller stays on eager launches.  Keep such copies out of
         // the step (the engine's own code has none; EVK_REPLAY_DEBUG=1 names the neighbours of the offending node).
-        if (getenv("EVK_REPLAY_DEBUG")) {
+        if (replay_debug()) {
           fprintf(stderr, "[replay] multi-dimensional memcpy at node %zu: width %zu height %zu depth %zu, src pitch %zu dst pitch %zu\n", k, (size_t)mp.extent.width,
                   (size_t)mp.extent.height, (size_t)mp.extent.depth, (size_t)mp.srcPtr.pitch, (size_t)mp.dstPtr.pitch);
           for (size_t j = (k > 4 ? k - 4 : 0); j < k + 3 && j < n; ++j) {
@@ -122,11 +124,11 @@ void* evk_replay_build(void* graph_handle, int32_t max_lanes) {
           }
         }
         evk_set_error("replay_build: node %zu is a multi-dimensional memcpy (not replayable)", k);
-        if (getenv("EVK_REPLAY_DEBUG")) { ++n_bad; continue; }          // list them all, fail after the walk
+        if (replay_debug()) { ++n_bad; continue; }          // list them all, fail after the walk
         delete p;
         return nullptr;
       }
-      if (getenv("EVK_REPLAY_DEBUG")) {
+      if (replay_debug()) {
         fprintf(stderr, "[replay] 1-D memcpy at node %zu: %zu bytes kind %d\n", k, (size_t)mp.extent.width, (int)mp.kind);
         for (size_t j = (k > 3 ? k - 3 : 0); j < k + 3 && j < n; ++j) {
           hipGraphNodeType tj; (void)hipGraphNodeGetType(nodes[order[j]], &tj);
@@ -234,8 +236,7 @@ void* evk_replay_build(void* graph_handle, int32_t max_lanes) {
   // backward chain) -- instead of whichever chain happens to start first.  EVK_REPLAY_CRIT_LANE=1 enables it; it did not help (the step is
   // 73-81 ms under the replayer with every priority assignment tried, 54 ms eager: DESIGN.md section 5).
   {
-    const char* e = getenv("EVK_REPLAY_CRIT_LANE");
-    if (e && atoi(e) != 0 && lane_tail.size() > 1) {          // measured (bench --graph 1): 81 ms per step with, 75 ms without -- opt-in experiment
+    if (evk_tunable("EVK_REPLAY_CRIT_LANE", 0) != 0 && lane_tail.size() > 1) {          // measured (bench --graph 1): 81 ms per step with, 75 ms without -- opt-in experiment
       std::vector<int> bn(lane_tail.size(), 0);
       for (const RNode& r : p->nodes)
         if (r.type == 0) {
@@ -248,7 +249,7 @@ void* evk_replay_build(void* graph_handle, int32_t max_lanes) {
         for (RNode& r : p->nodes) r.lane = r.lane == crit ? 0 : (r.lane == 0 ? crit : r.lane);
     }
   }
-  if (getenv("EVK_REPLAY_DEBUG")) {
+  if (replay_debug()) {
     std::vector<int> cnt(lane_tail.size(), 0);
     for (RNode& r : p->nodes) ++cnt[r.lane];
     for (size_t l = 0; l < cnt.size(); ++l) {
@@ -261,8 +262,7 @@ void* evk_replay_build(void* graph_handle, int32_t max_lanes) {
   }
   p->lanes.assign(lane_tail.size(), nullptr);
   // side lanes at the default priority (0), like the eager step's side streams; EVK_REPLAY_SIDE_PRIO overrides (1 = lowest on this device)
-  const char* sp = getenv("EVK_REPLAY_SIDE_PRIO");
-  const int side_prio = sp ? atoi(sp) : 0;
+  const int side_prio = evk_tunable("EVK_REPLAY_SIDE_PRIO", 0);
   for (size_t l = 1; l < p->lanes.size(); ++l)
     if (hipStreamCreateWithPriority(&p->lanes[l], hipStreamNonBlocking, side_prio) != hipSuccess) { evk_set_error("replay_build: hipStreamCreate failed"); delete p; return nullptr; }
   p->begin_event = new_event(p);

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void rm_combine_kernel(const bf16_t* __restric
 // cut 2000 launches (~10 ms of host time per step) to 2 and are the right trade when the host is the bottleneck.
 int g_rm_persist = -1;           // -1: EVK_RM_PERSIST (default off); 0 / 1: evk_rm_set_persistent
 inline bool rm_use_persistent(int L) {
-  if (g_rm_persist < 0) { const char* e = getenv("EVK_RM_PERSIST"); g_rm_persist = e ? (atoi(e) != 0) : 0; }
+  if (g_rm_persist < 0) g_rm_persist = evk_tunable("EVK_RM_PERSIST", 0) != 0;
   return g_rm_persist != 0 && L >= 8;
 }
 

@@ -71,7 +71,7 @@ __device__ __forceinline__ void split4(const float4 x, uint2& h, uint2& l) {
 int g_split16 = -1;
 inline int rm_split16() {
 #ifdef EVK_STORE_F16
-  if (g_split16 < 0) { const char* e = getenv("EVK_RM_SPLIT16"); g_split16 = e ? (atoi(e) != 0) : 0; }
+  if (g_split16 < 0) g_split16 = evk_tunable("EVK_RM_SPLIT16", 0) != 0;
   return g_split16;
 #else
   return 0;                                   // (bf16 has 8 significand bits: three terms would not reach f32)
@@ -248,14 +248,10 @@ inline GemmF mkf(const float* A, long lda, const float* W, const float* bias, co
 // up to three independent products in ONE launch (their workgroups are simply concatenated), optionally with the gate epilogue on the first
 int gemm_f32_multi(const GemmF* g, int nprob, const GateE* gate, hipStream_t s) {
   EVK_REQUIRE(nprob >= 1 && nprob <= 3, "rm f32 gemm: 1 .. 3 problems per launch");
-  static bool attr_done = false;
   constexpr int LDS = (2 * FSTAGE * 4 > 2 * 2 * HIMG * 2) ? 2 * FSTAGE * 4 : 2 * 2 * HIMG * 2;
   const bool split = rm_split16() != 0;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f32_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_done = true;
-  }
+  EVK_DYN_LDS_ONCE(gemm_f32_kernel<false>, LDS);
+  EVK_DYN_LDS_ONCE(gemm_f32_kernel<true>, LDS);
   GemmF3 pp{};
   int blocks[3] = {0, 0, 0};
   for (int i = 0; i < nprob; ++i) {

@@ -1,5 +1,6 @@
 // runtime.hip -- error reporting + HIP-event profiling hooks of libevoke_hip.so
 #include <stdarg.h>
+#include <stdlib.h>
 #include <mutex>
 #include <vector>
 #include "common.h"
@@ -11,6 +12,15 @@ void evk_set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+// The ONE place the library reads its environment.  `name` selects a measured alternative to a kernel route's default (or a probe / debug
+// print); the variable counts only under EVK_EXPERIMENTAL=1, which the tests that force a route set for their child process.
+int evk_tunable(const char* name, int dflt) {
+  static const bool on = [] { const char* e = getenv("EVK_EXPERIMENTAL"); return e && atoi(e) != 0; }();
+  if (!on) return dflt;
+  const char* e = getenv(name);
+  return e && *e ? atoi(e) : dflt;
 }
 
 int evk_check_launch(const char* what) {

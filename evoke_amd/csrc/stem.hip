@@ -289,7 +289,7 @@ __global__ __launch_bounds__(NTH, 2) void stem_wgrad_kernel(const StemWP p) {
 }
 
 int stem_grid(int ntiles) {
-  static const int g = [] { const char* e = getenv("EVK_STEM_BLOCKS"); return e ? atoi(e) : 256; }();
+  static const int g = evk_tunable("EVK_STEM_BLOCKS", 256);
   return ntiles < g ? ntiles : g;
 }
 
@@ -298,7 +298,7 @@ int stem_grid(int ntiles) {
 extern "C" {
 
 int evk_stem_halo_supported(int32_t N, int32_t H, int32_t W) {
-  static const int on = [] { const char* e = getenv("EVK_STEM_HALO"); return e ? atoi(e) : 1; }();
+  static const int on = evk_tunable("EVK_STEM_HALO", 1);
   return on && N > 0 && H > 0 && W > 0 && (H / 2) % TRO == 0 && H % 2 == 0 && (W / 2) % TCO == 0 && W % 2 == 0 ? 1 : 0;
 }
 

@@ -413,10 +413,10 @@ int evk_trunk_backward(const evk_trunk_cfg* cfg, const evk_trunk_layer* layers, 
   Ctx c{cfg, layers, static_cast<char*>(ws), &P, stream, training};
   WgradQueue q;
   TRY(q.init(stream, wgrad_stream));
-  static const bool gate_stats = [] { const char* e = getenv("EVK_BN_GATE_STATS"); return !e || atoi(e) != 0; }();
-  static const bool x_stats = [] { const char* e = getenv("EVK_BN_XSTATS"); return !e || atoi(e) != 0; }();
+  static const bool gate_stats = evk_tunable("EVK_BN_GATE_STATS", 1) != 0;
+  static const bool x_stats = evk_tunable("EVK_BN_XSTATS", 1) != 0;
   int nbz = 0;                           // > 0: the kernel that produced gZ left bn3's backward sums of the current block in P.part
-  static const bool flip_on = [] { const char* e = getenv("EVK_DGRAD_FLIP"); return !e || atoi(e) != 0; }();
+  static const bool flip_on = evk_tunable("EVK_DGRAD_FLIP", 1) != 0;
   if (flip_on) {        // flipped / transposed weights of every stride-1 3x3 convolution and every conv3 the strip GEMM takes, one launch (evk_conv_flip_weights)
     std::vector<const void*> ws_; std::vector<void*> wt_; std::vector<int32_t> co_, ci_, k_;
     for (size_t i = 1; i < P.pairs.size(); ++i)
@@ -493,7 +493,7 @@ int evk_trunk_backward(const evk_trunk_cfg* cfg, const evk_trunk_layer* layers, 
       {
         // down-sampling shortcut: a pointwise stride-2 convolution gives gradient to the even pixels only -- the product on the compact
         // rows (a quarter of them), then one pass that spreads them and writes the zeros (EVK_DOWN_COMPACT=0: the gathering GEMM)
-        static const bool compact = [] { const char* e = getenv("EVK_DOWN_COMPACT"); return !e || atoi(e) != 0; }();
+        static const bool compact = evk_tunable("EVK_DOWN_COMPACT", 1) != 0;
         const evk_conv_geom& gd = P.pairs[i + 3].g;
         if (compact && gd.KH == 1 && gd.KW == 1 && gd.stride_h == 2 && gd.stride_w == 2 && gd.pad_h == 0 && gd.pad_w == 0 &&
             gd.Hi == 2 * gd.Ho && gd.Wi == 2 * gd.Wo && gd.Ci % 8 == 0) {

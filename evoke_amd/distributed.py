@@ -43,6 +43,12 @@ def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def forced():
+    """EVK_FORCE_DIST=1 with a live process group: the rehearsal mode -- every collective of the data-parallel path (bucketed gradient
+    sum, update-mask union, the contrastive exchange) is ISSUED even on one rank, where each of them is the identity."""
+    return dist.is_available() and dist.is_initialized() and os.environ.get('EVK_FORCE_DIST', '0') == '1'
+
+
 def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
@@ -84,7 +90,7 @@ def gather_rows(x, patient_ids):
     Two collectives per call: ONE all-gather of a fixed-capacity int64 record per rank -- [row count, 64-bit study-id hashes ...] -- read
     back with one host copy (the row counts are shapes: the host must know them), then the autograd all-gather of the rows padded to
     the largest count."""
-    if world_size() == 1:
+    if world_size() == 1 and not forced():
         return x, np.asarray(patient_ids)
     world = dist.get_world_size()
     n = x.shape[0]
@@ -93,10 +99,22 @@ def gather_rows(x, patient_ids):
     rec = np.zeros(1 + GATHER_CAP, dtype=np.int64)
     rec[0] = n
     rec[1:1 + n] = [fnv1a64(p) for p in patient_ids]
-    mine = ops.upload(rec, x.device) if x.is_cuda else torch.from_numpy(rec)
-    every = torch.empty(world * (1 + GATHER_CAP), dtype=torch.long, device=x.device)
-    dist.all_gather_into_tensor(every, mine.contiguous())
-    every = every.cpu().numpy().reshape(world, 1 + GATHER_CAP)
+    if x.is_cuda:
+        # The record depends on host data only (the batch's study ids), the read-back must not wait for the GPU work already queued on the
+        # compute stream (the whole forward up to the loss: a host that stalls there twice per step turns a host-bound step into a
+        # serialised one -- 23.6 -> 28.0 ms on the 224^2 Pretrain step with a 1-rank group).  So the id exchange runs on the 'comm' stream,
+        # which is idle during the forward; every rank issues it at the same point of its program, so the collective order still agrees.
+        comm = ops.side_stream('comm')
+        with torch.cuda.stream(comm):
+            mine = ops.upload(rec, x.device)
+            every = torch.empty(world * (1 + GATHER_CAP), dtype=torch.long, device=x.device)
+            dist.all_gather_into_tensor(every, mine.contiguous())
+            every = every.cpu()          # (blocking copy on 'comm': waits for the all-gather only)
+    else:
+        mine = torch.from_numpy(rec)
+        every = torch.empty(world * (1 + GATHER_CAP), dtype=torch.long)
+        dist.all_gather_into_tensor(every, mine.contiguous())
+    every = every.numpy().reshape(world, 1 + GATHER_CAP)
     counts = [int(c) for c in every[:, 0]]
     ids = np.concatenate([every[r, 1:1 + c] for r, c in enumerate(counts)])
     return _AllGatherRows.apply(x, counts), ids
@@ -163,6 +181,11 @@ class GradReducer:
         self.opt = None            # weakref to the FusedOptimizer whose flat buffers these are (for_optimizer): receives the union below
         self.touched_union = None  # uint8 per parameter (group order): 1 = SOME rank produced a gradient for it this step
         self.issued = []           # bucket indices in the order their collectives were issued this step (tests read it)
+        self.last_issued, self.last_early = [], 0          # the same of the step finish() completed last, and how many went out before finish()
+        # timing=True (bench.py): HIP events on the 'comm' stream around every bucket's collective (from "its producers are done" to "its
+        # result is there") and on the main stream around finish()'s wait for them; read with comm_stats() after a device synchronisation
+        self.timing = False
+        self._ev_comm, self._ev_exposed = [], []
         self.begin('default')
         ops.register_grad_callback(self.on_grad)
 
@@ -194,13 +217,13 @@ class GradReducer:
                 self.pending[self.bucket_of[pid]] += c
 
     def _active(self):
-        return world_size() > 1 or (dist.is_initialized() and os.environ.get('EVK_FORCE_DIST', '0') == '1')
+        return world_size() > 1 or forced()
 
     def _collective(self, buf):
         """the gradient sum of one bucket in the configured mode; returns async handles (possibly none: the blocking steps of a
         mode run on the communication stream and are ordered by it)"""
         world = dist.get_world_size()
-        if self.mode == 'direct' and world > 1 and buf.numel() % world == 0 and buf.numel() >= 1024 * world:
+        if self.mode == 'direct' and (world > 1 or forced()) and buf.numel() % world == 0 and buf.numel() >= 1024 * world:
             recv = torch.empty_like(buf)
             dist.all_to_all_single(recv, buf)                                   # chunk j of every rank -> rank j
             shard = recv.view(world, -1).sum(0)                                 # this rank's slice of the sum
@@ -239,7 +262,15 @@ class GradReducer:
                 if st != comm and st != cur:
                     comm.wait_stream(st)
             with torch.cuda.stream(comm):
-                self.handles += self._collective(self.flat[fi][s:e])
+                if self.timing:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(comm)
+                    for h in self._collective(self.flat[fi][s:e]):
+                        h.wait()          # (stream-level: 'comm' waits for the collective's own stream; the host does not block)
+                    e1.record(comm)
+                    self._ev_comm.append((e0, e1, 4 * (e - s)))
+                else:
+                    self.handles += self._collective(self.flat[fi][s:e])
             return
         self.handles += self._collective(self.flat[fi][s:e])
 
@@ -288,8 +319,23 @@ class GradReducer:
         self.touched_union = t
         opt.set_global_touched(t)
 
+    def comm_stats(self, steps):
+        """(timing=True) per-step figures of the last `steps` steps; synchronise the device first.  comm_ms = sum over buckets of the time
+        between "the bucket's producers are done" and "its collective has finished" on the communication stream (collectives of different
+        buckets serialise on RCCL's stream, so the sum is the stream's busy time); exposed_ms = how long the main stream stood still in
+        finish() waiting for the last collectives and the update-mask exchange -- the part of comm_ms the backward did not hide."""
+        n = max(1, steps)
+        comm = sum(a.elapsed_time(b) for a, b, _ in self._ev_comm) / n
+        exposed = sum(a.elapsed_time(b) for a, b in self._ev_exposed) / n
+        out = dict(comm_ms_per_step=comm, exposed_comm_ms_per_step=exposed, collectives_per_step=len(self._ev_comm) / n,
+                   buckets=len(self.buckets), bucket_bytes=[4 * (e - s) for _, s, e in self.buckets],
+                   reduced_bytes_per_step=sum(nb for _, _, nb in self._ev_comm) / n)
+        self._ev_comm, self._ev_exposed = [], []
+        return out
+
     def finish(self):
         """Call after backward(): reduces what was not launched from the backward (descending order), waits for everything."""
+        early = len(self.issued)        # collectives that went out from inside the backward
         if self.flat and self.flat[0].is_cuda:
             ops.join_side_streams()
             for st in self.streams:
@@ -300,9 +346,18 @@ class GradReducer:
         for h in self.handles:
             h.wait()
         self.handles = []
-        if self.flat and self.flat[0].is_cuda and self._active():
+        on_gpu = bool(self.flat) and self.flat[0].is_cuda and self._active()
+        if on_gpu and self.timing:
+            m0 = torch.cuda.Event(enable_timing=True)
+            m0.record()
+        if on_gpu:
             ops.H.current_stream().wait_stream(ops.side_stream('comm'))
         self._share_touched()
+        if on_gpu and self.timing:
+            m1 = torch.cuda.Event(enable_timing=True)
+            m1.record()
+            self._ev_exposed.append((m0, m1))
         if self.learning:
             self.learned[self.key] = dict(self.counts)
+        self.last_issued, self.last_early = list(self.issued), early          # (begin() resets the step's bookkeeping)
         self.begin(self.key)

@@ -430,8 +430,11 @@ class ResNetTrunk(nn.Sequential):
         pairs = self.pairs()
         cfg = self.native_cfg()
         dev = images.device
+        # num_batches_tracked: the native TRAINING forward rewrites running_mean / running_var through raw pointers (their torch version
+        # counters never move) but counts the pass with a torch op on this buffer -- a train-mode forward without an optimizer step in
+        # between (BN recalibration under no_grad, a frozen extractor under a torch.optim optimizer) must refold too
         key = (ops.WEIGHT_EPOCH[0], dev,
-               tuple(t._version for _, bn in pairs for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)),
+               tuple(t._version for _, bn in pairs for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked)),
                tuple(bn.running_mean.data_ptr() for _, bn in pairs[:2]))
         st = getattr(self, '_evk_fold', None)
         refold = st is None or st[0] != key

@@ -255,3 +255,119 @@ def test_reducer_collectives_wait_for_the_weight_gradient_stream():
         assert torch.allclose(flat.view_as(W).cpu(), want, rtol=1e-3, atol=1e-3)
     finally:
         ops.clear_grad_callbacks()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# RCCL rehearsal: the collectives of the data-parallel step on the nccl (= RCCL) backend.  RCCL refuses two ranks on one device, so the
+# one GPU of a test box can only host a 1-rank group -- but with EVK_FORCE_DIST=1 that group still ISSUES everything a multi-rank step
+# issues: every bucket's collective on the 'comm' stream in descending order (launched from the backward once a structure is learned),
+# the uint8 MAX all-reduce of the update mask, the two all-gathers of gather_rows.  On one rank each of them is the identity, so the
+# trajectory must equal the non-distributed one.  What this can and cannot show: it EXECUTES every RCCL call of the step (dtypes, shapes,
+# stream use, the asynchronous handles) and would expose a collective that corrupts its buffer; a collective issued too EARLY is invisible
+# on one rank (the identity commutes with the late additions) -- that ordering is what the two-rank gloo tests above check.  The step is
+# not bit-deterministic from run to run (last-bit noise of the column sums), so the comparison uses the tolerances of
+# the graph-vs-eager test, with the run-to-run spread of two non-distributed runs printed beside it; optimizer step counts must be EQUAL.
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _rccl_worker(port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', EVK_FORCE_DIST='1')
+    import torch.distributed as dist
+    from evoke_amd import distributed as D, hip as H, ops, optim
+    from evoke_amd.model_pretrain_finetune import FineTune, Pretrain
+    from tests.helpers import ARGS, V, load_tokenizer
+    torch.cuda.set_device(0)
+    try:
+        ops.set_dropout_enabled(False)
+        tok = load_tokenizer()
+
+        def run(kind, mode, roundtrip16=False):
+            ops.clear_grad_callbacks()
+            sc = ops.loss_scaler()
+            if sc is not None:
+                sc.state.copy_(torch.tensor([ops.LOSS_SCALE_INIT, 0.0, 0.0, 0.0]))
+            args = dict(ARGS, task=kind, pt_lr=5e-5, ft_lr=5e-4, optim='RAdam', weight_decay=5e-5, amsgrad=True)
+            torch.manual_seed(77)
+            model = (FineTune if kind == 'finetune' else Pretrain)(args, tok, 'mimic_cxr').cuda().train()
+            if kind == 'pretrain':
+                model.gather = D.gather_rows          # identity without a process group; the two exchanges with one
+            opt = optim.build_two_stage_optimizer(args, model, clip_value=0.1)
+            red = D.GradReducer.for_optimizer(opt, bucket_bytes=16 << 20, mode=mode)
+            red.timing = red.active
+            losses, issued = [], []
+            for i in range(2):          # step 1 learns the structure (everything reduced at finish()), step 2 launches from the backward
+                losses.append(_step(kind, model, opt, red, _shard(kind, i, V), 1))
+                issued.append((list(red.last_issued), red.last_early))
+                if roundtrip16:         # what the '16bit' mode does to the gradients of ONE rank: f32 -> 16-bit storage format -> f32
+                    for g in opt.flat_grads():
+                        low = torch.empty(g.numel(), dtype=ops.BF16, device=g.device)
+                        H.check(H.lib.evk_cast(H.ptr(g), H.F32, H.ptr(low), H.BF16, g.numel(), H.stream()), 'cast')
+                        H.check(H.lib.evk_cast(H.ptr(low), H.BF16, H.ptr(g), H.F32, g.numel(), H.stream()), 'cast')
+                opt.step()
+            torch.cuda.synchronize()
+            stats = red.comm_stats(2) if red.timing else None
+            out = dict(losses=losses, p=[st['p'].detach().cpu().clone() for st in opt.flat], steps=[st['steps'].cpu().clone() for st in opt.flat],
+                       n_buckets=len(red.buckets), issued=issued, active=bool(red.active), stats=stats,
+                       touched=None if red.touched_union is None else int(red.touched_union.sum().item()))
+            del model, opt, red
+            return out
+
+        res = {}
+        for kind in ('finetune', 'pretrain'):
+            res[kind, 'ref'] = run(kind, 'allreduce')
+            if kind == 'finetune':
+                res[kind, 'ref_again'] = run(kind, 'allreduce')
+            res[kind, 'ref16'] = run(kind, 'allreduce', roundtrip16=True)
+        assert not res['finetune', 'ref']['active']
+        D.init_distributed('nccl')
+        assert dist.get_backend() == 'nccl' and D.forced() and D.world_size() == 1
+        for kind in ('finetune', 'pretrain'):
+            for mode in ('allreduce', 'direct', '16bit'):
+                res[kind, mode] = run(kind, mode)
+
+        def diff(a, b):
+            """(losses within 2e-4 relative, parameters allclose, step counts EQUAL, largest parameter difference) -- the step is not
+            bit-deterministic from run to run (last-bit noise of the column sums), so two runs are compared the way
+            test_step_graph_replays_the_eager_trajectory compares them"""
+            l_ok = all(abs(x - y) <= 2e-4 * max(1.0, abs(x)) for x, y in zip(a['losses'], b['losses']))
+            p_ok = all(torch.allclose(x, y, rtol=1e-3, atol=2e-5) for x, y in zip(a['p'], b['p']))
+            s_ok = all(torch.equal(x, y) for x, y in zip(a['steps'], b['steps']))
+            return bool(l_ok), bool(p_ok), bool(s_ok), max(float((x - y).abs().max()) for x, y in zip(a['p'], b['p']))
+
+        # plain Python values only: tensors sent through the queue would be shared-memory handles of a process that is about to exit
+        rep = dict(run_to_run=diff(res['finetune', 'ref'], res['finetune', 'ref_again']))
+        for kind in ('finetune', 'pretrain'):
+            for mode in ('allreduce', 'direct', '16bit'):
+                got, want = res[kind, mode], res[kind, 'ref16' if mode == '16bit' else 'ref']
+                rep[kind, mode] = dict(diff=diff(got, want), losses=got['losses'], want_losses=want['losses'],
+                                       **{k: got[k] for k in ('active', 'touched', 'issued', 'n_buckets', 'stats')})
+        q.put((0, 'ok', rep))
+    except Exception:          # noqa: BLE001 -- reported to the parent
+        import traceback
+        q.put((0, 'error', traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_forced_one_rank_rccl_step_equals_the_non_distributed_step():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    _, status, rep = q.get(timeout=900)
+    p.join(timeout=60)
+    assert status == 'ok', rep
+    assert all(rep['run_to_run'][:3]), rep['run_to_run']
+    print('\n[two non-distributed runs of the same two steps] largest parameter difference %.3e' % rep['run_to_run'][3])
+    for kind in ('finetune', 'pretrain'):
+        for mode in ('allreduce', 'direct', '16bit'):
+            got = rep[kind, mode]
+            assert got['active'] and got['touched'] is not None and got['touched'] > 0, (kind, mode)
+            # every bucket's collective went out, in descending order, in both steps
+            assert [i for i, _ in got['issued']] == [list(range(got['n_buckets'] - 1, -1, -1))] * 2 and got['n_buckets'] >= 4, (kind, mode, got['issued'])
+            # ... in the first step of the structure all of them at finish(), in the second most of them from inside the backward
+            assert got['issued'][0][1] == 0 and got['issued'][1][1] >= got['n_buckets'] // 2, (kind, mode, [e for _, e in got['issued']])
+            assert got['stats']['collectives_per_step'] == got['n_buckets'], got['stats']
+            print('[rccl 1 rank, %s, %s] losses %s  comm %.2f ms / step in %d buckets, exposed %.2f ms; largest parameter difference to the non-distributed run %.3e' % (
+                kind, mode, ['%.5f' % v for v in got['losses']], got['stats']['comm_ms_per_step'], got['n_buckets'], got['stats']['exposed_comm_ms_per_step'], got['diff'][3]))
+            assert np.isfinite(got['losses']).all()
+            assert all(got['diff'][:3]), (kind, mode, got['losses'], got['want_losses'], got['diff'])

@@ -285,6 +285,16 @@ def test_inference_trunk_with_batchnorm_epilogues_follows_the_eval_forward(res):
     assert torch.equal(run(2), att_2u)
     assert torch.equal(att_2, att_2u)
     assert rel_err(att_2.float(), att_f.float().cpu()) > 1e-3, 'the running statistic changed but the scale / shift vectors did not'
+    # ... also when the native TRAINING forward moved the running statistics through raw pointers (no torch version counter moves, no
+    # optimizer step in between: BN recalibration under no_grad) -- ADVICE round 4
+    if res == 224:
+        m.train()
+        with torch.no_grad():
+            m(img)
+        m.eval()
+        att_3, att_3u = run(2), run(-1)
+        assert torch.equal(att_3, att_3u), 'stale batch-norm coefficients after a train-mode forward without an optimizer step'
+        assert not torch.equal(att_3, att_2), 'the train-mode forward did not move the running statistics'
 
 
 @pytest.mark.parametrize('name', [n for n, c in CASES.items() if c['kind'] == 'beam' and c['max_seq_len'] <= 40])
