@@ -418,11 +418,16 @@ def main():
         opt.step()
         return loss.detach()
 
-    # Step replay (evoke_amd/graph.py + csrc/replay.hip): the step is stream-captured once and its launch sequence re-issued from
-    # C++ -- host issue time 33 -> 12 ms per step (measured, profiles/r02_b_*), but with all work queued at once the side lanes
-    # (weight gradients, relational memory) compete with the critical path and the GPU-side step grows from 57.8 to 64 ms, so it
-    # stays opt-in (--graph 1) until the lanes carry the capture's stream priorities.
-    use_graph = a.graph if a.graph >= 0 else 0
+    # Step replay (evoke_amd/graph.py + csrc/replay.hip): the step is stream-captured once and its launch sequence re-issued from C++ on
+    # lanes that ARE the capture's streams (round 5: a capture probe notes which stream created which node; the minimum path cover of
+    # rounds 2-4 scrambled trunk forward + weight gradients into one lane and ran 71 ms).  Measured on one box (profiles/r05_replay_sweep.txt):
+    # eager 48.6 ms (host issue 29 ms), replayed 49.2 ms at equal stream priorities (host issue 9 ms), 52.7 ms with the main lane at the
+    # higher priority -- and 48.1 ms once the relational-memory lane (a chain of ~1400 dependent launches of a few microseconds) runs at the
+    # higher priority too (evoke_amd/graph.py: LANE_PRIORITY; 224^2: 30.8 eager, 30.0 replayed).  The same priority on the EAGER step's
+    # relational-memory stream makes that step 60 % slower (78 ms), so it is a property of the replay lanes only.
+    # default: replayed on one rank (measured <= the eager step at every workload, profiles/r05_replay_sweep.txt + r05_stream_priorities.txt);
+    # eager whenever a process group exists -- the bucketed RCCL calls are issued from inside the backward and are not part of a capture
+    use_graph = a.graph if a.graph >= 0 else (1 if (world == 1 and not D.forced()) else 0)
     step = step_eager
     if use_graph:
         from evoke_amd.graph import StepGraph

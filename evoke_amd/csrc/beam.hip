@@ -265,7 +265,10 @@ __global__ __launch_bounds__(256) void beam_step_fast_kernel(const BeamP p) {
     for (int r = 0; r < beam; ++r) {
       float bv = v; int bi = id;
       wave_argmax(bv, bi);
-      if (lane == 0) { win_v[r] = bv; win_i[r] = bi; }
+      // No comparable candidate left (every log-probability of the sample NaN or -inf: the forward guard only scans the trunk output): the
+      // sentinel index would address LDS rows beyond the sample's beams below -- slot r then keeps ITS OWN hypothesis and emits token 0 ([PAD]),
+      // a defined state instead of garbage.
+      if (lane == 0) { win_v[r] = bv; win_i[r] = bi == 0x7fffffff ? r * V1 : bi; }
       if (id == bi) { v = -INFINITY; id = 0x7fffffff; }
     }
   }

@@ -106,6 +106,21 @@ struct EvkDeviceOnce {
     });                                                                                                                            \
   } while (0)
 
+// runtime.hip: true for streams made by evk_stream_create_cu_mask (kernels that need their whole grid resident at once must not run there)
+bool evk_stream_is_cu_masked(hipStream_t s);
+
+// Capture probe (replay.hip): while a training step is being stream-captured for the step replayer, every launch of the library notes which
+// HIP stream created which graph node (hipStreamGetCaptureInfo_v2 right after the launch: the stream's dependency set is the new node), so
+// that the replayer's lanes ARE the capture's streams.  One predictable branch per launch when the probe is off.
+extern bool g_evk_capture_probe;
+void evk_capture_note(hipStream_t s);
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)            \
+  do {                                                                                               \
+    (kernelName)<<<(numBlocks), (numThreads), (memPerBlock), (streamId)>>>(__VA_ARGS__);             \
+    if (g_evk_capture_probe) evk_capture_note(streamId);                                             \
+  } while (0)
+
 // profiling: an event pair around each launch when enabled (bench.py roofline leg)
 void evk_prof_begin(int family, hipStream_t s);
 void evk_prof_end(int family, hipStream_t s, double flops);

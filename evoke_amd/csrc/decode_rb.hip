@@ -312,7 +312,23 @@ int evk_decode_rowblock(const void* a, const void* w1_packed, const float* b1, c
   // buffer and the whole grid is resident at once (one 512-thread workgroup per CU suffices: 4 x rbs <= 256); EVK_DECODE_RB_SPLIT=0 disables
   static const int split_on = evk_tunable("EVK_DECODE_RB_SPLIT", 1);
   p.rbs = rbs;
-  if (sync_ws && split_on && 4 * rbs <= 256) {
+  // The four workgroups of a row block wait for each other (cluster_arrive_wait), so ALL 4 x rbs workgroups of the launch must be resident
+  // together: the grid is held to what the device admits at once -- compute units x the occupancy the runtime reports for this kernel, queried
+  // once per device -- and a stream that may only use a share of the compute units (evk_stream_create_cu_mask) never takes the split variant.
+  // Within that bound forward progress needs nothing else: a workgroup that waits holds a slot, never a lock, and workgroups are dispatched in
+  // index order, so the siblings of a resident workgroup are the next ones to be placed.
+  static EvkDeviceOnce cap_once;
+  const long cap = reinterpret_cast<long>(cap_once.get([]() -> void* {
+    int dev = 0, cus = 0, per_cu_a = 0, per_cu_b = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_a, decode_rowblock_kernel<false, 4>, NTH, 0) != hipSuccess) per_cu_a = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_b, decode_rowblock_kernel<true, 4>, NTH, 0) != hipSuccess) per_cu_b = 0;
+    (void)hipGetLastError();
+    const long c = (long)cus * (per_cu_a < per_cu_b ? per_cu_a : per_cu_b);
+    return reinterpret_cast<void*>(c > 0 ? c : 1L);          // (non-null: "queried"; 1 = nothing fits, the split variant is never taken)
+  }));
+  if (sync_ws && split_on && 4L * rbs <= cap && !evk_stream_is_cu_masked(s)) {
     p.sync_ctr = reinterpret_cast<unsigned*>(sync_ws);                                                        // [2][rbs]
     p.sync_part = reinterpret_cast<float*>(reinterpret_cast<char*>(sync_ws) + (size_t)rbs * 256);
     p.sync_hid = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(sync_ws) + (size_t)rbs * 256 + (size_t)rbs * 4 * 2 * TMR * 4);

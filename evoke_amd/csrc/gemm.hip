@@ -796,6 +796,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmP p) {
           v[j] = act_apply(v[j], p.act);
           if (p.resid) v[j] += p.r_f32 ? reinterpret_cast<const float*>(p.resid)[(long)m * p.ldr + nn + j]
                                        : bf2f(reinterpret_cast<const bf16_t*>(p.resid)[(long)m * p.ldr + nn + j]);
+          if (p.gate && !(bf2f(p.gate[(long)m * p.ldg + nn + j]) > 0.f)) v[j] = 0.f;          // relu_gate, after resid (as the tile kernel)
           if (p.c_f32) reinterpret_cast<float*>(p.C)[(long)m * p.ldc + nn + j] = v[j];
           else reinterpret_cast<bf16_t*>(p.C)[(long)m * p.ldc + nn + j] = f2bf(v[j]);
         }
@@ -1269,7 +1270,7 @@ extern "C" int evk_gemm_launch(const evk_gemm* d, evk_stream_t stream) {
   ProfScope ps(EVK_FAM_GEMM, s, flops);
   const int am = d->a_mode, bm = d->b_mode;
   if (am == EVK_A_PLAIN && bm == EVK_B_PLAIN && batch == 1 && !p.accumulate && d->K % SK_KC == 0 &&
-      cdiv(d->M, 128) * cdiv(d->N, 128) < skinny_tiles() && d->M <= skinny_rows() && !d->colstats && !d->relu_gate)
+      cdiv(d->M, 128) * cdiv(d->N, 128) < skinny_tiles() && d->M <= skinny_rows() && !d->colstats && !(d->relu_gate && d->gatestats))
     return launch_skinny(p, s);
   if (am == EVK_A_PLAIN && bm == EVK_B_PLAIN) return launch_modes<EVK_A_PLAIN, EVK_B_PLAIN>(p, batch, d->splitk, d->workspace, d->workspace_bytes, d, s);
   if (am == EVK_A_CONV && bm == EVK_B_PLAIN) return launch_modes<EVK_A_CONV, EVK_B_PLAIN>(p, batch, d->splitk, d->workspace, d->workspace_bytes, d, s);

@@ -13,10 +13,29 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <queue>
+#include <mutex>
 #include <unordered_map>
 #include <vector>
 #include <string.h>
 #include "common.h"
+
+// ---- capture probe (common.h): node -> the HIP stream whose launch created it, noted by every launch of the library while armed
+bool g_evk_capture_probe = false;
+static std::mutex g_probe_mu;
+static std::unordered_map<hipGraphNode_t, hipStream_t> g_probe_map;
+static std::unordered_map<hipStream_t, int> g_lane_prio;          // capture stream -> priority of the lane that replays it (evk_replay_lane_priority)
+
+void evk_capture_note(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  hipGraph_t g = nullptr;
+  const hipGraphNode_t* deps = nullptr;
+  size_t n = 0;
+  if (hipStreamGetCaptureInfo_v2(s, &st, &id, &g, &deps, &n) != hipSuccess) { (void)hipGetLastError(); return; }
+  if (st != hipStreamCaptureStatusActive || n != 1 || !deps) return;          // right after a launch the stream's dependency set is that node
+  std::lock_guard<std::mutex> lk(g_probe_mu);
+  g_probe_map[deps[0]] = s;
+}
 
 namespace {
 
@@ -53,8 +72,36 @@ int new_event(Plan* p) {
 
 extern "C" {
 
-/* Builds a replay plan from a captured (not necessarily instantiated) hipGraph_t.  Returns NULL on failure (evk_last_error). */
-void* evk_replay_build(void* graph_handle, int32_t max_lanes) {
+/* Arms (1) / disarms (0) the capture probe; arming forgets what an earlier capture noted.  Arm it right before the capture begins and build
+ * the plan with evk_replay_build_streams before disarming. */
+int evk_capture_probe(int32_t on) {
+  std::lock_guard<std::mutex> lk(g_probe_mu);
+  if (on) g_probe_map.clear();
+  g_evk_capture_probe = on != 0;
+  return EVK_OK;
+}
+
+void* evk_replay_build_streams(void* graph_handle, int32_t max_lanes, evk_stream_t origin);
+
+/* The lane that replays capture stream `captured` runs at HIP queue priority `prio` (-1 above the default, 0 default) instead of that stream's
+ * own priority; applies to plans built afterwards.  Measured (profiles/r05_stream_priorities.txt): with the whole step queued at once the
+ * relational-memory chain -- ~1400 dependent launches of a few microseconds -- wants the higher priority (replayed step 48.9 -> 48.1 ms at
+ * 384^2, 31.4 -> 30.0 ms at 224^2), while the SAME priority on the eager step's stream makes that step 60 % slower (78 ms). */
+int evk_replay_lane_priority(evk_stream_t captured, int32_t prio) {
+  std::lock_guard<std::mutex> lk(g_probe_mu);
+  g_lane_prio[reinterpret_cast<hipStream_t>(captured)] = prio;
+  return EVK_OK;
+}
+
+/* Builds a replay plan from a captured (not necessarily instantiated) hipGraph_t.  Returns NULL on failure (evk_last_error).
+ * Lanes = a minimum path cover of the dependency graph (no knowledge of the capture's streams). */
+void* evk_replay_build(void* graph_handle, int32_t max_lanes) { return evk_replay_build_streams(graph_handle, max_lanes, nullptr); }
+
+/* The same with the capture probe's notes: `origin` = the stream the capture began on (its nodes become lane 0 = the caller's stream at
+ * run time); every other capture stream becomes a lane of its own, created at the default priority like the eager step's side streams.  Nodes
+ * the library did not launch itself (torch's glue kernels, memsets) continue the lane of their FIRST dependency -- a capturing stream lists
+ * its own previous node first, the nodes of the events it waited for after it.  origin == NULL or no notes: the path cover. */
+void* evk_replay_build_streams(void* graph_handle, int32_t max_lanes, evk_stream_t origin) {
   hipGraph_t graph = reinterpret_cast<hipGraph_t>(graph_handle);
   if (!graph || max_lanes < 1) { evk_set_error("replay_build: bad args"); return nullptr; }
   size_t n = 0, ne = 0;
@@ -205,12 +252,44 @@ void* evk_replay_build(void* graph_handle, int32_t max_lanes) {
       }
     }
   }
+  // lanes by capture stream (probe notes), when there are any
+  std::vector<int> forced(n, -1);
+  std::vector<hipStream_t> lane_stream;       // lane -> the capture stream it stands for (stream lanes only)
+  size_t n_streams = 0, n_noted = 0;
+  if (origin) {
+    std::lock_guard<std::mutex> lk(g_probe_mu);
+    std::unordered_map<hipStream_t, int> lane_id;
+    lane_id[reinterpret_cast<hipStream_t>(origin)] = 0;
+    for (size_t k = 0; k < n && !g_probe_map.empty(); ++k) {
+      auto it = g_probe_map.find(nodes[order[k]]);
+      if (it != g_probe_map.end()) {
+        auto ins = lane_id.emplace(it->second, (int)lane_id.size());
+        forced[k] = ins.first->second;
+        ++n_noted;
+      } else {
+        size_t nd = 0;
+        int lane = 0;
+        if (hipGraphNodeGetDependencies(nodes[order[k]], nullptr, &nd) == hipSuccess && nd > 0) {
+          std::vector<hipGraphNode_t> deps(nd);
+          if (hipGraphNodeGetDependencies(nodes[order[k]], deps.data(), &nd) == hipSuccess && nd > 0) {
+            auto f = id.find(deps[0]);
+            if (f != id.end() && forced[pos[f->second]] >= 0) lane = forced[pos[f->second]];
+          }
+        }
+        forced[k] = lane;
+      }
+    }
+    n_streams = lane_id.size();
+    if (n_noted == 0 || (int)n_streams > max_lanes) { std::fill(forced.begin(), forced.end(), -1); n_streams = 0; }
+    else { lane_stream.assign(n_streams, nullptr); for (auto& kv : lane_id) lane_stream[kv.second] = kv.first; }
+  }
   std::vector<int> lane_tail;                 // per lane: issue index of its last node
+  if (n_streams) lane_tail.assign(n_streams, -1);
   for (size_t k = 0; k < n; ++k) {
     RNode& r = p->nodes[k];
     const std::vector<int>& pr = pred[order[k]];
-    int lane = -1;
-    if (prv[k] >= 0) lane = p->nodes[prv[k]].lane;
+    int lane = forced[k];
+    if (lane < 0 && prv[k] >= 0) lane = p->nodes[prv[k]].lane;
     if (lane < 0) {
       if (lane_tail.empty()) { lane = 0; lane_tail.push_back(-1); }
       else if ((int)lane_tail.size() < max_lanes) { lane = (int)lane_tail.size(); lane_tail.push_back(-1); }
@@ -249,7 +328,32 @@ void* evk_replay_build(void* graph_handle, int32_t max_lanes) {
         for (RNode& r : p->nodes) r.lane = r.lane == crit ? 0 : (r.lane == 0 ? crit : r.lane);
     }
   }
+  // Pacing (EVK_REPLAY_PACE = W >= 0, with stream lanes only): the eager step's host issues the lanes interleaved in program order and is
+  // never far ahead of the GPU, so a side lane's kernel rarely starts long before the main-lane kernels issued in front of it have run; the
+  // replayer queues every lane within ~10 ms, and the side lanes then run as far ahead as their dependencies allow and share the CUs with
+  // the critical path from the first microsecond.  With pacing, every P-th kernel of a side lane (EVK_REPLAY_PACE_EVERY, default 8) also
+  // waits for the main-lane kernel that was issued W main-lane kernels before it: all added edges point forward in issue order (no cycle).
+  const int pace_w = n_streams ? evk_tunable("EVK_REPLAY_PACE", -1) : -1;
+  if (pace_w >= 0) {
+    const int every = std::max(1, evk_tunable("EVK_REPLAY_PACE_EVERY", 8));
+    std::vector<int> main_idx;
+    std::vector<int> since(lane_tail.size(), 0);
+    for (size_t k = 0; k < n; ++k) {
+      RNode& r = p->nodes[k];
+      if (r.type != 0) continue;
+      if (r.lane == 0) { main_idx.push_back((int)k); continue; }
+      if (++since[r.lane] < every) continue;
+      since[r.lane] = 0;
+      const int j = (int)main_idx.size() - 1 - pace_w;
+      if (j < 0) continue;
+      RNode& rq = p->nodes[main_idx[j]];
+      if (rq.record < 0) { rq.record = new_event(p); if (rq.record < 0) { evk_set_error("replay_build: hipEventCreate failed"); delete p; return nullptr; } }
+      r.waits.push_back(rq.record);
+      ++p->n_cross;
+    }
+  }
   if (replay_debug()) {
+    fprintf(stderr, "[replay] %zu nodes, %zu noted by the capture probe, %zu capture streams%s\n", n, n_noted, n_streams, n_streams ? "" : " (path-cover lanes)");
     std::vector<int> cnt(lane_tail.size(), 0);
     for (RNode& r : p->nodes) ++cnt[r.lane];
     for (size_t l = 0; l < cnt.size(); ++l) {
@@ -262,9 +366,19 @@ void* evk_replay_build(void* graph_handle, int32_t max_lanes) {
   }
   p->lanes.assign(lane_tail.size(), nullptr);
   // side lanes at the default priority (0), like the eager step's side streams; EVK_REPLAY_SIDE_PRIO overrides (1 = lowest on this device)
+  // (stream lanes: every lane runs at the priority of the capture stream it stands for -- the eager step's own assignment, e.g. the latency-bound
+  // relational-memory chain above the chip-filling weight-gradient kernels)
   const int side_prio = evk_tunable("EVK_REPLAY_SIDE_PRIO", 0);
-  for (size_t l = 1; l < p->lanes.size(); ++l)
-    if (hipStreamCreateWithPriority(&p->lanes[l], hipStreamNonBlocking, side_prio) != hipSuccess) { evk_set_error("replay_build: hipStreamCreate failed"); delete p; return nullptr; }
+  for (size_t l = 1; l < p->lanes.size(); ++l) {
+    int prio = side_prio;
+    if (l < lane_stream.size() && lane_stream[l]) {
+      std::lock_guard<std::mutex> lk(g_probe_mu);
+      auto it = g_lane_prio.find(lane_stream[l]);
+      if (it != g_lane_prio.end()) prio = it->second;
+      else if (hipStreamGetPriority(lane_stream[l], &prio) != hipSuccess) { prio = side_prio; (void)hipGetLastError(); }
+    }
+    if (hipStreamCreateWithPriority(&p->lanes[l], hipStreamNonBlocking, prio) != hipSuccess) { evk_set_error("replay_build: hipStreamCreate failed"); delete p; return nullptr; }
+  }
   p->begin_event = new_event(p);
   for (size_t l = 1; l < p->lanes.size(); ++l) {
     const int e = new_event(p);

@@ -19,11 +19,11 @@ int rmf32_attn_train(const float* qkv, const float* xp, long x_bstride, float* a
                      hipStream_t s);
 int rmf32_gate_train(const float* xp, long x_bstride, const float* gu, const float* nm1, const float* h2, float* m, bf16_t* m16_next, bf16_t* tm16_next,
                      bf16_t* out, long out_bstride, bf16_t* si, bf16_t* sf, bf16_t* tnm, int B, hipStream_t s);
-int rmf32_qkv_gu(const float* mem, const float* Wqkv, const float* bqkv, float* qkv, bf16_t* qkv16, const float* U, const float* bU, float* gu, int R,
-                 hipStream_t s);
+int rmf32_qkv_gu(const float* mem, const float* tmem, const float* Wqkv, const float* bqkv, float* qkv, bf16_t* qkv16, const float* U, const float* bU,
+                 float* gu, int R, hipStream_t s);
 int rmf32_w2_gate_train(const float* h1, const float* W2, const float* b2, bf16_t* h2_16, const float* xp, long x_bstride, const float* gu, const float* nm1,
-                        float* m, bf16_t* m16_next, bf16_t* tm16_next, bf16_t* out, long out_bstride, bf16_t* si, bf16_t* sf, bf16_t* tnm, int R,
-                        hipStream_t s);
+                        float* m, bf16_t* m16_next, bf16_t* tm16_next, bf16_t* out, long out_bstride, bf16_t* si, bf16_t* sf, bf16_t* tnm, float* tm32,
+                        int R, hipStream_t s);
 
 namespace {
 
@@ -165,6 +165,7 @@ __global__ __launch_bounds__(256) void rm_gate_fwd2_kernel(const GateP p) {
 struct GateBP {
   const bf16_t* dout; long dout_bstride; const bf16_t* dcarry; const bf16_t* si; const bf16_t* sf; const bf16_t* tnm; const bf16_t* m;
   bf16_t* dnm2; bf16_t* dmd; bf16_t* dgates; bf16_t* dgw; long dgw_bstride; int B;
+  const bf16_t* h2; bf16_t* dh2;          // dh2 = dnm2 * (h2 > 0): the first ReLU mask of the token rides on this launch (or null / null)
 };
 __global__ __launch_bounds__(256) void rm_gate_bwd2_kernel(const GateBP p) {
   const long total = (long)p.B * D_;
@@ -178,7 +179,9 @@ __global__ __launch_bounds__(256) void rm_gate_bwd2_kernel(const GateBP p) {
       float g = bf2f(p.dout[b * p.dout_bstride + s * D_ + c]);
       if (p.dcarry) g += bf2f(p.dcarry[e]);
       const float si = bf2f(p.si[e]), sf = bf2f(p.sf[e]), t = bf2f(p.tnm[e]);
-      p.dnm2[e] = f2bf(g * si * (1.f - t * t));
+      const bf16_t dn = f2bf(g * si * (1.f - t * t));
+      p.dnm2[e] = dn;
+      if (p.dh2) p.dh2[e] = bf2f(p.h2[e]) > 0.f ? dn : (bf16_t)0;
       p.dmd[e] = f2bf(g * sf);
       const float di = g * t * si * (1.f - si), df = g * bf2f(p.m[e]) * sf * (1.f - sf);
       p.dgates[(b * S_ + s) * 2 * D_ + c] = f2bf(di);
@@ -219,9 +222,10 @@ inline bool rm_use_persistent(int L) {
 inline int ew_blocks(long work) { long b = cdiv(work, 256); return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b)); }
 
 int gemm(const void* A, const void* B, void* C, int M, int N, int K, int b_mode, long ldb, const float* bias, const void* resid, int act,
-         evk_stream_t st) {
+         evk_stream_t st, const void* relu_gate = nullptr) {
   evk_gemm d{};
   d.A = A; d.B = B; d.C = C; d.bias = bias; d.resid = resid;
+  d.relu_gate = relu_gate; d.ldg = N;
   d.M = M; d.N = N; d.K = K; d.a_mode = EVK_A_PLAIN; d.b_mode = b_mode;
   d.lda = K; d.ldb = ldb; d.ldc = N; d.ldr = N;
   d.batch_outer = d.batch_inner = 1; d.alpha = 1.f; d.act = act; d.c_dtype = EVK_BF16; d.r_dtype = EVK_BF16;
@@ -719,7 +723,7 @@ int evk_rm_forward(const void* xk, const void* xv, const void* gw, const void* m
  *   ws32: evk_rm_f32_ws_bytes(B, L) bytes of f32 scratch. */
 int64_t evk_rm_f32_ws_bytes(int32_t B, int32_t L) {
   const long R = (long)B * S_;
-  return ((long)B * L * 2048 + R * D_ + R * 1536 + 4 * R * D_ + R * 2 * D_ + 1024) * 4;
+  return ((long)B * L * 2048 + 2 * R * D_ + R * 1536 + 4 * R * D_ + R * 2 * D_ + 1024) * 4;
 }
 
 int evk_rm_forward_f32(const float* x32, const float* Wx32, const float* bx, const void* m0, const float* Wqkv32, const float* bqkv, const float* Wo32,
@@ -739,6 +743,7 @@ int evk_rm_forward_f32(const float* x32, const float* Wx32, const float* bx, con
   auto take = [&](long n) { float* r = fp; fp += (n + 63) / 64 * 64; return r; };
   float* xp = take((long)B * L * 2048);            // keys | values | gates of every token, f32
   float* mem = take(RD);
+  float* tmem = take(RD);                          // tanh(memory), left by the gate epilogue of the previous token
   float* qkv = take(R * 1536);
   float* a = take(RD); float* nm1 = take(RD); float* h1 = take(RD); float* h2 = take(RD);
   float* gu = take(R * 2 * D_);
@@ -751,13 +756,13 @@ int evk_rm_forward_f32(const float* x32, const float* Wx32, const float* bx, con
   for (int t = 0; t < L; ++t) {
     const float* xt = xp + (long)t * 2048;
     // 5 launches per token: {q | k | v of the memory, U tanh(m)} as one, slot attention, Wo (+ m), W0, W2 with the gate in its epilogue
-    if (int e = rmf32_qkv_gu(mem, Wqkv32, bqkv, qkv, w.qkv + (long)t * R * 1536, U32, bU, gu, (int)R, s)) return e;
+    if (int e = rmf32_qkv_gu(mem, t ? tmem : nullptr, Wqkv32, bqkv, qkv, w.qkv + (long)t * R * 1536, U32, bU, gu, (int)R, s)) return e;
     if (int e = rmf32_attn_train(qkv, xt, xrow, a, w.a + t * RD, w.P + (long)t * B * HEADS * S_ * KEYS, p_drop,
                                  (unsigned long long)(seed + 0x51ED27ULL * (uint64_t)(t + 1)), B, s)) return e;
     if (int e = rmf32_gemm(a, D_, Wo32, bo, mem, D_, nm1, D_, (int)R, D_, EVK_ACT_NONE, 0, w.nm1 + t * RD, D_, s)) return e;
     if (int e = rmf32_gemm(nm1, D_, W032, b0, nullptr, 0, h1, D_, (int)R, D_, EVK_ACT_RELU, 0, w.h1 + t * RD, D_, s)) return e;
     if (int e = rmf32_w2_gate_train(h1, W232, b2, w.h2 + t * RD, xt, xrow, gu, nm1, mem, w.m + (t + 1) * RD, w.tm + (t + 1) * RD,
-                                    (bf16_t*)out + (long)t * S_ * D_, (long)L * S_ * D_, w.si + t * RD, w.sf + t * RD, w.tnm + t * RD, (int)R, s)) return e;
+                                    (bf16_t*)out + (long)t * S_ * D_, (long)L * S_ * D_, w.si + t * RD, w.sf + t * RD, w.tnm + t * RD, tmem, (int)R, s)) return e;
   }
   (void)h2;
   if (m_last)
@@ -844,26 +849,19 @@ int evk_rm_backward(const void* dout, const void* xk, const void* xv, const void
   for (int t = L - 1; t >= 0 && !persistent; --t) {
     bf16_t* dgs = w.dgs + (long)t * R * 2 * D_;
     bf16_t* dnm2 = w.dnm2s + t * RD;            // becomes dnm1 (stack) below
+    bf16_t* dh2 = w.dh2s + t * RD;
+    bf16_t* dh1 = w.dh1s + t * RD;
     GateBP gb{(const bf16_t*)dout + (long)t * S_ * D_, (long)L * S_ * D_, carry, w.si + t * RD, w.sf + t * RD, w.tnm + t * RD, w.m + t * RD,
-              w.t_dnm1, w.t_dmd, dgs, (bf16_t*)dgw + (long)t * 2 * D_, (long)L * 2 * D_, B};
+              w.t_dnm1, w.t_dmd, dgs, (bf16_t*)dgw + (long)t * 2 * D_, (long)L * 2 * D_, B, w.h2 + t * RD, dh2};
     {
       ProfScope ps(EVK_FAM_ELTWISE, s);
       hipLaunchKernelGGL(rm_gate_bwd2_kernel, dim3(ew_blocks((long)B * D_)), dim3(256), 0, s, gb);
     }
     // dtm = dgates . U
     if (int e = gemm(dgs, Ut, w.t_dtm, (int)R, D_, 2 * D_, EVK_B_PLAIN, 2 * D_, nullptr, nullptr, EVK_ACT_NONE, stream)) return e;
-    // dh2 = dnm2 * (h2 > 0);  t1 = dh2 . W2;  dh1 = t1 * (h1 > 0);  dnm1 = dh1 . W0 + dnm2
-    bf16_t* dh2 = w.dh2s + t * RD;
-    bf16_t* dh1 = w.dh1s + t * RD;
-    {
-      ProfScope ps(EVK_FAM_ELTWISE, s);
-      hipLaunchKernelGGL(relu_mask_kernel, dim3(ew_blocks(RD)), dim3(256), 0, s, w.t_dnm1, w.h2 + t * RD, dh2, RD);
-    }
-    if (int e = gemm(dh2, W2t, w.t_t1, (int)R, D_, D_, EVK_B_PLAIN, D_, nullptr, nullptr, EVK_ACT_NONE, stream)) return e;
-    {
-      ProfScope ps(EVK_FAM_ELTWISE, s);
-      hipLaunchKernelGGL(relu_mask_kernel, dim3(ew_blocks(RD)), dim3(256), 0, s, w.t_t1, w.h1 + t * RD, dh1, RD);
-    }
+    // dh2 = dnm2 * (h2 > 0) (written by the gate kernel);  dh1 = (dh2 . W2) * (h1 > 0) (ReLU mask in the product's epilogue);
+    // dnm1 = dh1 . W0 + dnm2        -- 8 launches per token (10 with the two masks as launches of their own)
+    if (int e = gemm(dh2, W2t, dh1, (int)R, D_, D_, EVK_B_PLAIN, D_, nullptr, nullptr, EVK_ACT_NONE, stream, w.h1 + t * RD)) return e;
     if (int e = gemm(dh1, W0t, dnm2, (int)R, D_, D_, EVK_B_PLAIN, D_, nullptr, w.t_dnm1, EVK_ACT_NONE, stream)) return e;   // dnm2 now holds dnm1
     // da = dnm1 . Wo ; attention backward
     if (int e = gemm(dnm2, Wot, w.t_da, (int)R, D_, D_, EVK_B_PLAIN, D_, nullptr, nullptr, EVK_ACT_NONE, stream)) return e;

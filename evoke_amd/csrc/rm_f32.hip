@@ -25,6 +25,7 @@ struct GateE {
   const float* xp; long x_bstride; const float* gu; const float* nm1; float* m;
   bf16_t* out16; long out_bstride;                 // memory row for the conditional layer norms: out16[b * out_bstride + slot * 512 + c]
   bf16_t* m16_next; bf16_t* tm16_next; bf16_t* si; bf16_t* sf; bf16_t* tnm;      // training saves ([R][512] each) or null
+  float* tm32;                                     // tanh(new memory) in f32 ([R][512]) or null
 };
 struct GemmF { const float* A; const float* W; const float* bias; const float* resid; float* C; int M, N; long lda, ldc, ldr; int act, a_tanh; bf16_t* C16; long ldc16;
                int nbx; };                          // nbx = N / 32: column blocks of this problem
@@ -76,6 +77,39 @@ inline int rm_split16() {
 #else
   return 0;                                   // (bf16 has 8 significand bits: three terms would not reach f32)
 #endif
+}
+
+// one output element of a product: activation, residual, f32 / 16-bit stores and, on the last product of a token, the gate (see GateE)
+__device__ __forceinline__ void f32_epilogue(const GemmF3& pp, const GemmF& p, int m, int col, float v) {
+  if (m >= p.M) return;
+  if (p.act == EVK_ACT_RELU) v = fmaxf(v, 0.f);
+  if (p.resid) v += p.resid[(long)m * p.ldr + col];
+  if (p.C) p.C[(long)m * p.ldc + col] = v;
+  if (p.C16) p.C16[(long)m * p.ldc16 + col] = f2bf(v);          // what the 16-bit backward of the training recurrence reads
+  if (pp.has_gate) {
+    const GateE& g = pp.gate;                                  // v = h2[m][col]
+    const long b = m / S3, e = (long)m * D512 + col;
+    const int sl = m - (int)b * S3;
+    const float ig = g.xp[b * g.x_bstride + 1024 + col] + g.gu[(long)m * 1024 + col];
+    const float fg = g.xp[b * g.x_bstride + 1536 + col] + g.gu[(long)m * 1024 + 512 + col];
+    const float si = 1.f / (1.f + expf(-ig)), sf = 1.f / (1.f + expf(-fg));
+    const float t = tanhf(g.nm1[e] + v);
+    float nx = si * t + sf * g.m[e];
+    // the 16-bit copy is the f32 STATE rounded once more: without this fence the compiler forms it with a mixed-precision fma
+    // (v_fma_mixlo_f16: one rounding of the exact sum), which differs from round16(round32(.)) at ties
+    asm volatile("" : "+v"(nx));
+    g.m[e] = nx;
+    const bf16_t n16 = f2bf(nx);
+    g.out16[b * g.out_bstride + sl * D512 + col] = n16;
+    if (g.tm32 || g.m16_next) {
+      const float tn = tanhf(nx);
+      if (g.tm32) g.tm32[e] = tn;                              // tanh(memory) in f32: the A operand of the next token's U product
+      if (g.m16_next) {
+        g.m16_next[e] = n16; g.tm16_next[e] = f2bf(tn);
+        g.si[e] = f2bf(si); g.sf[e] = f2bf(sf); g.tnm[e] = f2bf(t);
+      }
+    }
+  }
 }
 
 template <bool SPLIT>
@@ -208,35 +242,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmF3 pp) {
     const int col = n0 + wn * 32 + jt * 16 + (lane & 15);
     const float bias = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = m0 + wm * 16 + 4 * (lane >> 4) + j;
-      if (m >= p.M) continue;
-      float v = acc[jt][j] + bias;
-      if (p.act == EVK_ACT_RELU) v = fmaxf(v, 0.f);
-      if (p.resid) v += p.resid[(long)m * p.ldr + col];
-      if (p.C) p.C[(long)m * p.ldc + col] = v;
-      if (p.C16) p.C16[(long)m * p.ldc16 + col] = f2bf(v);          // what the 16-bit backward of the training recurrence reads
-      if (pp.has_gate) {
-        const GateE& g = pp.gate;                                  // v = h2[m][col]
-        const long b = m / S3, e = (long)m * D512 + col;
-        const int sl = m - (int)b * S3;
-        const float ig = g.xp[b * g.x_bstride + 1024 + col] + g.gu[(long)m * 1024 + col];
-        const float fg = g.xp[b * g.x_bstride + 1536 + col] + g.gu[(long)m * 1024 + 512 + col];
-        const float si = 1.f / (1.f + expf(-ig)), sf = 1.f / (1.f + expf(-fg));
-        const float t = tanhf(g.nm1[e] + v);
-        float nx = si * t + sf * g.m[e];
-        // the 16-bit copy is the f32 STATE rounded once more: without this fence the compiler forms it with a mixed-precision fma
-        // (v_fma_mixlo_f16: one rounding of the exact sum), which differs from round16(round32(.)) at ties
-        asm volatile("" : "+v"(nx));
-        g.m[e] = nx;
-        const bf16_t n16 = f2bf(nx);
-        g.out16[b * g.out_bstride + sl * D512 + col] = n16;
-        if (g.m16_next) {
-          g.m16_next[e] = n16; g.tm16_next[e] = f2bf(tanhf(nx));
-          g.si[e] = f2bf(si); g.sf[e] = f2bf(sf); g.tnm[e] = f2bf(t);
-        }
-      }
-    }
+    for (int j = 0; j < 4; ++j) f32_epilogue(pp, p, m0 + wm * 16 + 4 * (lane >> 4) + j, col, acc[jt][j] + bias);
   }
 }
 
@@ -409,18 +415,19 @@ int rmf32_attn_train(const float* qkv, const float* xp, long x_bstride, float* a
   return evk_check_launch("rm f32 attention (train)");
 }
 // q | k | v of the memory and U tanh(m) as one launch (training recurrence: the token's x projections are hoisted out of the loop)
-int rmf32_qkv_gu(const float* mem, const float* Wqkv, const float* bqkv, float* qkv, bf16_t* qkv16, const float* U, const float* bU, float* gu, int R,
-                 hipStream_t s) {
+int rmf32_qkv_gu(const float* mem, const float* tmem, const float* Wqkv, const float* bqkv, float* qkv, bf16_t* qkv16, const float* U, const float* bU,
+                 float* gu, int R, hipStream_t s) {
+  // tmem = tanh(mem) in f32 when the previous token's gate epilogue left it (GateE::tm32); null: the product applies tanh to its A operand itself
   const GemmF g2[2] = {mkf(mem, D512, Wqkv, bqkv, nullptr, 0, qkv, 1536, R, 1536, EVK_ACT_NONE, 0, qkv16, 1536),
-                       mkf(mem, D512, U, bU, nullptr, 0, gu, 1024, R, 1024, EVK_ACT_NONE, 1)};
+                       mkf(tmem ? tmem : mem, D512, U, bU, nullptr, 0, gu, 1024, R, 1024, EVK_ACT_NONE, tmem ? 0 : 1)};
   return gemm_f32_multi(g2, 2, nullptr, s);
 }
 // h2 = relu(h1 W2^T + b2) (16-bit copy saved) with the gate epilogue: memory in place + every 16-bit save of the training recurrence
 int rmf32_w2_gate_train(const float* h1, const float* W2, const float* b2, bf16_t* h2_16, const float* xp, long x_bstride, const float* gu, const float* nm1,
-                        float* m, bf16_t* m16_next, bf16_t* tm16_next, bf16_t* out, long out_bstride, bf16_t* si, bf16_t* sf, bf16_t* tnm, int R,
-                        hipStream_t s) {
+                        float* m, bf16_t* m16_next, bf16_t* tm16_next, bf16_t* out, long out_bstride, bf16_t* si, bf16_t* sf, bf16_t* tnm, float* tm32,
+                        int R, hipStream_t s) {
   const GemmF g1 = mkf(h1, D512, W2, b2, nullptr, 0, nullptr, D512, R, D512, EVK_ACT_RELU, 0, h2_16, D512);
-  const GateE ge{xp, x_bstride, gu, nm1, m, out, out_bstride, m16_next, tm16_next, si, sf, tnm};
+  const GateE ge{xp, x_bstride, gu, nm1, m, out, out_bstride, m16_next, tm16_next, si, sf, tnm, tm32};
   return gemm_f32_multi(&g1, 1, &ge, s);
 }
 int rmf32_gate_train(const float* xp, long x_bstride, const float* gu, const float* nm1, const float* h2, float* m, bf16_t* m16_next, bf16_t* tm16_next,
@@ -479,7 +486,7 @@ int evk_rm_decode_step_f32(const float* x, const float* Wx, const float* bx, flo
   if (int e = gemm_f32(nm1, D512, W0, b0, nullptr, 0, h1, D512, R, D512, EVK_ACT_RELU, 0, s)) return e;
   {
     const GemmF g1 = mkf(h1, D512, W2, b2, nullptr, 0, nullptr, D512, R, D512, EVK_ACT_RELU, 0);
-    const GateE ge{xp, 2048L, gu, nm1, mem, (bf16_t*)out16, (long)S3 * D512, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const GateE ge{xp, 2048L, gu, nm1, mem, (bf16_t*)out16, (long)S3 * D512, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (int e = gemm_f32_multi(&g1, 1, &ge, s)) return e;
   }
   (void)h2;

@@ -66,6 +66,13 @@ void evk_prof_end(int family, hipStream_t s, double flops) {
   g_open = nullptr;
 }
 
+static std::vector<hipStream_t> g_masked_streams;          // guarded by g_mu
+bool evk_stream_is_cu_masked(hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (hipStream_t m : g_masked_streams) if (m == s) return true;
+  return false;
+}
+
 static const unsigned long long* g_seed_epoch = nullptr;
 const unsigned long long* evk_seed_epoch_ptr() { return g_seed_epoch; }
 
@@ -88,10 +95,16 @@ int evk_stream_create_cu_mask(const uint32_t* mask, int32_t words, void** stream
   const hipError_t err = hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask);
   if (err != hipSuccess) { evk_set_error("stream_create_cu_mask: %s", hipGetErrorString(err)); return EVK_ELAUNCH; }
   *stream_out = s;
+  { std::lock_guard<std::mutex> lk(g_mu); g_masked_streams.push_back(s); }
   return EVK_OK;
 }
 
 int evk_stream_destroy(void* stream) {
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (size_t i = 0; i < g_masked_streams.size(); ++i)
+      if (g_masked_streams[i] == reinterpret_cast<hipStream_t>(stream)) { g_masked_streams.erase(g_masked_streams.begin() + i); break; }
+  }
   if (stream && hipStreamDestroy(reinterpret_cast<hipStream_t>(stream)) != hipSuccess) { evk_set_error("stream_destroy failed"); return EVK_ELAUNCH; }
   return EVK_OK;
 }

@@ -27,6 +27,12 @@ from . import ops
 # 'replay': capture once, re-issue the recorded launches from C++ (csrc/replay.hip); 'hipgraph': hipGraphLaunch (7-12 us of host
 # time per node on ROCm 7.2: slower than eager Python for the 6k-node training step, kept for comparison)
 MODE = os.environ.get('EVK_STEP_GRAPH_MODE', 'replay')
+# HIP queue priority of the replay lane of each named side stream (ops.side_stream); every other lane keeps its capture stream's priority.
+# 'rm': the relational-memory chain goes first -- in the REPLAYED step only (csrc/replay.hip: evk_replay_lane_priority)
+LANE_PRIORITY = {'rm': int(os.environ.get('EVK_REPLAY_RM_PRIO', '-1'))}
+for _kv in os.environ.get('EVK_REPLAY_LANE_PRIO', '').split(','):          # experiments: "wgrad:1,text:-1" (HIP: -1 high, 0 default, 1 low)
+    if ':' in _kv:
+        LANE_PRIORITY[_kv.split(':')[0].strip()] = int(_kv.split(':')[1])
 
 
 def structure_key(tensors, patient_ids, extra=()):
@@ -86,11 +92,16 @@ class StepGraph:
         pool = StepGraph._shared_pool.get(dev)          # step graphs replay one at a time on one stream: one private pool for all
         if pool is None or os.environ.get('EVK_STEP_GRAPH_SHARED_POOL', '1') == '0':
             pool = StepGraph._shared_pool[dev] = torch.cuda.graph_pool_handle()
+        origin = [None]
         try:
+            if MODE == 'replay':
+                H.check(H.lib.evk_capture_probe(1), 'capture_probe')          # every library launch notes (graph node -> stream)
             with torch.cuda.graph(g, pool=pool, capture_error_mode='relaxed'):
+                origin[0] = H.stream()                                        # the stream the capture runs on: lane 0 of the plan
                 out = self.fn()
         except Exception as e:          # noqa: BLE001 -- stay on the (eager) HIP path
             import warnings
+            H.lib.evk_capture_probe(0)
             self.failed = e
             del ops.CAPTURE_KEEPALIVE[keep0:]
             warnings.warn('step graph capture failed (%r); running eagerly' % (e,))
@@ -99,7 +110,15 @@ class StepGraph:
         self.keep = ops.CAPTURE_KEEPALIVE[keep0:]          # pinned staging buffers the graph's upload kernels read: freed with this object
         del ops.CAPTURE_KEEPALIVE[keep0:]
         if MODE == 'replay':
-            plan = H.lib.evk_replay_build(C.c_void_p(g.raw_cuda_graph()), 16)
+            if os.environ.get('EVK_REPLAY_LANES', 'streams') == 'streams':
+                for name, prio in LANE_PRIORITY.items():
+                    st = ops.existing_side_stream(name)
+                    if st is not None:
+                        H.check(H.lib.evk_replay_lane_priority(C.c_void_p(st.cuda_stream), prio), 'replay_lane_priority')
+                plan = H.lib.evk_replay_build_streams(C.c_void_p(g.raw_cuda_graph()), 16, C.c_void_p(origin[0]))
+            else:                                       # the minimum path cover (rounds 2-4)
+                plan = H.lib.evk_replay_build(C.c_void_p(g.raw_cuda_graph()), 16)
+            H.lib.evk_capture_probe(0)
             if not plan:
                 import warnings
                 self.failed = RuntimeError(H.lib.evk_last_error().decode())

@@ -94,6 +94,8 @@ def _load():
         fn.restype = C.c_int64 if name.endswith('_bytes') else C.c_int
     lib.evk_replay_build.restype = C.c_void_p
     lib.evk_replay_build.argtypes = [C.c_void_p, C.c_int32]
+    lib.evk_replay_build_streams.restype = C.c_void_p
+    lib.evk_replay_build_streams.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     want = 16 if STORE == 'f16' else 0
     if lib.evk_storage_format() != want:
         raise RuntimeError('evoke_amd: %s stores format %d, EVK_STORE=%s needs %d -- rebuild' % (LIB_PATH, lib.evk_storage_format(), STORE, want))

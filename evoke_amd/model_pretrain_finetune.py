@@ -272,6 +272,11 @@ class FineTune(_Base):
                     job[4] = job[3].cpu()
 
         def finish(job):
+            # a worker clears job[1] (in advance()) BEFORE its download: whoever sees job[1] is None must still join the worker -- otherwise this
+            # thread downloads the result a second time, frees the slot while the worker is inside .cpu() on that stream, and an exception raised
+            # in the worker's tail is lost
+            if job[5] is not None:
+                job[5].result()
             seq, report_ids = job[3], job[2]
             if job[4] is None:
                 with torch.cuda.stream(dec_s[job[0]]):

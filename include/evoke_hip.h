@@ -114,6 +114,13 @@ int evk_device_cu_count(int32_t device, int32_t* cus);
  *   evk_replay_info: out6[0..6] = {nodes, kernels, memcpys, memsets, lanes (streams), cross-lane edges, nodes replayed as isolated
  *   one-node graphs (copy flavours whose parameters the public query does not return faithfully)}.                        */
 void* evk_replay_build(void* hip_graph, int32_t max_lanes);
+/* Lanes that ARE the capture's streams: evk_capture_probe(1) before the capture begins makes every launch of the library note which stream
+ * created which graph node; evk_replay_build_streams (origin = the stream the capture began on -> lane 0 = the caller's stream at run time)
+ * gives every other capture stream a lane of its own; evk_capture_probe(0) afterwards.  Without notes it falls back to evk_replay_build's
+ * minimum path cover.  (trainer_v0401.py:426-435 is the step; its eager PyTorch streams have no counterpart to mirror.) */
+int evk_capture_probe(int32_t on);
+int evk_replay_lane_priority(evk_stream_t captured, int32_t prio);   /* lane of that capture stream: HIP queue priority (-1 above default) */
+void* evk_replay_build_streams(void* hip_graph, int32_t max_lanes, evk_stream_t origin);
 int evk_replay_info(void* plan, int64_t* out6);
 int evk_replay_run(void* plan, evk_stream_t stream);
 int evk_replay_run_n(void* plan, evk_stream_t stream, int32_t n);   /* n replays back to back (the ~100 token steps of a beam search,

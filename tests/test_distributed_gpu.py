@@ -268,6 +268,10 @@ def test_reducer_collectives_wait_for_the_weight_gradient_stream():
 # not bit-deterministic from run to run (last-bit noise of the column sums), so the comparison uses the tolerances of
 # the graph-vs-eager test, with the run-to-run spread of two non-distributed runs printed beside it; optimizer step counts must be EQUAL.
 # ---------------------------------------------------------------------------------------------------------------------------------
+# FineTune in every gradient-sum mode; Pretrain (the two exchanges of gather_rows on top) in the default mode and in 'direct'
+RCCL_CASES = [('finetune', 'allreduce'), ('finetune', 'direct'), ('finetune', '16bit'), ('pretrain', 'allreduce'), ('pretrain', 'direct')]
+
+
 def _rccl_worker(port, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', EVK_FORCE_DIST='1')
     import torch.distributed as dist
@@ -315,13 +319,12 @@ def _rccl_worker(port, q):
             res[kind, 'ref'] = run(kind, 'allreduce')
             if kind == 'finetune':
                 res[kind, 'ref_again'] = run(kind, 'allreduce')
-            res[kind, 'ref16'] = run(kind, 'allreduce', roundtrip16=True)
+                res[kind, 'ref16'] = run(kind, 'allreduce', roundtrip16=True)
         assert not res['finetune', 'ref']['active']
         D.init_distributed('nccl')
         assert dist.get_backend() == 'nccl' and D.forced() and D.world_size() == 1
-        for kind in ('finetune', 'pretrain'):
-            for mode in ('allreduce', 'direct', '16bit'):
-                res[kind, mode] = run(kind, mode)
+        for kind, mode in RCCL_CASES:
+            res[kind, mode] = run(kind, mode)
 
         def diff(a, b):
             """(losses within 2e-4 relative, parameters allclose, step counts EQUAL, largest parameter difference) -- the step is not
@@ -334,8 +337,8 @@ def _rccl_worker(port, q):
 
         # plain Python values only: tensors sent through the queue would be shared-memory handles of a process that is about to exit
         rep = dict(run_to_run=diff(res['finetune', 'ref'], res['finetune', 'ref_again']))
-        for kind in ('finetune', 'pretrain'):
-            for mode in ('allreduce', 'direct', '16bit'):
+        for kind, mode in RCCL_CASES:
+            if True:
                 got, want = res[kind, mode], res[kind, 'ref16' if mode == '16bit' else 'ref']
                 rep[kind, mode] = dict(diff=diff(got, want), losses=got['losses'], want_losses=want['losses'],
                                        **{k: got[k] for k in ('active', 'touched', 'issued', 'n_buckets', 'stats')})
@@ -358,8 +361,8 @@ def test_forced_one_rank_rccl_step_equals_the_non_distributed_step():
     assert status == 'ok', rep
     assert all(rep['run_to_run'][:3]), rep['run_to_run']
     print('\n[two non-distributed runs of the same two steps] largest parameter difference %.3e' % rep['run_to_run'][3])
-    for kind in ('finetune', 'pretrain'):
-        for mode in ('allreduce', 'direct', '16bit'):
+    for kind, mode in RCCL_CASES:
+        if True:
             got = rep[kind, mode]
             assert got['active'] and got['touched'] is not None and got['touched'] > 0, (kind, mode)
             # every bucket's collective went out, in descending order, in both steps
