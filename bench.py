@@ -138,7 +138,7 @@ def decode_record(model, a, rank, world, dev, with_cpu):
     n = max(2, min(a.steps, 8))
     step_ms, dt, err = [], float('inf'), None
     pipelined = os.environ.get('EVK_DECODE_PIPELINE', '1') != '0'
-    depth = max(1, int(os.environ.get('EVK_DECODE_DEPTH', '2'))) if pipelined else 1
+    depth = max(1, int(os.environ.get('EVK_DECODE_DEPTH', '3'))) if pipelined else 1
     try:
         for _ in range(max(1, min(a.warmup, 2))):
             step()
@@ -440,7 +440,9 @@ def main():
 
     # The step's own (critical-path) stream gets the higher HIP queue priority; the side streams (weight gradients, relational
     # memory, text encoder, collectives) keep the default one and fill the CUs the main stream leaves idle.
-    main_stream = torch.cuda.Stream(device=dev, priority=-1) if os.environ.get('EVK_MAIN_PRIO', '1') == '1' else torch.cuda.current_stream()
+    # (the replayed step runs every lane, its own included, at the default priority: a fifth hardware queue -- the high-priority class has its
+    # own -- costs it 3-8 ms, profiles/r05_hw_queues.txt)
+    main_stream = torch.cuda.Stream(device=dev, priority=-1) if os.environ.get('EVK_MAIN_PRIO', '0' if use_graph else '1') == '1' else torch.cuda.current_stream()
     main_stream.wait_stream(torch.cuda.current_stream())
     torch.cuda.set_stream(main_stream)
     n_warm = max(a.warmup, 3) if use_graph else a.warmup          # capture happens on the 3rd call: keep it out of the timed steps

@@ -24,6 +24,7 @@ bool g_evk_capture_probe = false;
 static std::mutex g_probe_mu;
 static std::unordered_map<hipGraphNode_t, hipStream_t> g_probe_map;
 static std::unordered_map<hipStream_t, int> g_lane_prio;          // capture stream -> priority of the lane that replays it (evk_replay_lane_priority)
+static std::unordered_map<hipStream_t, hipStream_t> g_lane_alias; // capture stream -> the capture stream whose lane replays it too (evk_replay_lane_alias)
 
 void evk_capture_note(hipStream_t s) {
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
@@ -57,7 +58,81 @@ struct Plan {
   int begin_event = -1;
   std::vector<int> tail_events;             // events recorded at the end of the side lanes, joined by lane 0
   size_t n_kernels = 0, n_copies = 0, n_sets = 0, n_cross = 0;
+  std::vector<int> lane_prio;               // HIP priority each side lane was created with
+  std::vector<hipStream_t> spare;           // streams rejected by the hardware-queue check (kept alive: they hold their queue slot)
+  bool queues_checked = false;
+  int n_realiased = 0;
 };
+
+inline bool replay_debug();
+
+// ---- do two streams share a hardware queue?
+// The HIP runtime multiplexes streams onto a few hardware queues per priority (GPU_MAX_HW_QUEUES, default 4); which queue a new stream gets
+// depends on how many streams the process created before.  Two LANES on one hardware queue are serialised kernel by kernel, and the replayed
+// FineTune step then costs 72-80 ms instead of 47 (profiles/r05_hw_queues.txt: the step time over GPU_MAX_HW_QUEUES = 4 / 6 / 8 / 12 is
+// 48.7 / 72 / 47.0 / 76 ms with nothing else changed).  The check: one single-wave kernel that spins for ~150 us of wall clock on each of the two
+// streams, launched back to back from idle streams -- concurrent streams finish both in ~one spin, streams on one queue in two.
+__global__ void replay_spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  for (int i = 0; i < (1 << 20) && wall_clock64() - t0 < ticks; ++i) __builtin_amdgcn_s_sleep(16);          // bounded: ends whatever the clock does
+}
+
+double spin_ms(hipStream_t a, hipStream_t b, long long ticks) {
+  (void)hipStreamSynchronize(a);
+  if (b) (void)hipStreamSynchronize(b);
+  hipEvent_t e0, e1, e2;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess) return -1.0;
+  (void)hipEventRecord(e0, a);
+  hipLaunchKernelGGL(replay_spin_kernel, dim3(1), dim3(64), 0, a, ticks);
+  (void)hipEventRecord(e1, a);
+  if (b) {
+    hipLaunchKernelGGL(replay_spin_kernel, dim3(1), dim3(64), 0, b, ticks);
+    (void)hipEventRecord(e2, b);
+  }
+  (void)hipStreamSynchronize(a);
+  if (b) (void)hipStreamSynchronize(b);
+  float ta = 0.f, tb = 0.f;
+  (void)hipEventElapsedTime(&ta, e0, e1);
+  if (b) (void)hipEventElapsedTime(&tb, e0, e2);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+  (void)hipGetLastError();
+  return (double)(ta > tb ? ta : tb);
+}
+
+// 1: kernels on a and b overlap, 0: they are serialised (one hardware queue), -1: could not measure
+int streams_concurrent(hipStream_t a, hipStream_t b) {
+  if (a == b) return 0;
+  int dev = 0, khz = 0;
+  (void)hipGetDevice(&dev);
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
+  const long long ticks = (long long)khz * 150 / 1000;          // 150 us
+  const double one = spin_ms(a, nullptr, ticks);
+  const double two = spin_ms(a, b, ticks);                       // b's kernel is queued right behind a's: end of b measured from a's start
+  if (one <= 0.0 || two <= 0.0) return -1;
+  return two < 1.6 * one ? 1 : 0;
+}
+
+// make every side lane of the plan concurrent with lane 0 (`s0`) and with the other side lanes: a lane that shares a hardware queue is replaced
+// by a newly created stream of the same priority (the rejected one stays alive, so the runtime's assignment moves on), up to 16 attempts per lane
+void separate_lanes(Plan* p, hipStream_t s0) {
+  std::vector<hipStream_t> chosen{s0};
+  for (size_t l = 1; l < p->lanes.size(); ++l) {
+    hipStream_t cand = p->lanes[l];
+    for (int tries = 0; tries < 16; ++tries) {
+      bool clash = false;
+      for (hipStream_t c : chosen) if (streams_concurrent(c, cand) == 0) { clash = true; break; }
+      if (!clash) break;
+      hipStream_t fresh = nullptr;
+      if (hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking, l < p->lane_prio.size() ? p->lane_prio[l] : 0) != hipSuccess) { (void)hipGetLastError(); break; }
+      p->spare.push_back(cand);
+      cand = fresh;
+      ++p->n_realiased;
+    }
+    p->lanes[l] = cand;
+    chosen.push_back(cand);
+  }
+  if (replay_debug()) fprintf(stderr, "[replay] hardware-queue check: %d lane streams replaced\n", p->n_realiased);
+}
 
 inline bool replay_debug() { static const int on = evk_tunable("EVK_REPLAY_DEBUG", 0); return on != 0; }
 
@@ -90,6 +165,16 @@ void* evk_replay_build_streams(void* graph_handle, int32_t max_lanes, evk_stream
 int evk_replay_lane_priority(evk_stream_t captured, int32_t prio) {
   std::lock_guard<std::mutex> lk(g_probe_mu);
   g_lane_prio[reinterpret_cast<hipStream_t>(captured)] = prio;
+  return EVK_OK;
+}
+
+/* The nodes of capture stream `captured` are replayed on the lane of capture stream `onto` (NULL: forget the alias): two capture streams
+ * share one in-order lane, in capture order.  Always valid -- every dependency points to a node issued earlier -- and it removes the
+ * concurrency between the two chains; applies to plans built afterwards. */
+int evk_replay_lane_alias(evk_stream_t captured, evk_stream_t onto) {
+  std::lock_guard<std::mutex> lk(g_probe_mu);
+  if (onto) g_lane_alias[reinterpret_cast<hipStream_t>(captured)] = reinterpret_cast<hipStream_t>(onto);
+  else g_lane_alias.erase(reinterpret_cast<hipStream_t>(captured));
   return EVK_OK;
 }
 
@@ -263,7 +348,9 @@ void* evk_replay_build_streams(void* graph_handle, int32_t max_lanes, evk_stream
     for (size_t k = 0; k < n && !g_probe_map.empty(); ++k) {
       auto it = g_probe_map.find(nodes[order[k]]);
       if (it != g_probe_map.end()) {
-        auto ins = lane_id.emplace(it->second, (int)lane_id.size());
+        hipStream_t st = it->second;
+        for (int hop = 0; hop < 4; ++hop) { auto al = g_lane_alias.find(st); if (al == g_lane_alias.end()) break; st = al->second; }
+        auto ins = lane_id.emplace(st, (int)lane_id.size());
         forced[k] = ins.first->second;
         ++n_noted;
       } else {
@@ -378,6 +465,8 @@ void* evk_replay_build_streams(void* graph_handle, int32_t max_lanes, evk_stream
       else if (hipStreamGetPriority(lane_stream[l], &prio) != hipSuccess) { prio = side_prio; (void)hipGetLastError(); }
     }
     if (hipStreamCreateWithPriority(&p->lanes[l], hipStreamNonBlocking, prio) != hipSuccess) { evk_set_error("replay_build: hipStreamCreate failed"); delete p; return nullptr; }
+    p->lane_prio.resize(p->lanes.size(), 0);
+    p->lane_prio[l] = prio;
   }
   p->begin_event = new_event(p);
   for (size_t l = 1; l < p->lanes.size(); ++l) {
@@ -388,12 +477,23 @@ void* evk_replay_build_streams(void* graph_handle, int32_t max_lanes, evk_stream
   return p;
 }
 
+/* *concurrent = 1 when kernels launched on the two streams overlap, 0 when the runtime serialises them (the streams share a hardware queue);
+ * both streams are synchronised and two ~150 us single-wave kernels run on each.  For callers that drive several streams at once (the serving
+ * loop's searches in flight): pick streams that do not share a queue. */
+int evk_streams_concurrent(evk_stream_t a, evk_stream_t b, int32_t* concurrent) {
+  EVK_REQUIRE(concurrent, "streams_concurrent: null result");
+  const int r = streams_concurrent(reinterpret_cast<hipStream_t>(a), reinterpret_cast<hipStream_t>(b));
+  if (r < 0) { evk_set_error("streams_concurrent: could not time the streams"); return EVK_ELAUNCH; }
+  *concurrent = r;
+  return EVK_OK;
+}
+
 /* nodes / kernels / memcpys / memsets / lanes / cross-lane edges / isolated one-node sub-graphs of a plan */
 int evk_replay_info(void* plan, int64_t* out6) {
   Plan* p = reinterpret_cast<Plan*>(plan);
   EVK_REQUIRE(p && out6, "replay_info: bad args");
   out6[0] = (int64_t)p->nodes.size(); out6[1] = (int64_t)p->n_kernels; out6[2] = (int64_t)p->n_copies; out6[3] = (int64_t)p->n_sets;
-  out6[4] = (int64_t)p->lanes.size(); out6[5] = (int64_t)p->n_cross; out6[6] = 0;
+  out6[4] = (int64_t)p->lanes.size(); out6[5] = (int64_t)p->n_cross; out6[6] = (int64_t)p->n_realiased;
   return EVK_OK;
 }
 
@@ -404,6 +504,15 @@ int evk_replay_run(void* plan, evk_stream_t stream) {
   EVK_REQUIRE(p, "replay_run: null plan");
   hipStream_t s0 = reinterpret_cast<hipStream_t>(stream);
   p->lanes[0] = s0;
+  if (!p->queues_checked && p->lanes.size() > 1) {
+    // first run of a multi-lane plan: no two lanes on one hardware queue (once; the device is drained first so that the check times idle streams)
+    p->queues_checked = true;
+    static const int on = evk_tunable("EVK_REPLAY_SEPARATE_LANES", 1);
+    if (on) {
+      (void)hipDeviceSynchronize();
+      separate_lanes(p, s0);
+    }
+  }
   if (p->lanes.size() > 1) {
     if (hipEventRecord(p->events[p->begin_event], s0) != hipSuccess) { evk_set_error("replay_run: hipEventRecord failed"); return EVK_ELAUNCH; }
     for (size_t l = 1; l < p->lanes.size(); ++l) (void)hipStreamWaitEvent(p->lanes[l], p->events[p->begin_event], 0);
@@ -457,6 +566,7 @@ int evk_replay_destroy(void* plan) {
   if (!p) return EVK_OK;
   for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
   for (size_t l = 1; l < p->lanes.size(); ++l) if (p->lanes[l]) (void)hipStreamDestroy(p->lanes[l]);
+  for (hipStream_t st : p->spare) (void)hipStreamDestroy(st);
   delete p;
   return EVK_OK;
 }

@@ -27,9 +27,17 @@ from . import ops
 # 'replay': capture once, re-issue the recorded launches from C++ (csrc/replay.hip); 'hipgraph': hipGraphLaunch (7-12 us of host
 # time per node on ROCm 7.2: slower than eager Python for the 6k-node training step, kept for comparison)
 MODE = os.environ.get('EVK_STEP_GRAPH_MODE', 'replay')
-# HIP queue priority of the replay lane of each named side stream (ops.side_stream); every other lane keeps its capture stream's priority.
-# 'rm': the relational-memory chain goes first -- in the REPLAYED step only (csrc/replay.hip: evk_replay_lane_priority)
-LANE_PRIORITY = {'rm': int(os.environ.get('EVK_REPLAY_RM_PRIO', '-1'))}
+# HIP queue priority of the replay lane of a named side stream (ops.side_stream) where it should differ from its capture stream's.  None by
+# default: every priority assignment tried either changed nothing or put the step into a 72-110 ms mode (profiles/r05_hw_queues.txt -- the
+# runtime gives each priority class hardware queues of its own, and more than four active queues per process is where that mode begins);
+# EVK_REPLAY_RM_PRIO / EVK_REPLAY_LANE_PRIO reproduce those measurements.
+LANE_PRIORITY = {}
+if os.environ.get('EVK_REPLAY_RM_PRIO', '') not in ('', '0'):
+    LANE_PRIORITY['rm'] = int(os.environ['EVK_REPLAY_RM_PRIO'])
+LANE_MERGE = {}          # side stream name -> 'main' or another side stream name: replayed on that lane (EVK_REPLAY_MERGE="rm:wgrad,text:main")
+for _kv in os.environ.get('EVK_REPLAY_MERGE', '').split(','):
+    if ':' in _kv:
+        LANE_MERGE[_kv.split(':')[0].strip()] = _kv.split(':')[1].strip()
 for _kv in os.environ.get('EVK_REPLAY_LANE_PRIO', '').split(','):          # experiments: "wgrad:1,text:-1" (HIP: -1 high, 0 default, 1 low)
     if ':' in _kv:
         LANE_PRIORITY[_kv.split(':')[0].strip()] = int(_kv.split(':')[1])
@@ -64,6 +72,10 @@ class StepGraph:
     def _replay(self):
         if self.plan is not None:
             H.check(H.lib.evk_replay_run(self.plan, H.stream()), 'replay_run')
+            if self.info is not None and 'checked' not in self.info:          # (the first run separates lanes that share a hardware queue)
+                info = (C.c_int64 * 7)()
+                H.check(H.lib.evk_replay_info(self.plan, info), 'replay_info')
+                self.info.update(lane_streams_replaced=int(info[6]), checked=True)
         else:
             self.graph.replay()
         if self.on_replay is not None:
@@ -115,6 +127,11 @@ class StepGraph:
                     st = ops.existing_side_stream(name)
                     if st is not None:
                         H.check(H.lib.evk_replay_lane_priority(C.c_void_p(st.cuda_stream), prio), 'replay_lane_priority')
+                for name, onto in LANE_MERGE.items():          # experiments: two capture streams on one in-order lane
+                    st = ops.existing_side_stream(name)
+                    dst = origin[0] if onto == 'main' else (ops.existing_side_stream(onto).cuda_stream if ops.existing_side_stream(onto) is not None else None)
+                    if st is not None and dst is not None:
+                        H.check(H.lib.evk_replay_lane_alias(C.c_void_p(st.cuda_stream), C.c_void_p(dst)), 'replay_lane_alias')
                 plan = H.lib.evk_replay_build_streams(C.c_void_p(g.raw_cuda_graph()), 16, C.c_void_p(origin[0]))
             else:                                       # the minimum path cover (rounds 2-4)
                 plan = H.lib.evk_replay_build(C.c_void_p(g.raw_cuda_graph()), 16)
@@ -128,7 +145,7 @@ class StepGraph:
             self.plan = plan
             info = (C.c_int64 * 7)()
             H.check(H.lib.evk_replay_info(self.plan, info), 'replay_info')
-            self.info = dict(zip(('nodes', 'kernels', 'memcpys', 'memsets', 'lanes', 'cross_lane_edges', 'isolated_subgraphs'), list(info)))
+            self.info = dict(zip(('nodes', 'kernels', 'memcpys', 'memsets', 'lanes', 'cross_lane_edges', 'lane_streams_replaced'), list(info)))
         self.graph, self.out = g, out
         if self.make_on_replay is not None:
             self.on_replay = self.make_on_replay()

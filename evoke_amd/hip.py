@@ -162,6 +162,36 @@ def masked_stream(device, reserve):
     return _masked_streams[key]
 
 
+_rejected_streams = []          # streams the hardware-queue check turned down: kept alive so that the runtime's assignment moves on
+
+
+def streams_concurrent(a, b):
+    """True when kernels launched on the two torch streams overlap; False when the HIP runtime serialises them -- it multiplexes streams
+    onto a few hardware queues per priority (GPU_MAX_HW_QUEUES, default 4), and which queue a new stream gets depends on how many streams the
+    process created before (evk_streams_concurrent: two ~150 us single-wave kernels, both streams synchronised first)."""
+    out = C.c_int32(0)
+    check(lib.evk_streams_concurrent(C.c_void_p(a.cuda_stream), C.c_void_p(b.cuda_stream), C.byref(out)), 'streams_concurrent')
+    return bool(out.value)
+
+
+def concurrent_streams(count, priority=0, device=None, against=(), tries=16):
+    """`count` new torch streams of `priority` that are pairwise concurrent with each other and with the streams in `against`: for work that
+    is meant to overlap (the serving loop's searches in flight and its encoder stream).  A candidate that shares a hardware queue with an
+    accepted stream is set aside (alive, see _rejected_streams) and another one is created, at most `tries` times per stream."""
+    chosen = list(against)
+    out = []
+    for _ in range(count):
+        cand = torch.cuda.Stream(device=device, priority=priority)
+        for _t in range(tries):
+            if all(streams_concurrent(c, cand) for c in chosen):
+                break
+            _rejected_streams.append(cand)
+            cand = torch.cuda.Stream(device=device, priority=priority)
+        chosen.append(cand)
+        out.append(cand)
+    return out
+
+
 def ptr(t):
     return t.data_ptr() if t is not None else None
 

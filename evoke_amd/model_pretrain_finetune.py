@@ -168,11 +168,11 @@ class FineTune(_Base):
         """forward(..., mode=mode) over a sequence of batches, as a generator of its return values, with the device kept busy across
         batches.  The decode of a batch is a chain of ~100 x ~56 small dependent kernels: latency bound, most of the GPU idles while it
         runs, and the host can only issue it at the GPU's pace (a launch queue is finite).  So `depth` batches are decoded at the same time,
-        each on its own high-priority HIP stream with its own persistent beam session and its own host thread, which hands the whole token
+        each on its own HIP stream with its own persistent beam session and its own host thread, which hands the whole token
         loop to the launch queue from native code (evk_replay_run_n: the interpreter is not on the per-token path, the GIL is free);
         this thread meanwhile queues the visual extractor / fusion / text encoders of the following batch on a further stream.  Per batch the
         kernels, their order and therefore the results are exactly those of forward() (tests/test_model_gpu.py).  batches: iterable of
-        (images, report_ids, report_masks, patient_ids, inc_ids, inc_masks).  depth: EVK_DECODE_DEPTH or 2.  (The distilgpt2 backend has no
+        (images, report_ids, report_masks, patient_ids, inc_ids, inc_masks).  depth: EVK_DECODE_DEPTH or 3.  (The distilgpt2 backend has no
         stepwise sessions: for it only the encoders run ahead, _generate_encoders_ahead.)"""
         import os
         from collections import deque
@@ -182,7 +182,7 @@ class FineTune(_Base):
             yield from self._generate_encoders_ahead(batches, mode)
             return
         from .decode import beam_search
-        depth = max(1, int(depth if depth is not None else os.environ.get('EVK_DECODE_DEPTH', '2')))
+        depth = max(1, int(depth if depth is not None else os.environ.get('EVK_DECODE_DEPTH', '3')))
         # EVK_DECODE_THREADS=1 (default): one host thread per search in flight issues its token loop (evk_replay_run_n, GIL released);
         # 0: this thread issues the token steps of all searches round-robin
         threaded = os.environ.get('EVK_DECODE_THREADS', '1') != '0'
@@ -203,9 +203,13 @@ class FineTune(_Base):
         # the default is 0 (no mask)
         reserve = int(os.environ.get('EVK_ENC_RESERVE_CUS', '0'))
         enc_s = H.masked_stream(cur.device, reserve) if reserve > 0 else torch.cuda.Stream()
-        # the decode chains are latency bound: their small kernels go first.  (EVK_DECODE_PRIO: comma list of stream priorities)
+        # Every stream at the DEFAULT priority (EVK_DECODE_PRIO: comma list to override).  Rounds 3-4 ran the searches on high-priority streams
+        # ("their small kernels go first"); the HIP runtime gives each priority class hardware queues of its own, and the extra active queues
+        # cost more than the ordering buys: 115.6 k tokens/s with two high-priority searches, 120.1 k with two default ones, 127.5 k with three
+        # (105 k with three high-priority ones in round 3) -- profiles/r05_decode_stream_priorities.txt.
+        # (streams picked so that no two share a hardware queue -- H.concurrent_streams -- measured no difference here: 115.1 vs 116.3 k tokens/s)
         prios = [int(v) for v in os.environ.get('EVK_DECODE_PRIO', '').split(',') if v.strip() != '']
-        dec_s = [torch.cuda.Stream(priority=(prios[i] if i < len(prios) else -1)) for i in range(depth)]
+        dec_s = [torch.cuda.Stream(priority=(prios[i] if i < len(prios) else 0)) for i in range(depth)]
         for st in [enc_s] + dec_s:
             st.wait_stream(cur)
 

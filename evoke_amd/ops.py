@@ -360,9 +360,9 @@ def grad_done(p):
 # side streams: latency-bound branches (the relational-memory recurrence, the indication text encoder) run on their
 # own HIP stream concurrently with the fat ResNet kernels; autograd replays each op's backward on its forward stream.
 # ----------------------------------------------------------------------------------------------------
-# HIP queue priority of each named side stream in the EAGER step (-1 = above the default).  All default: giving the relational-memory stream
-# the higher priority -- which the REPLAYED step profits from (evoke_amd/graph.py: LANE_PRIORITY) -- makes the eager step 60 % slower
-# (48.3 -> 78.2 ms at 384^2, 30.8 -> 65.9 ms at 224^2: profiles/r05_stream_priorities.txt); EVK_RM_STREAM_PRIO reproduces that measurement.
+# HIP queue priority of each named side stream in the eager step (-1 = above the default).  All default: the HIP runtime gives every priority
+# class hardware queues of its own, and a relational-memory stream in the high-priority class makes the eager step 60-110 % slower (48.3 ->
+# 78.2 ms at 384^2, 30.8 -> 65.9 ms at 224^2: profiles/r05_stream_priorities.txt, r05_hw_queues.txt); EVK_RM_STREAM_PRIO reproduces that measurement.
 SIDE_STREAM_PRIORITY = {'rm': int(os.environ.get('EVK_RM_STREAM_PRIO', '0'))}
 _side_streams = {}
 _side_raw = set()            # (device, raw handle) of every side stream
@@ -376,6 +376,7 @@ def side_stream(name, device=None):
     key = (name, dev)
     st = _side_streams.get(key)
     if st is None:
+        # (picking side streams that share no hardware queue -- H.concurrent_streams -- changes nothing for the eager step: 48.20 -> 48.16 ms)
         st = _side_streams[key] = torch.cuda.Stream(device=dev, priority=SIDE_STREAM_PRIORITY.get(name, 0))
         _side_raw.add((dev, st.cuda_stream))
     raw = H._raw_stream(dev)

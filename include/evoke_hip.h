@@ -111,7 +111,7 @@ int evk_device_cu_count(int32_t device, int32_t* cus);
  * is only a recording: evk_replay_build walks its nodes / edges / kernel parameters and evk_replay_run re-issues them with plain
  * hipLaunchKernel calls on a few streams (hipGraphLaunch itself costs 7-12 us of host time per node on ROCm 7.2).  The caller
  * keeps the hipGraph_t alive for the life of the plan (kernel argument blocks are owned by it).
- *   evk_replay_info: out6[0..6] = {nodes, kernels, memcpys, memsets, lanes (streams), cross-lane edges, nodes replayed as isolated
+ *   evk_replay_info: out6[0..6] = {nodes, kernels, memcpys, memsets, lanes (streams), cross-lane edges, lane streams replaced by the hardware-queue check (was: nodes replayed as isolated
  *   one-node graphs (copy flavours whose parameters the public query does not return faithfully)}.                        */
 void* evk_replay_build(void* hip_graph, int32_t max_lanes);
 /* Lanes that ARE the capture's streams: evk_capture_probe(1) before the capture begins makes every launch of the library note which stream
@@ -119,9 +119,11 @@ void* evk_replay_build(void* hip_graph, int32_t max_lanes);
  * gives every other capture stream a lane of its own; evk_capture_probe(0) afterwards.  Without notes it falls back to evk_replay_build's
  * minimum path cover.  (trainer_v0401.py:426-435 is the step; its eager PyTorch streams have no counterpart to mirror.) */
 int evk_capture_probe(int32_t on);
+int evk_replay_lane_alias(evk_stream_t captured, evk_stream_t onto);     /* replay `captured`'s nodes on the lane of `onto` (NULL: undo) */
 int evk_replay_lane_priority(evk_stream_t captured, int32_t prio);   /* lane of that capture stream: HIP queue priority (-1 above default) */
 void* evk_replay_build_streams(void* hip_graph, int32_t max_lanes, evk_stream_t origin);
 int evk_replay_info(void* plan, int64_t* out6);
+int evk_streams_concurrent(evk_stream_t a, evk_stream_t b, int32_t* concurrent);   /* do kernels on the two streams overlap (1) or share a hardware queue (0)? */
 int evk_replay_run(void* plan, evk_stream_t stream);
 int evk_replay_run_n(void* plan, evk_stream_t stream, int32_t n);   /* n replays back to back (the ~100 token steps of a beam search,
                                                                        modules/beam_search.py / att_model.py:139-192's loop, from one call) */

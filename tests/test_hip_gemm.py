@@ -321,17 +321,35 @@ def test_gemm_rejects_bad_args(H):
         H.gemm_launch(d)
 
 
-@pytest.mark.skipif(os.environ.get('EVK_TILE256') is not None, reason='already running with a forced tile choice')
-def test_kernel_suite_with_the_256x256_tile_forced():
-    """gemm.hip picks the 256 x 256 / 16-wave tile only for plain NT products of >= 1024 big tiles; EVK_TILE256=1 forces it
-    for every plain NT product with M, N >= 256 (batched attention scores, linears with bias / activation / residual
-    epilogues, ragged edges), so the kernel tests run once more that way in a child interpreter (the choice is read once)."""
+# Every kernel ROUTE the library can be switched to (csrc: evk_tunable, honoured only under EVK_EXPERIMENTAL=1) besides the measured default: the
+# routes that were the default in earlier rounds and stay as fallbacks for geometries the specialised kernels refuse.  One child interpreter
+# (the switches are read once per process) runs the kernel suites and one model-level parity case with ALL of them forced at once.
+FALLBACK_ROUTES = dict(
+    EVK_EXPERIMENTAL='1',
+    EVK_TILE256='1',                 # 256 x 256 / 16-wave tile for every plain NT product with M, N >= 256 (default: >= 1024 big tiles only)
+    EVK_GEMM_TN='0',                 # weight gradients on the tile kernel instead of csrc/gemm_tn.hip
+    EVK_GEMM_STRIP='0',              # contracting 1x1 convolutions on the tile kernel instead of the strip GEMM
+    EVK_CONV1X1_WS='0',              # expanding 1x1 convolutions on the tile kernel instead of the weight-stationary kernel
+    EVK_CONV3X3_HALO='0', EVK_CONV3X3_WGRAD_HALO='0', EVK_STEM_HALO='0',          # implicit-GEMM 3x3 / stem instead of the halo-tile kernels
+    EVK_S2_PARITY='0', EVK_DGRAD_FLIP='0', EVK_DOWN_COMPACT='0',                  # gathering data gradients instead of parity classes / flipped weights / compact shortcut
+    EVK_BN_GATE_STATS='0', EVK_BN_XSTATS='0', EVK_BN_FOLD='0',                    # batch-norm backward sums by their own reductions
+    EVK_BEAM_STEP_FAST='0', EVK_DECODE_RB_SPLIT='0')                              # batched-walk beam step, one workgroup per row block
+
+
+@pytest.mark.skipif(os.environ.get('EVK_TILE256') is not None, reason='already running on the fallback routes')
+def test_kernel_suite_on_the_fallback_routes():
+    """gemm.hip picks the 256 x 256 / 16-wave tile only for plain NT products of >= 1024 big tiles, the convolutions go to halo / strip /
+    weight-stationary kernels, batch-norm backward sums ride on data-gradient epilogues ...: FALLBACK_ROUTES forces the other side of every such
+    choice (batched attention scores, linears with bias / activation / residual epilogues and ragged edges on the big tile; every convolution
+    on the implicit-GEMM tile path; the trunk runner without its fused statistics), and the kernel tests plus one FineTune parity case run once
+    more that way in a child interpreter.  Left out: the tests that assert a specialised kernel TOOK a launch."""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(here, 'test_hip_gemm.py'), os.path.join(here, 'test_hip_ops.py'),
-                        '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider'], env=dict(os.environ, EVK_TILE256='1'),
-                       capture_output=True, text=True, timeout=900, cwd=os.path.dirname(here))
+                        os.path.join(here, 'test_model_gpu.py'), '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider', '-k',
+                        '(test_hip_gemm or test_hip_ops or (finetune_matches_reference and ft224_inc)) and not strip_gemm_is_what and not fallback_routes'],
+                       env=dict(os.environ, **FALLBACK_ROUTES), capture_output=True, text=True, timeout=900, cwd=os.path.dirname(here))
     tail = '\n'.join((r.stdout + r.stderr).splitlines()[-20:])
     print(tail)
     assert r.returncode == 0, tail
