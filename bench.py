@@ -138,7 +138,7 @@ def decode_record(model, a, rank, world, dev, with_cpu):
     n = max(2, min(a.steps, 8))
     step_ms, dt, err = [], float('inf'), None
     pipelined = os.environ.get('EVK_DECODE_PIPELINE', '1') != '0'
-    depth = max(1, int(os.environ.get('EVK_DECODE_DEPTH', '3'))) if pipelined else 1
+    depth = max(1, int(os.environ.get('EVK_DECODE_DEPTH', '4'))) if pipelined else 1
     try:
         for _ in range(max(1, min(a.warmup, 2))):
             step()
@@ -196,7 +196,7 @@ def decode_record(model, a, rank, world, dev, with_cpu):
                                % (a.res, beam, B, a.views, L, V), 'parallelism': 'replicas x%d' % world,
                    'mean_generated_len': mean_len, 'hip_graph_step': DEC.stats.get('graph'),
                    'pipelined_encoders': pipelined, 'searches_in_flight': depth,
-                   'host_thread_per_search': pipelined and os.environ.get('EVK_DECODE_THREADS', '1') != '0',
+                   'host_thread_per_search': pipelined and os.environ.get('EVK_DECODE_THREADS', '0') != '0',
                    'inference_trunk_mode': int(__import__('evoke_amd.trunk', fromlist=['FOLD_BN']).FOLD_BN[0]),
                    'relational_memory': 'f32 (default)' if DEC._RM_F32[0] else '16-bit (EVK_DECODE_RM_F32=0)',
                    'fused_beam_bookkeeping': DEC.stats.get('fused_bookkeeping'), 'launches_per_token_step': n_launch},
@@ -438,11 +438,11 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    # The step's own (critical-path) stream gets the higher HIP queue priority; the side streams (weight gradients, relational
-    # memory, text encoder, collectives) keep the default one and fill the CUs the main stream leaves idle.
-    # (the replayed step runs every lane, its own included, at the default priority: a fifth hardware queue -- the high-priority class has its
-    # own -- costs it 3-8 ms, profiles/r05_hw_queues.txt)
-    main_stream = torch.cuda.Stream(device=dev, priority=-1) if os.environ.get('EVK_MAIN_PRIO', '0' if use_graph else '1') == '1' else torch.cuda.current_stream()
+    # Every stream of the step at the DEFAULT HIP priority.  (Rounds 2-4 gave the step's own stream the higher priority: +-0.2 ms for the eager
+    # step on this round's boxes -- 48.0 vs 47.8 ms -- and 3-8 ms SLOWER for the replayed one.  The runtime gives each priority class hardware
+    # queues of its own, and a fifth active queue is where the step's slow mode begins (profiles/r05_hw_queues.txt); with N > 1 the RCCL
+    # stream is one more active queue, so the safe configuration keeps everything in one class.  EVK_MAIN_PRIO=1 restores the old behaviour.)
+    main_stream = torch.cuda.Stream(device=dev, priority=-1) if os.environ.get('EVK_MAIN_PRIO', '0') == '1' else torch.cuda.current_stream()
     main_stream.wait_stream(torch.cuda.current_stream())
     torch.cuda.set_stream(main_stream)
     n_warm = max(a.warmup, 3) if use_graph else a.warmup          # capture happens on the 3rd call: keep it out of the timed steps

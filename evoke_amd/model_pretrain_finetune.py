@@ -172,7 +172,7 @@ class FineTune(_Base):
         loop to the launch queue from native code (evk_replay_run_n: the interpreter is not on the per-token path, the GIL is free);
         this thread meanwhile queues the visual extractor / fusion / text encoders of the following batch on a further stream.  Per batch the
         kernels, their order and therefore the results are exactly those of forward() (tests/test_model_gpu.py).  batches: iterable of
-        (images, report_ids, report_masks, patient_ids, inc_ids, inc_masks).  depth: EVK_DECODE_DEPTH or 3.  (The distilgpt2 backend has no
+        (images, report_ids, report_masks, patient_ids, inc_ids, inc_masks).  depth: EVK_DECODE_DEPTH or 4.  (The distilgpt2 backend has no
         stepwise sessions: for it only the encoders run ahead, _generate_encoders_ahead.)"""
         import os
         from collections import deque
@@ -182,10 +182,11 @@ class FineTune(_Base):
             yield from self._generate_encoders_ahead(batches, mode)
             return
         from .decode import beam_search
-        depth = max(1, int(depth if depth is not None else os.environ.get('EVK_DECODE_DEPTH', '3')))
-        # EVK_DECODE_THREADS=1 (default): one host thread per search in flight issues its token loop (evk_replay_run_n, GIL released);
-        # 0: this thread issues the token steps of all searches round-robin
-        threaded = os.environ.get('EVK_DECODE_THREADS', '1') != '0'
+        depth = max(1, int(depth if depth is not None else os.environ.get('EVK_DECODE_DEPTH', '4')))
+        # EVK_DECODE_THREADS=0 (default since round 5): this thread issues the token steps of all searches round-robin; 1: one host thread per
+        # search in flight issues its token loop (evk_replay_run_n, GIL released).  With every stream at the default priority and four searches
+        # in flight the single issuing thread measures 137-138 k tokens/s, the threads 132-135 k (profiles/r05_decode_stream_priorities.txt)
+        threaded = os.environ.get('EVK_DECODE_THREADS', '0') != '0'
         burst = max(1, int(os.environ.get('EVK_DECODE_BURST', '8')))          # token steps per native call ...
         ahead = max(1, int(os.environ.get('EVK_DECODE_AHEAD', '2')))          # ... and bursts a search may be ahead of the GPU
         pool = None

@@ -342,13 +342,15 @@ def test_kernel_suite_on_the_fallback_routes():
     weight-stationary kernels, batch-norm backward sums ride on data-gradient epilogues ...: FALLBACK_ROUTES forces the other side of every such
     choice (batched attention scores, linears with bias / activation / residual epilogues and ragged edges on the big tile; every convolution
     on the implicit-GEMM tile path; the trunk runner without its fused statistics), and the kernel tests plus one FineTune parity case run once
-    more that way in a child interpreter.  Left out: the tests that assert a specialised kernel TOOK a launch."""
+    more that way in a child interpreter.  Left out: the tests that assert a specialised kernel TOOK a launch (the strip-GEMM routing test, the
+    halo weight-gradient and stride-2 parity tests, which end with `routed entry point == specialised kernel, bit for bit`)."""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(here, 'test_hip_gemm.py'), os.path.join(here, 'test_hip_ops.py'),
                         os.path.join(here, 'test_model_gpu.py'), '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider', '-k',
-                        '(test_hip_gemm or test_hip_ops or (finetune_matches_reference and ft224_inc)) and not strip_gemm_is_what and not fallback_routes'],
+                        '(test_hip_gemm or test_hip_ops or (finetune_matches_reference and ft224_inc)) and not strip_gemm_is_what and not fallback_routes '
+                        'and not halo_conv3x3_weight_gradient and not stride2_conv3x3_data_gradient_by_output_parity'],
                        env=dict(os.environ, **FALLBACK_ROUTES), capture_output=True, text=True, timeout=900, cwd=os.path.dirname(here))
     tail = '\n'.join((r.stdout + r.stderr).splitlines()[-20:])
     print(tail)

@@ -924,8 +924,8 @@ def test_pipelined_generation_equals_per_batch_inference():
 
 
 @pytest.mark.parametrize('env', [
-    {'EVK_DECODE_THREADS': '0'},                                                   # the calling thread issues every token step round-robin
-    {'EVK_DECODE_THREADS': '1', 'EVK_DECODE_BURST': '1', 'EVK_DECODE_AHEAD': '1'},     # host threads, one step per native call
+    {'EVK_DECODE_THREADS': '0'},                                                   # the default: four searches in flight, the calling thread issues every token step round-robin
+    {'EVK_DECODE_THREADS': '1', 'EVK_DECODE_DEPTH': '2', 'EVK_DECODE_BURST': '1', 'EVK_DECODE_AHEAD': '1'},     # host threads, two searches, one step per native call
     {'EVK_DECODE_THREADS': '1', 'EVK_DECODE_DEPTH': '3', 'EVK_DECODE_BURST': '5'},     # three searches in flight, bursts that do not divide the loop
     {'EVK_DECODE_THREADS': '1', 'EVK_ENC_RESERVE_CUS': '8'},                       # encoders on a CU-masked stream (hip.masked_stream)
     {'EVK_DECODE_THREADS': '1', 'EVK_FOLD_BN': '1'},                               # batch norms in every convolution epilogue that has one
@@ -934,7 +934,7 @@ def test_pipelined_generation_equals_per_batch_inference():
 ], ids=['one_thread', 'threads_burst1', 'depth3_burst5', 'cu_mask', 'fused_bn', 'unfused_runner', 'training_runner'])
 def test_pipelined_generation_modes_return_the_same_ids(env, monkeypatch):
     """Every way generate_pipelined can drive the searches (host threads issuing native bursts of token steps / one thread round-robin,
-    2 or 3 searches in flight, encoders on a CU-masked stream, every setting of the inference trunk) returns the ids of
+    2, 3 or 4 searches in flight, encoders on a CU-masked stream, every setting of the inference trunk) returns the ids of
     forward(mode='inference') over the training runner, five batches of three different structures, in batch order."""
     from evoke_amd import trunk as T
     from evoke_amd.model_pretrain_finetune import FineTune
