@@ -427,7 +427,8 @@ def main():
     # relational-memory stream makes that step 60 % slower (78 ms), so it is a property of the replay lanes only.
     # default: replayed on one rank (measured <= the eager step at every workload, profiles/r05_replay_sweep.txt + r05_stream_priorities.txt);
     # eager whenever a process group exists -- the bucketed RCCL calls are issued from inside the backward and are not part of a capture
-    use_graph = a.graph if a.graph >= 0 else (1 if (world == 1 and not D.forced()) else 0)
+    # (the capture needs three untimed calls: with fewer warm-up steps than that the default stays eager, so that exactly W warm-up steps run)
+    use_graph = a.graph if a.graph >= 0 else (1 if (world == 1 and not D.forced() and a.warmup >= 3) else 0)
     step = step_eager
     if use_graph:
         from evoke_amd.graph import StepGraph

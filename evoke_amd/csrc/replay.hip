@@ -24,7 +24,6 @@ bool g_evk_capture_probe = false;
 static std::mutex g_probe_mu;
 static std::unordered_map<hipGraphNode_t, hipStream_t> g_probe_map;
 static std::unordered_map<hipStream_t, int> g_lane_prio;          // capture stream -> priority of the lane that replays it (evk_replay_lane_priority)
-static std::unordered_map<hipStream_t, hipStream_t> g_lane_alias; // capture stream -> the capture stream whose lane replays it too (evk_replay_lane_alias)
 
 void evk_capture_note(hipStream_t s) {
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
@@ -165,16 +164,6 @@ void* evk_replay_build_streams(void* graph_handle, int32_t max_lanes, evk_stream
 int evk_replay_lane_priority(evk_stream_t captured, int32_t prio) {
   std::lock_guard<std::mutex> lk(g_probe_mu);
   g_lane_prio[reinterpret_cast<hipStream_t>(captured)] = prio;
-  return EVK_OK;
-}
-
-/* The nodes of capture stream `captured` are replayed on the lane of capture stream `onto` (NULL: forget the alias): two capture streams
- * share one in-order lane, in capture order.  Always valid -- every dependency points to a node issued earlier -- and it removes the
- * concurrency between the two chains; applies to plans built afterwards. */
-int evk_replay_lane_alias(evk_stream_t captured, evk_stream_t onto) {
-  std::lock_guard<std::mutex> lk(g_probe_mu);
-  if (onto) g_lane_alias[reinterpret_cast<hipStream_t>(captured)] = reinterpret_cast<hipStream_t>(onto);
-  else g_lane_alias.erase(reinterpret_cast<hipStream_t>(captured));
   return EVK_OK;
 }
 
@@ -348,9 +337,7 @@ void* evk_replay_build_streams(void* graph_handle, int32_t max_lanes, evk_stream
     for (size_t k = 0; k < n && !g_probe_map.empty(); ++k) {
       auto it = g_probe_map.find(nodes[order[k]]);
       if (it != g_probe_map.end()) {
-        hipStream_t st = it->second;
-        for (int hop = 0; hop < 4; ++hop) { auto al = g_lane_alias.find(st); if (al == g_lane_alias.end()) break; st = al->second; }
-        auto ins = lane_id.emplace(st, (int)lane_id.size());
+        auto ins = lane_id.emplace(it->second, (int)lane_id.size());
         forced[k] = ins.first->second;
         ++n_noted;
       } else {
@@ -413,30 +400,6 @@ void* evk_replay_build_streams(void* graph_handle, int32_t max_lanes, evk_stream
       for (size_t l = 1; l < bn.size(); ++l) if (bn[l] > bn[crit]) crit = (int)l;
       if (crit != 0 && bn[crit] > 0)
         for (RNode& r : p->nodes) r.lane = r.lane == crit ? 0 : (r.lane == 0 ? crit : r.lane);
-    }
-  }
-  // Pacing (EVK_REPLAY_PACE = W >= 0, with stream lanes only): the eager step's host issues the lanes interleaved in program order and is
-  // never far ahead of the GPU, so a side lane's kernel rarely starts long before the main-lane kernels issued in front of it have run; the
-  // replayer queues every lane within ~10 ms, and the side lanes then run as far ahead as their dependencies allow and share the CUs with
-  // the critical path from the first microsecond.  With pacing, every P-th kernel of a side lane (EVK_REPLAY_PACE_EVERY, default 8) also
-  // waits for the main-lane kernel that was issued W main-lane kernels before it: all added edges point forward in issue order (no cycle).
-  const int pace_w = n_streams ? evk_tunable("EVK_REPLAY_PACE", -1) : -1;
-  if (pace_w >= 0) {
-    const int every = std::max(1, evk_tunable("EVK_REPLAY_PACE_EVERY", 8));
-    std::vector<int> main_idx;
-    std::vector<int> since(lane_tail.size(), 0);
-    for (size_t k = 0; k < n; ++k) {
-      RNode& r = p->nodes[k];
-      if (r.type != 0) continue;
-      if (r.lane == 0) { main_idx.push_back((int)k); continue; }
-      if (++since[r.lane] < every) continue;
-      since[r.lane] = 0;
-      const int j = (int)main_idx.size() - 1 - pace_w;
-      if (j < 0) continue;
-      RNode& rq = p->nodes[main_idx[j]];
-      if (rq.record < 0) { rq.record = new_event(p); if (rq.record < 0) { evk_set_error("replay_build: hipEventCreate failed"); delete p; return nullptr; } }
-      r.waits.push_back(rq.record);
-      ++p->n_cross;
     }
   }
   if (replay_debug()) {

@@ -34,10 +34,6 @@ MODE = os.environ.get('EVK_STEP_GRAPH_MODE', 'replay')
 LANE_PRIORITY = {}
 if os.environ.get('EVK_REPLAY_RM_PRIO', '') not in ('', '0'):
     LANE_PRIORITY['rm'] = int(os.environ['EVK_REPLAY_RM_PRIO'])
-LANE_MERGE = {}          # side stream name -> 'main' or another side stream name: replayed on that lane (EVK_REPLAY_MERGE="rm:wgrad,text:main")
-for _kv in os.environ.get('EVK_REPLAY_MERGE', '').split(','):
-    if ':' in _kv:
-        LANE_MERGE[_kv.split(':')[0].strip()] = _kv.split(':')[1].strip()
 for _kv in os.environ.get('EVK_REPLAY_LANE_PRIO', '').split(','):          # experiments: "wgrad:1,text:-1" (HIP: -1 high, 0 default, 1 low)
     if ':' in _kv:
         LANE_PRIORITY[_kv.split(':')[0].strip()] = int(_kv.split(':')[1])
@@ -127,11 +123,6 @@ class StepGraph:
                     st = ops.existing_side_stream(name)
                     if st is not None:
                         H.check(H.lib.evk_replay_lane_priority(C.c_void_p(st.cuda_stream), prio), 'replay_lane_priority')
-                for name, onto in LANE_MERGE.items():          # experiments: two capture streams on one in-order lane
-                    st = ops.existing_side_stream(name)
-                    dst = origin[0] if onto == 'main' else (ops.existing_side_stream(onto).cuda_stream if ops.existing_side_stream(onto) is not None else None)
-                    if st is not None and dst is not None:
-                        H.check(H.lib.evk_replay_lane_alias(C.c_void_p(st.cuda_stream), C.c_void_p(dst)), 'replay_lane_alias')
                 plan = H.lib.evk_replay_build_streams(C.c_void_p(g.raw_cuda_graph()), 16, C.c_void_p(origin[0]))
             else:                                       # the minimum path cover (rounds 2-4)
                 plan = H.lib.evk_replay_build(C.c_void_p(g.raw_cuda_graph()), 16)

@@ -119,7 +119,6 @@ void* evk_replay_build(void* hip_graph, int32_t max_lanes);
  * gives every other capture stream a lane of its own; evk_capture_probe(0) afterwards.  Without notes it falls back to evk_replay_build's
  * minimum path cover.  (trainer_v0401.py:426-435 is the step; its eager PyTorch streams have no counterpart to mirror.) */
 int evk_capture_probe(int32_t on);
-int evk_replay_lane_alias(evk_stream_t captured, evk_stream_t onto);     /* replay `captured`'s nodes on the lane of `onto` (NULL: undo) */
 int evk_replay_lane_priority(evk_stream_t captured, int32_t prio);   /* lane of that capture stream: HIP queue priority (-1 above default) */
 void* evk_replay_build_streams(void* hip_graph, int32_t max_lanes, evk_stream_t origin);
 int evk_replay_info(void* plan, int64_t* out6);

@@ -13,7 +13,7 @@ run() {   # name, env...
 }
 python3 bench.py --workload $WL --res $RES --steps 12 --warmup 4 --no-cpu-baseline --no-decode --no-prof --graph 0 > $O/eager.json 2> $O/eager.err
 G="--graph 1"
-for v in "streams:EVK_X=1" "cover:EVK_REPLAY_LANES=cover" "streams_eqprio:EVK_MAIN_PRIO=0" "pace0:EVK_EXPERIMENTAL=1 EVK_REPLAY_PACE=0" "pace4:EVK_EXPERIMENTAL=1 EVK_REPLAY_PACE=4" "pace16:EVK_EXPERIMENTAL=1 EVK_REPLAY_PACE=16" "pace4_e2:EVK_EXPERIMENTAL=1 EVK_REPLAY_PACE=4 EVK_REPLAY_PACE_EVERY=2" "pace32_e4:EVK_EXPERIMENTAL=1 EVK_REPLAY_PACE=32 EVK_REPLAY_PACE_EVERY=4"; do
+for v in "streams:EVK_X=1" "cover:EVK_REPLAY_LANES=cover" "streams_eqprio:EVK_MAIN_PRIO=0"; do
   name=${v%%:*}; envs=${v#*:}
   env $envs python3 bench.py --workload $WL --res $RES --steps 12 --warmup 4 --no-cpu-baseline --no-decode --no-prof --graph 1 > $O/$name.json 2> $O/$name.err || { echo "FAILED $name"; tail -5 $O/$name.err; }
 done
