@@ -135,7 +135,7 @@ def decode_record(model, a, rank, world, dev, with_cpu):
     # Replicas: no rank waits for another inside the measurement.  A rank that fails reports an infinite time, and the ONE collective
     # (max over ranks) sits outside the guarded region so that every rank reaches it whatever happened -- a barrier inside would hang
     # the whole job on a single rank's exception.
-    n = max(2, min(a.steps, 8))
+    n = max(2, min(a.steps, 16))          # batches in the timed region (the pipeline fills during the first and drains during the last)
     step_ms, dt, err = [], float('inf'), None
     pipelined = os.environ.get('EVK_DECODE_PIPELINE', '1') != '0'
     depth = max(1, int(os.environ.get('EVK_DECODE_DEPTH', '4'))) if pipelined else 1
