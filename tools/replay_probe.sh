@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 for e in "$@"; do export "$e"; done
 python3 $R/bench.py --steps 10 --warmup 4 --no-cpu-baseline --no-decode --no-prof --graph 1 > $O/bench_graph.json 2> $O/bench_graph.err && \
 python3 $R/bench.py --steps 10 --warmup 4 --no-cpu-baseline --no-decode --no-prof --graph 0 > $O/bench_eager.json 2> $O/bench_eager.err && \
-EVK_REPLAY_DEBUG=1 rocprofv3 --kernel-trace --output-format csv -d $O/g -o g -- python3 $R/bench.py --steps 4 --warmup 4 --no-cpu-baseline --no-decode --no-prof --graph 1 > $O/g.log 2>&1 && \
+EVK_EXPERIMENTAL=1 EVK_REPLAY_DEBUG=1 rocprofv3 --kernel-trace --output-format csv -d $O/g -o g -- python3 $R/bench.py --steps 4 --warmup 4 --no-cpu-baseline --no-decode --no-prof --graph 1 > $O/g.log 2>&1 && \
 python3 $R/tools/step_timeline.py $O/g/g_kernel_trace.csv > $O/timeline_graph.txt 2>&1
 grep "\[replay\] lane" $O/g.log > $O/lanes.txt
 python3 - <<PY
