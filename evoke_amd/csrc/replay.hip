@@ -151,6 +151,7 @@ extern "C" {
 int evk_capture_probe(int32_t on) {
   std::lock_guard<std::mutex> lk(g_probe_mu);
   if (on) g_probe_map.clear();
+  else g_lane_prio.clear();          // (lane priorities are set between the capture and the build: they belong to that one plan)
   g_evk_capture_probe = on != 0;
   return EVK_OK;
 }

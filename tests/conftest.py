@@ -64,3 +64,23 @@ def pytest_collection_finish(session):
     if ('test_bf16_storage_build_passes_the_gpu_suite' in names and len(names) > 40          # the whole GPU suite, not a hand-picked test
             and os.environ.get('EVK_STORE', 'f16').lower() != 'bf16' and os.environ.get('EVK_BF16_CHILD_INLINE') != '1'):
         start_bf16_child()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """A session that ends before the bf16 test has joined its child (-x after an earlier failure, a keyboard interrupt) must not leave the
+    child running on the GPU."""
+    proc = BF16_CHILD.get('proc')
+    if proc is not None and proc.poll() is None:
+        proc.kill()
+        try:
+            proc.wait(timeout=30)
+        except Exception:          # noqa: BLE001
+            pass
+    log = BF16_CHILD.get('log')
+    if log is not None:
+        try:
+            log.close()
+            os.unlink(log.name)
+        except OSError:
+            pass
+    BF16_CHILD.clear()

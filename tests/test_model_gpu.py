@@ -894,6 +894,8 @@ def test_bf16_storage_build_passes_the_gpu_suite():
     log.seek(0)
     tail = '\n'.join(log.read().splitlines()[-30:])
     print(tail)
+    log.close()
+    os.unlink(log.name)
     CT.BF16_CHILD.clear()
     assert rc == 0, tail
 
