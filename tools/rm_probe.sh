@@ -4,7 +4,6 @@ O=$R/gpurun_out/${1:-r5rmp}
 mkdir -p $O
 cd $R
 python3 tools/rm_probe.py 32 100 5 2>&1 | tail -2
-EVK_EXPERIMENTAL=1 EVK_RM_F32_DIRECT=0 python3 tools/rm_probe.py 32 100 5 2>&1 | tail -1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d $O/t -o t -- python3 $R/tools/rm_probe.py 32 100 3 > $O/t.log 2>&1
 python3 - <<PY
