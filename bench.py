@@ -447,8 +447,25 @@ def main():
     main_stream.wait_stream(torch.cuda.current_stream())
     torch.cuda.set_stream(main_stream)
     n_warm = max(a.warmup, 3) if use_graph else a.warmup          # capture happens on the 3rd call: keep it out of the timed steps
+    # Guard of the replayed default (untimed, inside the warm-up): the replayed step has a slow mode when the runtime's hardware queues are
+    # laid out badly (72-111 ms instead of 47, profiles/r05_hw_queues.txt).  The shipped configuration has not shown it in any run, but a
+    # benchmark must not depend on that: each warm-up step is timed on its own (a device synchronisation on both sides), and if the
+    # replayed steps (call 4 onwards) take more than 1.25 x the eager ones (calls 1-2) the timed region runs the eager step instead.
+    graph_guard = None
+    warm_ms = []
     for _ in range(n_warm):
+        if use_graph:
+            torch.cuda.synchronize()
+            tw = time.perf_counter()
         step()
+        if use_graph:
+            torch.cuda.synchronize()
+            warm_ms.append(1e3 * (time.perf_counter() - tw))
+    if use_graph and len(warm_ms) >= 4 and getattr(step, 'graph', None) is not None:
+        eager_ms, replay_ms = min(warm_ms[:2]), min(warm_ms[3:])
+        graph_guard = {'eager_warmup_step_ms': eager_ms, 'replayed_warmup_step_ms': replay_ms, 'kept_replay': bool(replay_ms <= 1.25 * eager_ms)}
+        if not graph_guard['kept_replay']:
+            step, use_graph = step_eager, 0
     barrier()
     skipped0 = ops.overflow_steps(dev)
     red.timing = bool(red.active)          # events around the collectives (a process group exists: N > 1, or the EVK_FORCE_DIST=1 rehearsal)
@@ -530,7 +547,7 @@ def main():
                    'overflow_skipped_steps': skipped, 'loss_scale': ops.loss_scale_value(dev),
                    'batches': 'one synthetic batch per rank, fed every step',
                    'host_launch_ms_per_step': host_issue_ms, 'host_loop_ms_per_step': 1e3 * host_dt / a.steps,
-                   'step_graph': bool(use_graph and getattr(step, 'graph', None) is not None),
+                   'step_graph': bool(use_graph and getattr(step, 'graph', None) is not None), 'step_graph_guard': graph_guard,
                    'step_replay_plan': getattr(step, 'info', None)},
     }
     if fam:

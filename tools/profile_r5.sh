@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/${1:-r5prof}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o st -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-decode --no-prof > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o st -- python3 $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-decode --no-prof > $O/stats.log 2>&1
 python3 $R/tools/step_timeline.py $O/stats/st_kernel_trace.csv > $O/timeline.txt 2>&1
 EVK_DECODE_DEPTH=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/dstats -o ds -- python3 $R/bench.py --workload decode --steps 2 --warmup 1 --no-cpu-baseline > $O/dstats.log 2>&1
 if [ "$2" = "all" ]; then
