@@ -753,7 +753,9 @@ int evk_rm_forward_f32(const float* x32, const float* Wx32, const float* bx, con
   if (int e = evk_cast(m0, EVK_BF16, w.m, EVK_BF16, RD, stream)) return e;
   if (int e = evk_act_fwd(w.m, w.tm, RD, EVK_ACT_TANH, stream)) return e;
   const long xrow = (long)L * 2048;                 // sample stride of xp
-  for (int t = 0; t < L; ++t) {
+  // timing probe (EVK_EXPERIMENTAL=1 EVK_PROBE_SKIP_RM_FWD=1: garbage memories): the step without the recurrence's forward chain
+  static const bool probe_skip_fwd = evk_tunable("EVK_PROBE_SKIP_RM_FWD", 0) != 0;
+  for (int t = 0; t < L && !probe_skip_fwd; ++t) {
     const float* xt = xp + (long)t * 2048;
     // 5 launches per token: {q | k | v of the memory, U tanh(m)} as one, slot attention, Wo (+ m), W0, W2 with the gate in its epilogue
     if (int e = rmf32_qkv_gu(mem, t ? tmem : nullptr, Wqkv32, bqkv, qkv, w.qkv + (long)t * R * 1536, U32, bU, gu, (int)R, s)) return e;
@@ -836,6 +838,9 @@ int evk_rm_backward(const void* dout, const void* xk, const void* xv, const void
   Ws w = carve(ws, B, L);
   const long R = w.R, RD = R * D_;
   const bf16_t* carry = nullptr;
+  // timing probe (EVK_EXPERIMENTAL=1 EVK_PROBE_SKIP_RM_BWD=1: wrong gradients): the step without the recurrence's backward chain
+  static const bool probe_skip = evk_tunable("EVK_PROBE_SKIP_RM_BWD", 0) != 0;
+  if (probe_skip) return EVK_OK;
   const bool persistent = rm_use_persistent(L);
   if (persistent) {
     PersistP pp{};

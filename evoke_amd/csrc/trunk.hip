@@ -429,8 +429,10 @@ int evk_trunk_backward(const evk_trunk_cfg* cfg, const evk_trunk_layer* layers, 
   for (size_t i = 1; i < P.pairs.size(); ++i)         // parity-class weights of the stride-2 3x3 convolutions (three small launches)
     if (P.wcls[i] >= 0) TRY(evk_conv3x3s2_class_weights(layers[i].w, c.at(P.wcls[i]), P.pairs[i].g.Co, P.pairs[i].g.Ci, stream));
 
+  // timing probe (EVK_EXPERIMENTAL=1 EVK_PROBE_SKIP_WGRAD=1: wrong gradients): how much of the step's wall time do the trunk's weight gradients cost?
+  static const bool probe_skip_wgrad = evk_tunable("EVK_PROBE_SKIP_WGRAD", 0) != 0;
   auto wgrad = [&](int i, const void* xin) -> int {
-    if (!layers[i].dw) return EVK_OK;
+    if (!layers[i].dw || probe_skip_wgrad) return EVK_OK;
     evk_stream_t s2 = q.fork();
     return evk_conv2d_wgrad(c.at(P.pairs[i].dy), xin, layers[i].dw, &P.pairs[i].g, c.at(P.slab), P.slab_bytes, s2);
   };
