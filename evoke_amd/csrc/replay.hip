@@ -79,8 +79,12 @@ __global__ void replay_spin_kernel(long long ticks) {
 double spin_ms(hipStream_t a, hipStream_t b, long long ticks) {
   (void)hipStreamSynchronize(a);
   if (b) (void)hipStreamSynchronize(b);
-  hipEvent_t e0, e1, e2;
-  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess) return -1.0;
+  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess) {
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    return -1.0;
+  }
   (void)hipEventRecord(e0, a);
   hipLaunchKernelGGL(replay_spin_kernel, dim3(1), dim3(64), 0, a, ticks);
   (void)hipEventRecord(e1, a);
@@ -101,6 +105,7 @@ double spin_ms(hipStream_t a, hipStream_t b, long long ticks) {
 // 1: kernels on a and b overlap, 0: they are serialised (one hardware queue), -1: could not measure
 int streams_concurrent(hipStream_t a, hipStream_t b) {
   if (a == b) return 0;
+  if (!b) std::swap(a, b);          // (spin_ms reads a null second stream as "none": the legacy default stream goes first)
   int dev = 0, khz = 0;
   (void)hipGetDevice(&dev);
   if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
