@@ -380,9 +380,18 @@ def main():
     a.views = a.views if a.views == 'u4' else int(a.views)
 
     from evoke_amd import distributed as D
-    rank, world, local = D.init_distributed()
+    # EVK_DIST_BACKEND=gloo: a REHEARSAL of the N > 1 code path on a box with fewer GPUs than ranks (RCCL refuses two ranks per device): the
+    # ranks share the devices there are (rank r on device r mod count) and gloo carries the collectives.  Its numbers mean nothing; the
+    # point is that bench.py's multi-rank branch (barriers, max-over-ranks timing, reducer, comm statistics, replicated decode) has run.
+    backend = os.environ.get('EVK_DIST_BACKEND') or None
+    if backend == 'gloo':
+        local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
+    rank, world, local = D.init_distributed(backend)
     if world != a.gpus:
         raise SystemExit('WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run --nproc-per-node %d' % (world, a.gpus, a.gpus))
+    if backend == 'gloo':
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
@@ -539,7 +548,7 @@ def main():
         'vs_baseline': None, 'dtype': H.STORE, 'data': 'synthetic',
         'config': {'workload': 'EVOKE-%d %s-view %s train step (fwd+bwd+allreduce+clip+RAdam), %d studies (%d images) per GPU, '
                                'L=%d, Li=%d, V=%d, random-init weights' % (a.res, a.views, kind, a.batch, int(batch['images'].shape[0]), L, Li, V),
-                   'parallelism': 'dp%d' % world, 'rccl_ranks': D.world_size(),
+                   'parallelism': 'dp%d' % world, 'rccl_ranks': D.world_size(), 'backend': (torch.distributed.get_backend() if D.world_size() > 1 or D.forced() else None),
                    'grad_sync': (red.mode + (' (EVK_FORCE_DIST=1: 1-rank process group, every collective issued)' if D.forced() and world == 1 else ''))
                    if red.active else 'none (1 rank, no process group)',
                    'comm': comm, 'loss_last': float(losses[-1].item()),
