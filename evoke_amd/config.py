@@ -4,6 +4,15 @@ released EVOKE configuration: 3-layer R2Gen decoder, d_model 512, relational mem
 bench.py, __graft_entry__.smoke() and the tests start from it; a caller's own dict overrides any key."""
 import os
 
+
+def tunable(name, default):
+    """Environment switches that select a measured ALTERNATIVE to a default of the engine (older decode paths, stream priorities, capture modes:
+    INTEGRATION.md section 4 lists them) count only under EVK_EXPERIMENTAL=1 -- the same rule as csrc's evk_tunable -- so that a stray variable
+    cannot move a production run onto a route the default test pass does not cover.  Product-level switches (EVK_STORE, EVK_GRAD_SYNC,
+    EVK_DECODE_DEPTH, ...) are read directly."""
+    return os.environ.get(name, default) if os.environ.get('EVK_EXPERIMENTAL', '0') == '1' else default
+
+
 ARGS = dict(
     resnet_checkpoint='', text_checkpoint=None, fusion_checkpoint=None, vocab_size=1444, encoder_hidden_size=768,
     encoder_num_hidden_layers=6, output_dim=2048, fusion_num_heads=8, sk_fusion_num_layers=1, max_seq_len=100,

@@ -390,24 +390,6 @@ void* evk_replay_build_streams(void* graph_handle, int32_t max_lanes, evk_stream
     }
     lane_tail[lane] = (int)k;
   }
-  // Lane 0 runs on the CALLER's stream, which the trainer / bench create with the higher HIP queue priority for the step's critical path.
-  // Make lane 0 the chain that carries that path -- the one with the most batch-norm kernels (they only occur in the trunk's forward /
-  // backward chain) -- instead of whichever chain happens to start first.  EVK_REPLAY_CRIT_LANE=1 enables it; it did not help (the step is
-  // 73-81 ms under the replayer with every priority assignment tried, 54 ms eager: DESIGN.md section 5).
-  {
-    if (evk_tunable("EVK_REPLAY_CRIT_LANE", 0) != 0 && lane_tail.size() > 1) {          // measured (bench --graph 1): 81 ms per step with, 75 ms without -- opt-in experiment
-      std::vector<int> bn(lane_tail.size(), 0);
-      for (const RNode& r : p->nodes)
-        if (r.type == 0) {
-          const char* nm = hipKernelNameRefByPtr(r.func, nullptr);
-          if (nm && (strstr(nm, "bn_apply") || strstr(nm, "bn_bwd_apply") || strstr(nm, "bn_stats_finalize"))) ++bn[r.lane];
-        }
-      int crit = 0;
-      for (size_t l = 1; l < bn.size(); ++l) if (bn[l] > bn[crit]) crit = (int)l;
-      if (crit != 0 && bn[crit] > 0)
-        for (RNode& r : p->nodes) r.lane = r.lane == crit ? 0 : (r.lane == 0 ? crit : r.lane);
-    }
-  }
   if (replay_debug()) {
     fprintf(stderr, "[replay] %zu nodes, %zu noted by the capture probe, %zu capture streams%s\n", n, n_noted, n_streams, n_streams ? "" : " (path-cover lanes)");
     std::vector<int> cnt(lane_tail.size(), 0);
@@ -421,10 +403,9 @@ void* evk_replay_build_streams(void* graph_handle, int32_t max_lanes, evk_stream
     }
   }
   p->lanes.assign(lane_tail.size(), nullptr);
-  // side lanes at the default priority (0), like the eager step's side streams; EVK_REPLAY_SIDE_PRIO overrides (1 = lowest on this device)
-  // (stream lanes: every lane runs at the priority of the capture stream it stands for -- the eager step's own assignment, e.g. the latency-bound
-  // relational-memory chain above the chip-filling weight-gradient kernels)
-  const int side_prio = evk_tunable("EVK_REPLAY_SIDE_PRIO", 0);
+  // side lanes: the priority of the capture stream each stands for (the eager step's own assignment: all default), unless
+  // evk_replay_lane_priority names another one for this plan
+  const int side_prio = 0;
   for (size_t l = 1; l < p->lanes.size(); ++l) {
     int prio = side_prio;
     if (l < lane_stream.size() && lane_stream[l]) {

@@ -10,6 +10,7 @@ as state, the per-position conditional-LayerNorm inputs taken from the current m
 """
 import ctypes as C
 import os
+from .config import tunable
 import threading
 import math
 
@@ -19,26 +20,26 @@ from . import hip as H
 from . import ops
 from .ops import BF16, F32
 
-_INDIRECT = [os.environ.get('EVK_DECODE_INDIRECT', '1') != '0']      # beam search re-orders a row table, not the K/V caches
+_INDIRECT = [tunable('EVK_DECODE_INDIRECT', '1') != '0']      # beam search re-orders a row table, not the K/V caches
 _GRAPH_ENABLED = [True]          # capture the per-token launch sequence in a HIP graph (set False to debug eagerly)
-_FUSED_APPEND = [os.environ.get('EVK_DECODE_FUSED_APPEND', '1') != '0']  # K / V cache append + strided q inside the self-attention kernel
+_FUSED_APPEND = [tunable('EVK_DECODE_FUSED_APPEND', '1') != '0']  # K / V cache append + strided q inside the self-attention kernel
 # decoder norms applied in the operand load of the projection that follows (evk_linear_ln): 'off' (default), 'final' = only the unconditional last norm in
 # front of the logits -- measured 0.489 -> 0.499 ms per token: 16 rows x 2 dependent wave reductions per wave cost more than the norm launch --,
 # 'all' = the nine conditional norms too -- measured 0.49 -> 0.64 ms per token: every one of the
 # N/16 workgroups of a projection re-reads its 64 rows of per-hypothesis gamma / beta deltas, 128 KB against a 64 KB activation tile, and a
 # workgroup's loads are bound by one CU's L1 fill rate.  The entry point stays (bit-identical to norm + GEMM, tested).
-_FUSED_LN = [os.environ.get('EVK_DECODE_FUSED_LN', 'off')]
-_SPLIT_CLN = [os.environ.get('EVK_DECODE_SPLIT_CLN', '1') != '0']       # first conditional-norm MLP layer as two launches (see cln_deltas)
-_FUSED_BOOK = [os.environ.get('EVK_DECODE_FUSED_BOOK', '1') != '0']      # beam bookkeeping as one kernel per token (csrc/beam.hip)
+_FUSED_LN = [tunable('EVK_DECODE_FUSED_LN', 'off')]
+_SPLIT_CLN = [tunable('EVK_DECODE_SPLIT_CLN', '1') != '0']       # first conditional-norm MLP layer as two launches (see cln_deltas)
+_FUSED_BOOK = [tunable('EVK_DECODE_FUSED_BOOK', '1') != '0']      # beam bookkeeping as one kernel per token (csrc/beam.hip)
 # relational memory of the decode step in f32 (csrc/rm_f32.hip) -- the DEFAULT since round 4: the engine's log-probabilities stay within 5.3e-3 of
 # the reference's at ALL 100 positions of the config-5 golden (the 16-bit recurrence: 2e-3 at position 10, 0.5 at position 90).  EVK_DECODE_RM_F32=0
 # selects the 16-bit recurrence (evk_rm_decode_step), which drifts at depth and is kept for comparison only.
 _RM_F32 = [os.environ.get('EVK_DECODE_RM_F32', '1') != '0']
 # output projection + residual + the NEXT conditional layer norm, and the whole feed-forward + residual + next norm, as ONE launch each for 16
 # hypotheses per workgroup (csrc/decode_rb.hip: weights streamed fragment-major from L2 into MFMA registers): 11 launches per decoder layer -> 6
-_ROWBLOCK = [os.environ.get('EVK_DECODE_ROWBLOCK', '1') != '0']
-_RM_STEP = [os.environ.get('EVK_DECODE_RM_STEP', '1') != '0']          # relational-memory step as one native call (evk_rm_decode_step)
-_REPLAYER = [os.environ.get('EVK_DECODE_REPLAYER', '1') != '0']      # re-issue the captured step with csrc/replay.hip instead of hipGraphLaunch
+_ROWBLOCK = [tunable('EVK_DECODE_ROWBLOCK', '1') != '0']
+_RM_STEP = [tunable('EVK_DECODE_RM_STEP', '1') != '0']          # relational-memory step as one native call (evk_rm_decode_step)
+_REPLAYER = [tunable('EVK_DECODE_REPLAYER', '1') != '0']      # re-issue the captured step with csrc/replay.hip instead of hipGraphLaunch
 stats = {}                       # facts about the last beam_search call (bench.py reads the per-token step time from here)
 _PLANS = []                      # (plan, graph, event recorded after the last replay): destroyed once the GPU has passed the event
 
@@ -722,7 +723,7 @@ def _session_ok(dec, args, enc):
     model = dec.model
     h = model.decoder.layers[0].self_attn.h
     return (_INDIRECT[0] and _FUSED_BOOK[0] and _FUSED_APPEND[0] and _GRAPH_ENABLED[0] and model.d_model // h == 64 and
-            int(args['max_seq_len']) <= 256 and os.environ.get('EVK_DECODE_SESSION', '1') != '0')
+            int(args['max_seq_len']) <= 256 and tunable('EVK_DECODE_SESSION', '1') != '0')
 
 
 @torch.no_grad()

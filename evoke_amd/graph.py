@@ -17,6 +17,7 @@ as the graph exists -- sized for 288 GB of HBM.
 """
 import ctypes as C
 import os
+from .config import tunable
 
 import numpy as np
 import torch
@@ -26,15 +27,15 @@ from . import ops
 
 # 'replay': capture once, re-issue the recorded launches from C++ (csrc/replay.hip); 'hipgraph': hipGraphLaunch (7-12 us of host
 # time per node on ROCm 7.2: slower than eager Python for the 6k-node training step, kept for comparison)
-MODE = os.environ.get('EVK_STEP_GRAPH_MODE', 'replay')
+MODE = tunable('EVK_STEP_GRAPH_MODE', 'replay')
 # HIP queue priority of the replay lane of a named side stream (ops.side_stream) where it should differ from its capture stream's.  None by
 # default: every priority assignment tried either changed nothing or put the step into a 72-110 ms mode (profiles/r05_hw_queues.txt -- the
 # runtime gives each priority class hardware queues of its own, and more than four active queues per process is where that mode begins);
 # EVK_REPLAY_RM_PRIO / EVK_REPLAY_LANE_PRIO reproduce those measurements.
 LANE_PRIORITY = {}
-if os.environ.get('EVK_REPLAY_RM_PRIO', '') not in ('', '0'):
-    LANE_PRIORITY['rm'] = int(os.environ['EVK_REPLAY_RM_PRIO'])
-for _kv in os.environ.get('EVK_REPLAY_LANE_PRIO', '').split(','):          # experiments: "wgrad:1,text:-1" (HIP: -1 high, 0 default, 1 low)
+if tunable('EVK_REPLAY_RM_PRIO', '') not in ('', '0'):
+    LANE_PRIORITY['rm'] = int(tunable('EVK_REPLAY_RM_PRIO', '0'))
+for _kv in tunable('EVK_REPLAY_LANE_PRIO', '').split(','):          # experiments: "wgrad:1,text:-1" (HIP: -1 high, 0 default, 1 low)
     if ':' in _kv:
         LANE_PRIORITY[_kv.split(':')[0].strip()] = int(_kv.split(':')[1])
 
@@ -98,7 +99,7 @@ class StepGraph:
         g = torch.cuda.CUDAGraph(keep_graph=True) if MODE == 'replay' else torch.cuda.CUDAGraph()
         dev = torch.cuda.current_device()
         pool = StepGraph._shared_pool.get(dev)          # step graphs replay one at a time on one stream: one private pool for all
-        if pool is None or os.environ.get('EVK_STEP_GRAPH_SHARED_POOL', '1') == '0':
+        if pool is None or tunable('EVK_STEP_GRAPH_SHARED_POOL', '1') == '0':
             pool = StepGraph._shared_pool[dev] = torch.cuda.graph_pool_handle()
         origin = [None]
         try:
@@ -118,7 +119,7 @@ class StepGraph:
         self.keep = ops.CAPTURE_KEEPALIVE[keep0:]          # pinned staging buffers the graph's upload kernels read: freed with this object
         del ops.CAPTURE_KEEPALIVE[keep0:]
         if MODE == 'replay':
-            if os.environ.get('EVK_REPLAY_LANES', 'streams') == 'streams':
+            if tunable('EVK_REPLAY_LANES', 'streams') == 'streams':
                 for name, prio in LANE_PRIORITY.items():
                     st = ops.existing_side_stream(name)
                     if st is not None:

@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 
 from . import hip as H
+from .config import tunable
 from . import losses, ops
 from .layers import (BertLayer, EncoderDecoder, LayerNormP, ProjectionHead, ScaledDotProductAttention, TextEncoderModel,
                      key_mask, multiview_fusion)
@@ -202,14 +203,14 @@ class FineTune(_Base):
         # duration); measured on the decode workload, though, the encoders lose more than the searches gain -- 117 k tokens/s without a
         # mask, 103 / 91 / 67 k with 8 / 16 / 24 reserved: the pipeline is bound by the sum of the GPU work, not by the chains' latency -- so
         # the default is 0 (no mask)
-        reserve = int(os.environ.get('EVK_ENC_RESERVE_CUS', '0'))
+        reserve = int(tunable('EVK_ENC_RESERVE_CUS', '0'))
         enc_s = H.masked_stream(cur.device, reserve) if reserve > 0 else torch.cuda.Stream()
         # Every stream at the DEFAULT priority (EVK_DECODE_PRIO: comma list to override).  Rounds 3-4 ran the searches on high-priority streams
         # ("their small kernels go first"); the HIP runtime gives each priority class hardware queues of its own, and the extra active queues
         # cost more than the ordering buys: 115.6 k tokens/s with two high-priority searches, 120.1 k with two default ones, 127.5 k with three
         # (105 k with three high-priority ones in round 3) -- profiles/r05_decode_stream_priorities.txt.
         # (streams picked so that no two share a hardware queue -- H.concurrent_streams -- measured no difference here: 115.1 vs 116.3 k tokens/s)
-        prios = [int(v) for v in os.environ.get('EVK_DECODE_PRIO', '').split(',') if v.strip() != '']
+        prios = [int(v) for v in tunable('EVK_DECODE_PRIO', '').split(',') if v.strip() != '']
         dec_s = [torch.cuda.Stream(priority=(prios[i] if i < len(prios) else 0)) for i in range(depth)]
         for st in [enc_s] + dec_s:
             st.wait_stream(cur)

@@ -9,6 +9,7 @@ cached bf16 "shadow" that the GEMMs read; parameter gradients are accumulated in
 """
 import contextlib
 import os
+from .config import tunable
 import ctypes as C
 import math
 
@@ -363,7 +364,7 @@ def grad_done(p):
 # HIP queue priority of each named side stream in the eager step (-1 = above the default).  All default: the HIP runtime gives every priority
 # class hardware queues of its own, and a relational-memory stream in the high-priority class makes the eager step 60-110 % slower (48.3 ->
 # 78.2 ms at 384^2, 30.8 -> 65.9 ms at 224^2: profiles/r05_stream_priorities.txt, r05_hw_queues.txt); EVK_RM_STREAM_PRIO reproduces that measurement.
-SIDE_STREAM_PRIORITY = {'rm': int(os.environ.get('EVK_RM_STREAM_PRIO', '0'))}
+SIDE_STREAM_PRIORITY = {'rm': int(tunable('EVK_RM_STREAM_PRIO', '0'))}
 _side_streams = {}
 _side_raw = set()            # (device, raw handle) of every side stream
 _main_raw = {}              # device -> raw handle of the stream remembered in _main_stream
@@ -492,7 +493,7 @@ def index_tensor(values, device):
     return upload(np.asarray(values, dtype=np.int64).reshape(-1), device)
 
 
-WGRAD_SIDE_STREAM = [os.environ.get('EVK_LINEAR_WGRAD_SIDE', '1') == '1']      # linear-layer dW on the 'wgrad' stream
+WGRAD_SIDE_STREAM = [tunable('EVK_LINEAR_WGRAD_SIDE', '1') == '1']      # linear-layer dW on the 'wgrad' stream
 
 
 _wgrad_join_queued = [False]
@@ -898,7 +899,7 @@ def layernorm(x, gamma, beta, eps=1e-5, mode=0, dgam=None, dbet=None):
 # ----------------------------------------------------------------------------------------------------
 # multi-head attention core on projected q/k/v ([B,T,H*dh] / [B,S,H*dh] bf16, heads interleaved)
 # ----------------------------------------------------------------------------------------------------
-FUSED_ATTENTION = [os.environ.get('EVK_FUSED_ATTENTION', '1') == '1']
+FUSED_ATTENTION = [tunable('EVK_FUSED_ATTENTION', '1') == '1']
 
 
 class _FusedAttention(torch.autograd.Function):
@@ -1017,7 +1018,7 @@ class _Attention(torch.autograd.Function):
         return dQ, dK, dV, None, None, None, None, None, None
 
 
-FUSED_MAX_DH = [int(os.environ.get('EVK_ATTN_FUSED_MAX_DH', '1000000'))]
+FUSED_MAX_DH = [int(tunable('EVK_ATTN_FUSED_MAX_DH', '1000000'))]
 
 
 def attention(q, k, v, heads, mask=None, causal=False, p_drop=0.0, training=False, scale=None):

@@ -929,7 +929,7 @@ def test_pipelined_generation_equals_per_batch_inference():
     {'EVK_DECODE_THREADS': '0'},                                                   # the default: four searches in flight, the calling thread issues every token step round-robin
     {'EVK_DECODE_THREADS': '1', 'EVK_DECODE_DEPTH': '2', 'EVK_DECODE_BURST': '1', 'EVK_DECODE_AHEAD': '1'},     # host threads, two searches, one step per native call
     {'EVK_DECODE_THREADS': '1', 'EVK_DECODE_DEPTH': '3', 'EVK_DECODE_BURST': '5'},     # three searches in flight, bursts that do not divide the loop
-    {'EVK_DECODE_THREADS': '1', 'EVK_ENC_RESERVE_CUS': '8'},                       # encoders on a CU-masked stream (hip.masked_stream)
+    {'EVK_DECODE_THREADS': '1', 'EVK_EXPERIMENTAL': '1', 'EVK_ENC_RESERVE_CUS': '8'},                       # encoders on a CU-masked stream (hip.masked_stream)
     {'EVK_DECODE_THREADS': '1', 'EVK_FOLD_BN': '1'},                               # batch norms in every convolution epilogue that has one
     {'EVK_DECODE_THREADS': '1', 'EVK_FOLD_BN': '0'},                               # inference runner, nothing fused
     {'EVK_DECODE_THREADS': '1', 'EVK_FOLD_BN': '-1'},                              # the training runner in eval mode (before round 4)

@@ -1,4 +1,5 @@
 set -x
+export EVK_EXPERIMENTAL=1          # the switches below select measured alternatives: honoured only under this flag
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/${1:-r5dprio}
 mkdir -p $O

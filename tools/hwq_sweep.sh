@@ -1,6 +1,7 @@
 # does the number of hardware queues the HIP runtime multiplexes streams onto (GPU_MAX_HW_QUEUES, default 4 per priority) explain the erratic
 # priority results?  eager and replayed steps at 4 / 8 / 16.   usage: bash tools/hwq_sweep.sh <outdir> [res]
 set -x
+export EVK_EXPERIMENTAL=1          # the switches below select measured alternatives: honoured only under this flag
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/${1:-r5hwq}
 RES=${2:-384}

@@ -1,5 +1,6 @@
 # repeatability of the replayed step at several hardware-queue counts, default lane priorities.  usage: bash tools/hwq_sweep2.sh <outdir>
 set -x
+export EVK_EXPERIMENTAL=1          # the switches below select measured alternatives: honoured only under this flag
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/${1:-r5hwq2}
 mkdir -p $O

@@ -1,5 +1,6 @@
 # the replayed step with the hardware-queue check (lanes that share a queue are replaced) over GPU_MAX_HW_QUEUES and stream priorities
 set -x
+export EVK_EXPERIMENTAL=1          # the switches below select measured alternatives: honoured only under this flag
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/${1:-r5hwq3}
 mkdir -p $O

@@ -1,5 +1,6 @@
 # stream priorities of the FineTune step, eager and replayed (round 5).  usage: bash tools/prio_sweep.sh <outdir> [res]
 set -x
+export EVK_EXPERIMENTAL=1          # the switches below select measured alternatives: honoured only under this flag
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/${1:-r5prio}
 RES=${2:-384}

@@ -1,5 +1,6 @@
 # replayed step: priority of the main stream x the relational-memory LANE x the eager relational-memory STREAM (does an idle high-priority stream matter?)
 set -x
+export EVK_EXPERIMENTAL=1          # the switches below select measured alternatives: honoured only under this flag
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/${1:-r5prio3}
 mkdir -p $O

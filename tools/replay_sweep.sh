@@ -1,6 +1,7 @@
 # round 5: the step replayer with lanes = capture streams, with / without pacing, against the eager step on the same box.
 # usage: bash tools/replay_sweep.sh <outdir> [res] [workload]
 set -x
+export EVK_EXPERIMENTAL=1          # the switches below select measured alternatives: honoured only under this flag
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/${1:-r5sweep}
 RES=${2:-384}

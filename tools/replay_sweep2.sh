@@ -1,5 +1,6 @@
 # eager vs replayed step (lanes = capture streams) on the host-bound configurations.   usage: bash tools/replay_sweep2.sh <outdir>
 set -x
+export EVK_EXPERIMENTAL=1          # the switches below select measured alternatives: honoured only under this flag
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/${1:-r5sweep2}
 mkdir -p $O
