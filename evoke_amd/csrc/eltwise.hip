@@ -539,9 +539,12 @@ int evk_embedding_bwd(const void* dout, int d_dtype, const int64_t* ids, float* 
 int evk_colsum(const void* x, float* out, int64_t M, int32_t N, int64_t ld, evk_stream_t stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   EVK_REQUIRE(x && out && M > 0 && N > 0 && ld >= N && ld % 2 == 0, "colsum: bad args (ld must be even)");
+  static const bool probe_skip = evk_tunable("EVK_PROBE_SKIP_COLSUM", 0) != 0;          // timing probe: wrong bias gradients
+  if (probe_skip) return EVK_OK;
   if (ld % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (N % 8 == 0 || ld >= (N + 7) / 8 * 8)) {
     const int gx = (int)cdiv(N, 256);
-    long gy = cdiv(768, gx);
+    static const int target_blocks = evk_tunable("EVK_COLSUM_BLOCKS", 768);
+    long gy = cdiv(target_blocks, gx);
     if (gy > cdiv(M, 32)) gy = cdiv(M, 32);
     if (gy < 1) gy = 1;
     const long rows = cdiv(M, gy);

@@ -1001,6 +1001,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(const SkrP p) {
 // one launch of the reduction: the wide kernel once the output gives every CU a few blocks of whole 4 KB runs (EVK_REDUCE_WIDE=0/1 forces)
 inline int launch_splitk_reduce(const SkrP& r, int batch, hipStream_t s) {
   static const int mode = evk_tunable("EVK_REDUCE_WIDE", -1);
+  static const bool probe_skip = evk_tunable("EVK_PROBE_SKIP_SPLITK_REDUCE", 0) != 0;          // timing probe: wrong weight gradients
+  if (probe_skip) return EVK_OK;
   const long nq = r.mn >> 2;
   const bool wide = mode >= 0 ? mode == 1 : cdiv(nq, 256) * batch >= 192;
   if (wide) hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3((int)cdiv(nq, 256), batch), dim3(256), 0, s, r);
