@@ -543,8 +543,7 @@ int evk_colsum(const void* x, float* out, int64_t M, int32_t N, int64_t ld, evk_
   if (probe_skip) return EVK_OK;
   if (ld % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (N % 8 == 0 || ld >= (N + 7) / 8 * 8)) {
     const int gx = (int)cdiv(N, 256);
-    static const int target_blocks = evk_tunable("EVK_COLSUM_BLOCKS", 768);
-    long gy = cdiv(target_blocks, gx);
+    long gy = cdiv(768, gx);
     if (gy > cdiv(M, 32)) gy = cdiv(M, 32);
     if (gy < 1) gy = 1;
     const long rows = cdiv(M, gy);
