@@ -268,8 +268,8 @@ def test_reducer_collectives_wait_for_the_weight_gradient_stream():
 # not bit-deterministic from run to run (last-bit noise of the column sums), so the comparison uses the tolerances of
 # the graph-vs-eager test, with the run-to-run spread of two non-distributed runs printed beside it; optimizer step counts must be EQUAL.
 # ---------------------------------------------------------------------------------------------------------------------------------
-# FineTune in every gradient-sum mode; Pretrain (the two exchanges of gather_rows on top) in the default mode and in 'direct'
-RCCL_CASES = [('finetune', 'allreduce'), ('finetune', 'direct'), ('finetune', '16bit'), ('pretrain', 'allreduce'), ('pretrain', 'direct')]
+# FineTune in every gradient-sum mode; Pretrain (the two exchanges of gather_rows on top) in the default mode
+RCCL_CASES = [('finetune', 'allreduce'), ('finetune', 'direct'), ('finetune', '16bit'), ('pretrain', 'allreduce')]
 
 
 def _rccl_worker(port, q):
