@@ -5,7 +5,7 @@
 // ~4.5k launches + Python overhead per training step).  Here the host loop lives in C++ and every token is
 //     fwd: 5 GEMM launches (m.[Wq;Wk;Wv], a.Wo + m, relu(.W0), relu(.W2), tanh(m).U) + 1 fused attention kernel
 //          (3 slots x 4 keys x 8 heads per sample, softmax + dropout + PV) + 1 fused gate kernel
-//     bwd: 5 data-gradient GEMMs + gate / relu-mask / attention / combine kernels,
+//     bwd: 5 data-gradient GEMMs + one gate kernel (which also forms the carried gradient of the token before and the first ReLU mask) + the attention kernel,
 // while everything that does not depend on the recurrence is hoisted out of the loop by the caller (x_t.Wk, x_t.Wv and
 // W(x_t) for all t are three ordinary batched GEMMs) and all weight gradients are ONE K = L*B*slots GEMM per weight
 // after the loop (the per-token operands are saved contiguously in the workspace).
@@ -166,6 +166,9 @@ struct GateBP {
   const bf16_t* dout; long dout_bstride; const bf16_t* dcarry; const bf16_t* si; const bf16_t* sf; const bf16_t* tnm; const bf16_t* m;
   bf16_t* dnm2; bf16_t* dmd; bf16_t* dgates; bf16_t* dgw; long dgw_bstride; int B;
   const bf16_t* h2; bf16_t* dh2;          // dh2 = dnm2 * (h2 > 0): the first ReLU mask of the token rides on this launch (or null / null)
+  // the carried memory gradient of the token processed BEFORE this one (t + 1), formed here instead of by a launch of its own (rm_combine_kernel):
+  // carry = round16(dmp + dmd + dtm * (1 - tm^2)) with that token's dmp / dmd / dtm / tm; null: dcarry is read (or there is none)
+  const bf16_t* c_dmp; const bf16_t* c_dmd; const bf16_t* c_dtm; const bf16_t* c_tm;
 };
 __global__ __launch_bounds__(256) void rm_gate_bwd2_kernel(const GateBP p) {
   const long total = (long)p.B * D_;
@@ -177,7 +180,10 @@ __global__ __launch_bounds__(256) void rm_gate_bwd2_kernel(const GateBP p) {
     for (int s = 0; s < S_; ++s) {
       const long e = (b * S_ + s) * D_ + c;
       float g = bf2f(p.dout[b * p.dout_bstride + s * D_ + c]);
-      if (p.dcarry) g += bf2f(p.dcarry[e]);
+      if (p.c_dmp) {          // (c_dmd may be the buffer this thread rewrites below: read first)
+        const float t1 = bf2f(p.c_tm[e]);
+        g += bf2f(f2bf(bf2f(p.c_dmp[e]) + bf2f(p.c_dmd[e]) + bf2f(p.c_dtm[e]) * (1.f - t1 * t1)));
+      } else if (p.dcarry) g += bf2f(p.dcarry[e]);
       const float si = bf2f(p.si[e]), sf = bf2f(p.sf[e]), t = bf2f(p.tnm[e]);
       const bf16_t dn = f2bf(g * si * (1.f - t * t));
       p.dnm2[e] = dn;
@@ -198,15 +204,6 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(const bf16_t* __restrict
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     y[i] = bf2f(ref[i]) > 0.f ? dy[i] : (bf16_t)0;
 }
-// dm = a + dmd + dtm * (1 - tm^2)
-__global__ __launch_bounds__(256) void rm_combine_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ dmd, const bf16_t* __restrict__ dtm,
-                                                         const bf16_t* __restrict__ tm, bf16_t* __restrict__ dm, long n) {
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const float t = bf2f(tm[i]);
-    dm[i] = f2bf(bf2f(a[i]) + bf2f(dmd[i]) + bf2f(dtm[i]) * (1.f - t * t));
-  }
-}
-
 // Measured on MI355X (FineTune 384^2, 32 samples, L = 100; profiles/r02_c_rm_persistent_kernel_stats.csv): persistent forward
 // 15.1 ms + backward 12.5 ms against 5.5 + 5.8 ms of kernel time for the per-token launch sequence -- every workgroup has to
 // pull the 4 MB of weights through ITS OWN vector L1 once per token, and one CU's L1 miss queue sustains ~27 GB/s (the same
@@ -837,7 +834,6 @@ int evk_rm_backward(const void* dout, const void* xk, const void* xv, const void
   EVK_REQUIRE(ws_bytes >= evk_rm_ws_bytes(B, L), "rm_backward: workspace too small");
   Ws w = carve(ws, B, L);
   const long R = w.R, RD = R * D_;
-  const bf16_t* carry = nullptr;
   // timing probe (EVK_EXPERIMENTAL=1 EVK_PROBE_SKIP_RM_BWD=1: wrong gradients): the step without the recurrence's backward chain
   static const bool probe_skip = evk_tunable("EVK_PROBE_SKIP_RM_BWD", 0) != 0;
   if (probe_skip) return EVK_OK;
@@ -856,8 +852,11 @@ int evk_rm_backward(const void* dout, const void* xk, const void* xv, const void
     bf16_t* dnm2 = w.dnm2s + t * RD;            // becomes dnm1 (stack) below
     bf16_t* dh2 = w.dh2s + t * RD;
     bf16_t* dh1 = w.dh1s + t * RD;
-    GateBP gb{(const bf16_t*)dout + (long)t * S_ * D_, (long)L * S_ * D_, carry, w.si + t * RD, w.sf + t * RD, w.tnm + t * RD, w.m + t * RD,
-              w.t_dnm1, w.t_dmd, dgs, (bf16_t*)dgw + (long)t * 2 * D_, (long)L * 2 * D_, B, w.h2 + t * RD, dh2};
+    // (t < L - 1: the carry of token t + 1 is formed from that token's dmp / dmd / dtm, still in the temporaries, and its tanh(m))
+    const bool cf = t < L - 1;
+    GateBP gb{(const bf16_t*)dout + (long)t * S_ * D_, (long)L * S_ * D_, nullptr, w.si + t * RD, w.sf + t * RD, w.tnm + t * RD, w.m + t * RD,
+              w.t_dnm1, w.t_dmd, dgs, (bf16_t*)dgw + (long)t * 2 * D_, (long)L * 2 * D_, B, w.h2 + t * RD, dh2,
+              cf ? w.t_dmp : nullptr, cf ? w.t_dmd : nullptr, cf ? w.t_dtm : nullptr, cf ? w.tm + (t + 1) * RD : nullptr};
     {
       ProfScope ps(EVK_FAM_ELTWISE, s);
       hipLaunchKernelGGL(rm_gate_bwd2_kernel, dim3(ew_blocks((long)B * D_)), dim3(256), 0, s, gb);
@@ -865,7 +864,7 @@ int evk_rm_backward(const void* dout, const void* xk, const void* xv, const void
     // dtm = dgates . U
     if (int e = gemm(dgs, Ut, w.t_dtm, (int)R, D_, 2 * D_, EVK_B_PLAIN, 2 * D_, nullptr, nullptr, EVK_ACT_NONE, stream)) return e;
     // dh2 = dnm2 * (h2 > 0) (written by the gate kernel);  dh1 = (dh2 . W2) * (h1 > 0) (ReLU mask in the product's epilogue);
-    // dnm1 = dh1 . W0 + dnm2        -- 8 launches per token (10 with the two masks as launches of their own)
+    // dnm1 = dh1 . W0 + dnm2        -- (10 launches per token with the two masks and the carry as launches of their own)
     if (int e = gemm(dh2, W2t, dh1, (int)R, D_, D_, EVK_B_PLAIN, D_, nullptr, nullptr, EVK_ACT_NONE, stream, w.h1 + t * RD)) return e;
     if (int e = gemm(dh1, W0t, dnm2, (int)R, D_, D_, EVK_B_PLAIN, D_, nullptr, w.t_dnm1, EVK_ACT_NONE, stream)) return e;   // dnm2 now holds dnm1
     // da = dnm1 . Wo ; attention backward
@@ -879,13 +878,8 @@ int evk_rm_backward(const void* dout, const void* xk, const void* xv, const void
       hipLaunchKernelGGL(rm_attn_bwd_kernel, dim3(B), dim3(256), 0, s, ap);
     }
     // dm(from projections) = dqkv . Wqkv + dnm1
+    // (its sum with dmd and dtm * (1 - tm^2) -- the gradient carried to token t - 1 -- is formed by that token's gate kernel: 7 launches per token)
     if (int e = gemm(dqkv, Wqkvt, w.t_dmp, (int)R, D_, 1536, EVK_B_PLAIN, 1536, nullptr, dnm2, EVK_ACT_NONE, stream)) return e;
-    bf16_t* nc = (t & 1) ? w.t_carry1 : w.t_carry0;
-    {
-      ProfScope ps(EVK_FAM_ELTWISE, s);
-      hipLaunchKernelGGL(rm_combine_kernel, dim3(ew_blocks(RD)), dim3(256), 0, s, w.t_dmp, w.t_dmd, w.t_dtm, w.tm + t * RD, nc, RD);
-    }
-    carry = nc;
   }
   // weight / bias gradients: one GEMM (K = L*R rows) + one column sum per parameter
   const long rows = (long)L * R;
