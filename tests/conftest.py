@@ -28,7 +28,8 @@ def tokenizer():
 # card, far below the box's limit -- and the test only waits for its verdict.  What the child runs: every model-level parity test against its
 # reference and ONE representative per kernel family (the other parametrisations exercise host logic and tile selection that do not depend on
 # the storage format); what it leaves to the default build's pass: multi-process reducer tests, serving-loop driving modes, trainer / optimizer
-# order tests, the forced-tile re-run.
+# order tests, the forced-tile re-run.  (ONE child beside the parent: with the fallback-route child of tests/test_hip_gemm.py started at the same time
+# the three processes oversubscribe the box's 16-CPU share -- the oracle legs of the two-rank tests then take 140 s instead of 20, the suite 717 s.)
 BF16_CHILD_SELECT = ' or '.join([
     # model level
     'finetune_matches_reference', 'pretrain_matches_reference', 'training_forward_log_probabilities', 'trunk_follows_bf16_emulation',
@@ -43,7 +44,6 @@ BF16_CHILD_SELECT = ' or '.join([
     'test_optim_group_step', 'test_native_trunk_matches_module_walk', 'test_decode_attention_matches_reference', 'test_linear_with_layernorm_in_the_operand',
     'test_preprocess_matches_pillow', 'test_dgrad_gate_statistics', 'test_step_graph_replays_the_eager_trajectory', 'test_dynamic_loss_scale_skips'])
 BF16_CHILD = {}
-FALLBACK_CHILD = {}          # the fallback-route child of tests/test_hip_gemm.py (same scheme: started at the end of collection, joined by its test)
 
 
 def start_bf16_child():
@@ -53,16 +53,6 @@ def start_bf16_child():
     cmd = [sys.executable, '-m', 'pytest', os.path.join(REPO, 'tests'), '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider', '-k', BF16_CHILD_SELECT,
            '--durations', '8']
     BF16_CHILD.update(proc=subprocess.Popen(cmd, env=dict(os.environ, EVK_STORE='bf16'), stdout=log, stderr=subprocess.STDOUT, cwd=REPO), log=log)
-
-
-def start_fallback_child():
-    import subprocess
-    import tempfile
-    from tests.test_hip_gemm import FALLBACK_ROUTES, FALLBACK_SELECT
-    log = tempfile.NamedTemporaryFile('w+', prefix='evk_fallback_child_', suffix='.log', delete=False)
-    cmd = [sys.executable, '-m', 'pytest', os.path.join(REPO, 'tests', 'test_hip_gemm.py'), os.path.join(REPO, 'tests', 'test_hip_ops.py'),
-           os.path.join(REPO, 'tests', 'test_model_gpu.py'), '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider', '-k', FALLBACK_SELECT]
-    FALLBACK_CHILD.update(proc=subprocess.Popen(cmd, env=dict(os.environ, **FALLBACK_ROUTES), stdout=log, stderr=subprocess.STDOUT, cwd=REPO), log=log)
 
 
 def pytest_collection_finish(session):
@@ -75,27 +65,23 @@ def pytest_collection_finish(session):
     if ('test_bf16_storage_build_passes_the_gpu_suite' in names and len(names) > 40          # the whole GPU suite, not a hand-picked test
             and os.environ.get('EVK_STORE', 'f16').lower() != 'bf16' and os.environ.get('EVK_BF16_CHILD_INLINE') != '1'):
         start_bf16_child()
-    if ('test_kernel_suite_on_the_fallback_routes' in names and len(names) > 40 and os.environ.get('EVK_TILE256') is None
-            and os.environ.get('EVK_STORE', 'f16').lower() != 'bf16' and os.environ.get('EVK_BF16_CHILD_INLINE') != '1'):
-        start_fallback_child()
 
 
 def pytest_sessionfinish(session, exitstatus):
     """A session that ends before the bf16 test has joined its child (-x after an earlier failure, a keyboard interrupt) must not leave the
     child running on the GPU."""
-    for child in (BF16_CHILD, FALLBACK_CHILD):
-        proc = child.get('proc')
-        if proc is not None and proc.poll() is None:
-            proc.kill()
-            try:
-                proc.wait(timeout=30)
-            except Exception:          # noqa: BLE001
-                pass
-        log = child.get('log')
-        if log is not None:
-            try:
-                log.close()
-                os.unlink(log.name)
-            except OSError:
-                pass
-        child.clear()
+    proc = BF16_CHILD.get('proc')
+    if proc is not None and proc.poll() is None:
+        proc.kill()
+        try:
+            proc.wait(timeout=30)
+        except Exception:          # noqa: BLE001
+            pass
+    log = BF16_CHILD.get('log')
+    if log is not None:
+        try:
+            log.close()
+            os.unlink(log.name)
+        except OSError:
+            pass
+    BF16_CHILD.clear()

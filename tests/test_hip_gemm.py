@@ -336,11 +336,6 @@ FALLBACK_ROUTES = dict(
     EVK_BEAM_STEP_FAST='0', EVK_DECODE_RB_SPLIT='0')                              # batched-walk beam step, one workgroup per row block
 
 
-# what the child runs: the kernel suites + one FineTune parity case, minus the tests that assert a specialised kernel TOOK a launch
-FALLBACK_SELECT = ('(test_hip_gemm or test_hip_ops or (finetune_matches_reference and ft224_inc)) and not strip_gemm_is_what and not fallback_routes '
-                   'and not halo_conv3x3_weight_gradient and not stride2_conv3x3_data_gradient_by_output_parity')
-
-
 @pytest.mark.skipif(os.environ.get('EVK_TILE256') is not None, reason='already running on the fallback routes')
 def test_kernel_suite_on_the_fallback_routes():
     """gemm.hip picks the 256 x 256 / 16-wave tile only for plain NT products of >= 1024 big tiles, the convolutions go to halo / strip /
@@ -348,25 +343,18 @@ def test_kernel_suite_on_the_fallback_routes():
     choice (batched attention scores, linears with bias / activation / residual epilogues and ragged edges on the big tile; every convolution
     on the implicit-GEMM tile path; the trunk runner without its fused statistics), and the kernel tests plus one FineTune parity case run once
     more that way in a child interpreter.  Left out: the tests that assert a specialised kernel TOOK a launch (the strip-GEMM routing test, the
-    halo weight-gradient and stride-2 parity tests, which end with `routed entry point == specialised kernel, bit for bit`).  When the whole GPU
-    suite is collected the child was started at the end of collection (tests/conftest.py) and is only joined here."""
-    from tests import conftest as CT
-    if not CT.FALLBACK_CHILD:
-        CT.start_fallback_child()
-    proc, log = CT.FALLBACK_CHILD['proc'], CT.FALLBACK_CHILD['log']
-    try:
-        rc = proc.wait(timeout=900)
-    finally:
-        if proc.poll() is None:
-            proc.kill()
-    log.flush()
-    log.seek(0)
-    tail = '\n'.join(log.read().splitlines()[-20:])
+    halo weight-gradient and stride-2 parity tests, which end with `routed entry point == specialised kernel, bit for bit`)."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(here, 'test_hip_gemm.py'), os.path.join(here, 'test_hip_ops.py'),
+                        os.path.join(here, 'test_model_gpu.py'), '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider', '-k',
+                        '(test_hip_gemm or test_hip_ops or (finetune_matches_reference and ft224_inc)) and not strip_gemm_is_what and not fallback_routes '
+                        'and not halo_conv3x3_weight_gradient and not stride2_conv3x3_data_gradient_by_output_parity'],
+                       env=dict(os.environ, **FALLBACK_ROUTES), capture_output=True, text=True, timeout=900, cwd=os.path.dirname(here))
+    tail = '\n'.join((r.stdout + r.stderr).splitlines()[-20:])
     print(tail)
-    log.close()
-    os.unlink(log.name)
-    CT.FALLBACK_CHILD.clear()
-    assert rc == 0, tail
+    assert r.returncode == 0, tail
 
 
 WS_SHAPES = [(980, 256, 1024), (4608, 64, 256), (2304, 128, 512), (1154, 512, 2048), (2309, 1024, 256), (1000, 512, 128), (1, 64, 256)]

@@ -22,9 +22,11 @@ def test_every_name_of_the_bf16_child_selection_matches_a_test():
 
 
 def test_the_fallback_route_child_names_existing_tests_and_switches():
-    from tests.test_hip_gemm import FALLBACK_SELECT
+    src = open(os.path.join(HERE, 'test_hip_gemm.py')).read()
     names = _gpu_test_names()
-    for token in re.findall(r'not ([a-z0-9_]+)', FALLBACK_SELECT):
+    for token in re.findall(r'not ([a-z0-9_]+)', src[src.index('def test_kernel_suite_on_the_fallback_routes'):src.index('WS_SHAPES = [')]):
+        if token in ('gpu',):
+            continue
         assert any(token in n for n in names), token
     # every forced switch is one the library actually reads (csrc: evk_tunable("NAME", default))
     from tests.test_hip_gemm import FALLBACK_ROUTES
