@@ -349,7 +349,10 @@ def test_kernel_suite_on_the_fallback_routes():
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(here, 'test_hip_gemm.py'), os.path.join(here, 'test_hip_ops.py'),
                         os.path.join(here, 'test_model_gpu.py'), '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider', '-k',
-                        '(test_hip_gemm or test_hip_ops or (finetune_matches_reference and ft224_inc)) and not strip_gemm_is_what and not fallback_routes '
+                        # the tests whose launches pass through a forced switch: products and linears (big tile, tile-kernel weight gradients),
+                        # convolutions / stem / trunk runner / batch norm (implicit-GEMM and unfused-statistics routes), beam step, row blocks
+                        '(gemm_ or linear or attention or conv or stem or trunk or batchnorm or dgrad or gate_statistics or beam_step or rowblock or '
+                        '(finetune_matches_reference and ft224_inc)) and not strip_gemm_is_what and not fallback_routes '
                         'and not halo_conv3x3_weight_gradient and not stride2_conv3x3_data_gradient_by_output_parity'],
                        env=dict(os.environ, **FALLBACK_ROUTES), capture_output=True, text=True, timeout=900, cwd=os.path.dirname(here))
     tail = '\n'.join((r.stdout + r.stderr).splitlines()[-20:])
